@@ -1,0 +1,188 @@
+"""ctypes view of the C ABI declared in include/fastnn.h.
+
+`Api(lib, prefix)` binds one shared library.  The product uses
+`Api(libfastnn_hip.so, "fnn_")`; the CPU tests reuse the same class for the
+emulation driver (`tests/emu`, prefix "emu_"), which exports the same entry
+points over the same host logic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+FNN_OK = 0
+STATUS_NAMES = {0: "FNN_OK", -1: "FNN_EINVAL", -2: "FNN_ENOMEM", -3: "FNN_EHIP", -4: "FNN_ERCCL",
+                -5: "FNN_ESTATE"}
+
+KIND_2WAY, KIND_3WAY, KIND_4WAY, KIND_FINISH = 2, 3, 4, 5
+
+
+class FnnOpts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("validate", C.c_int32), ("record_events", C.c_int32),
+                ("reserved", C.c_int32 * 13)]
+
+
+class FnnEvent(C.Structure):
+    _fields_ = [("m_before", C.c_int32), ("c_before", C.c_int32), ("cx_id", C.c_int32),
+                ("cy_id", C.c_int32), ("x_id", C.c_int32), ("y_id", C.c_int32), ("kind", C.c_int32),
+                ("u_id", C.c_int32), ("best", C.c_double), ("entries", C.c_int64)]
+
+    def key(self):
+        return (self.m_before, self.c_before, self.cx_id, self.cy_id, self.x_id, self.y_id,
+                self.kind, self.u_id)
+
+
+class FnnStats(C.Structure):
+    _fields_ = [("n_events", C.c_int64), ("sum_entries", C.c_int64), ("t_init_s", C.c_double),
+                ("t_agglom_s", C.c_double), ("t_expand_s", C.c_double), ("t_total_s", C.c_double),
+                ("t_scan_s", C.c_double), ("scan_launches", C.c_int64), ("scan_bytes", C.c_int64),
+                ("reserved", C.c_int64 * 8)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+EVENT_DTYPE = np.dtype(
+    [("m_before", "<i4"), ("c_before", "<i4"), ("cx_id", "<i4"), ("cy_id", "<i4"),
+     ("x_id", "<i4"), ("y_id", "<i4"), ("kind", "<i4"), ("u_id", "<i4"),
+     ("best", "<f8"), ("entries", "<i8")], align=True)
+
+
+class FnnError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{STATUS_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class Api:
+    def __init__(self, lib: C.CDLL, prefix: str):
+        self.lib = lib
+        self.prefix = prefix
+        f = self._fn
+        f("last_error", C.c_char_p, [])
+        f("create", C.c_int32, [C.c_int32, C.POINTER(FnnOpts), C.POINTER(C.c_void_p)])
+        f("destroy", C.c_int32, [C.c_void_p])
+        f("set_rows", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _dp, C.c_int64])
+        f("synth", C.c_int32, [C.c_void_p, C.c_uint64, C.c_int32])
+        f("run", C.c_int32, [C.c_void_p, _ip, C.POINTER(FnnStats)])
+        f("begin", C.c_int32, [C.c_void_p])
+        f("step", C.c_int32, [C.c_void_p, C.POINTER(FnnEvent)])
+        f("finish", C.c_int32, [C.c_void_p, _ip])
+        f("get_events", C.c_int64, [C.c_void_p, C.c_void_p, C.c_int64])
+        f("get_counts", C.c_int32, [C.c_void_p, _ip, _ip, _ip])
+        f("get_nodes", C.c_int32, [C.c_void_p, _ip, _ip, _dp])
+        f("get_live_matrix", C.c_int32, [C.c_void_p, _dp])
+
+    def _fn(self, name, restype, argtypes, optional=False):
+        try:
+            fn = getattr(self.lib, self.prefix + name)
+        except AttributeError:
+            if optional:
+                return None
+            raise
+        fn.restype = restype
+        fn.argtypes = argtypes
+        setattr(self, name, fn)
+        return fn
+
+    def check(self, rc):
+        if rc < 0:
+            raise FnnError(rc, (self.last_error() or b"").decode("utf-8", "replace"))
+        return rc
+
+
+class Handle:
+    """Thin RAII wrapper over an engine handle of either library."""
+
+    def __init__(self, api: Api, n: int, device: int = 0, validate: bool = False,
+                 record_events: bool = False):
+        self.api = api
+        self.n = int(n)
+        opts = FnnOpts()
+        opts.device = device
+        opts.validate = 1 if validate else 0
+        opts.record_events = 1 if record_events else 0
+        h = C.c_void_p()
+        api.check(api.create(self.n, C.byref(opts), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.api.destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- matrix --
+    def set_matrix(self, D: np.ndarray, chunk_rows: int = 0):
+        D = np.ascontiguousarray(D, dtype=np.float64)
+        if D.shape != (self.n, self.n):
+            raise ValueError(f"matrix must be {self.n} x {self.n}")
+        step = chunk_rows if chunk_rows > 0 else max(self.n, 1)
+        for r0 in range(0, self.n, step):
+            cnt = min(step, self.n - r0)
+            self.api.check(self.api.set_rows(self._h, r0, cnt, D[r0:].ctypes.data_as(_dp), self.n))
+
+    def synth(self, seed: int, dist: str = "uniform53"):
+        self.api.check(self.api.synth(self._h, seed, {"uniform53": 0, "dec4": 1}[dist]))
+
+    # -- run --
+    def run(self):
+        order = np.zeros(self.n + 1, dtype=np.int32)
+        st = FnnStats()
+        self.api.check(self.api.run(self._h, order.ctypes.data_as(_ip), C.byref(st)))
+        return order, st
+
+    def begin(self):
+        self.api.check(self.api.begin(self._h))
+
+    def step(self):
+        ev = FnnEvent()
+        r = self.api.check(self.api.step(self._h, C.byref(ev)))
+        return ev if r == 1 else None
+
+    def finish(self):
+        order = np.zeros(self.n + 1, dtype=np.int32)
+        self.api.check(self.api.finish(self._h, order.ctypes.data_as(_ip)))
+        return order
+
+    def events(self) -> np.ndarray:
+        k = self.api.get_events(self._h, None, 0)
+        out = np.zeros(max(k, 1), dtype=EVENT_DTYPE)
+        self.api.get_events(self._h, out.ctypes.data, k)
+        return out[:k]
+
+    def counts(self):
+        m, c, nn = C.c_int32(), C.c_int32(), C.c_int32()
+        self.api.check(self.api.get_counts(self._h, C.byref(m), C.byref(c), C.byref(nn)))
+        return m.value, c.value, nn.value
+
+    def nodes(self):
+        m, _, _ = self.counts()
+        ids = np.zeros(max(self.n, 1), np.int32)
+        nbr = np.zeros(max(self.n, 1), np.int32)
+        sx = np.zeros(max(self.n, 1), np.float64)
+        self.api.check(self.api.get_nodes(self._h, ids.ctypes.data_as(_ip), nbr.ctypes.data_as(_ip),
+                                          sx.ctypes.data_as(_dp)))
+        return ids[:m], nbr[:m], sx[:m]
+
+    def live_matrix(self) -> np.ndarray:
+        m, _, _ = self.counts()
+        out = np.zeros((m, m), dtype=np.float64)
+        self.api.check(self.api.get_live_matrix(self._h, out.ctypes.data_as(_dp)))
+        return out

@@ -1,0 +1,71 @@
+"""Builds libfastnn_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libfastnn_hip.so")
+SRC = os.path.join(HERE, "csrc", "fnn_hip.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "fnn_core.h"), os.path.join(HERE, "csrc", "fnn_engine.h"),
+        os.path.join(ROOT, "include", "fastnn.h")]
+
+# -ffp-contract=off: one rounding per fp64 operation on host and device (parity with Java doubles)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-parameter"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libfastnn_hip.so cannot be built (no CPU fallback exists)")
+
+
+def stale() -> bool:
+    return (not os.path.exists(LIB)) or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in DEPS)
+
+
+def check_isa() -> None:
+    """hipcc (ROCm 7.2, LLVM 22 git) was seen to lower a uniform `cond ? a : b` whose
+    condition is a VALU compare of uniform values held in VGPRs to `v_cmp` + `s_cselect`
+    without moving VCC into SCC, so the select read a stale SCC.  Scan the device ISA for
+    an s_cselect / s_cbranch_scc whose SCC producer is not a compare and refuse the build."""
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "fnn.s")
+        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                               "-S", "--cuda-device-only", "-o", asm, SRC], stderr=subprocess.DEVNULL)
+        writers = re.compile(r"^\s*(s_cmp|s_bitcmp|s_cmpk|s_add|s_sub|s_addc|s_subb|s_and|s_or|s_xor|s_not|s_lshl|"
+                             r"s_lshr|s_ashr|s_min|s_max|s_abs|s_andn2|s_orn2|s_nand|s_nor|s_xnor|s_bfe|"
+                             r"s_absdiff|s_wqm|s_quadmask|s_bcnt|s_ff|s_flbit|s_addk)")
+        cmp_like = re.compile(r"^\s*(s_cmp|s_bitcmp|s_cmpk|s_and_b64|s_or_b64|s_andn2_b64|s_and_b32|s_or_b32|"
+                              r"s_xor_b64|s_orn2_b64)")
+        last, kern, bad = None, None, []
+        for i, line in enumerate(open(asm), 1):
+            m = re.match(r"^(_Z\w+):", line)
+            if m:
+                kern, last = m.group(1), None
+            t = line.strip()
+            if t.startswith("s_cselect") or t.startswith("s_cbranch_scc"):
+                if last is None or not cmp_like.match(last):
+                    bad.append(f"{kern}:{i}: {t} (SCC from: {last.strip() if last else None})")
+            if writers.match(line):
+                last = line
+        if bad:
+            raise RuntimeError("suspicious SCC use in device ISA (compiler miscompile?):\n" + "\n".join(bad))
+
+
+def build(force: bool = False) -> str:
+    if force or stale():
+        check_isa()
+        cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC]
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))

@@ -1,0 +1,78 @@
+"""Host-side mirror of the reference's plug-in seam for the Canonical path.
+
+Reference: `class NeighborNetCanonical extends NetMakerOriginal`
+(NeighborNetCanonical.java:29-36), constructed by FastNN.main for `-mode Canonical`
+(FastNN.java:324-328) and driven by one call to `runNeighborNet()`
+(NetMakerOriginal.java:129-162, FastNN.java:378/:391).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+class NeighborNetCanonical:
+    """Same constructor shape and method name as the Java class.
+
+    d          -- n x n symmetric fp64 distance matrix with zero diagonal (`double[][] d`).
+                  Unlike the reference (NetMakerOriginal.java:653-656) the caller's array
+                  is not modified.
+    numTaxa    -- number of taxa (`ntax`)
+    numThreads -- accepted for signature compatibility; the GPU engine always produces the
+                  `-threads 1` result (the reference's pool branch is not deterministic,
+                  SURVEY.md F7)
+    pool       -- ignored (the Java ExecutorService)
+    """
+
+    def __init__(self, d, numTaxa: int, numThreads: int = 1, pool=None, *, device: int = 0,
+                 validate: bool = True, record_events: bool = False):
+        from . import api
+        self._api = api()
+        self.ntax = int(numTaxa)
+        self.numThreads = int(numThreads)
+        self.pool = pool
+        self.D = np.ascontiguousarray(d, dtype=np.float64)
+        if self.D.shape != (self.ntax, self.ntax):
+            raise ValueError(f"d must be {self.ntax} x {self.ntax}")
+        self._device = device
+        self._validate = validate
+        self._record = record_events
+        self.ordering = None
+        self.stats = None
+        self.events = None
+
+    def runNeighborNet(self) -> np.ndarray:
+        """int[ntax+1]: ordering[0] = 0, ordering[1] = 1, 1-based ids in circular order."""
+        if self.ntax <= 3:  # NetMakerOriginal.java:133-140
+            self.ordering = np.arange(self.ntax + 1, dtype=np.int32)
+            return self.ordering
+        with _capi.Handle(self._api, self.ntax, device=self._device, validate=self._validate,
+                          record_events=self._record) as h:
+            h.set_matrix(self.D)
+            order, st = h.run()
+            if self._record:
+                self.events = h.events()
+        self.ordering = order
+        self.stats = st.as_dict()
+        return order
+
+    def getOrdering(self):  # NetMakerOriginal.java:72-74
+        return self.ordering
+
+
+def canonical_order(D: np.ndarray, device: int = 0, validate: bool = True) -> np.ndarray:
+    """One-call form over `fnn_canonical_order_f64`."""
+    from . import api
+    a = api()
+    D = np.ascontiguousarray(D, dtype=np.float64)
+    n = D.shape[0]
+    order = np.zeros(n + 1, dtype=np.int32)
+    opts = _capi.FnnOpts()
+    opts.device = device
+    opts.validate = 1 if validate else 0
+    a.check(a.canonical_order_f64(D.ctypes.data_as(C.POINTER(C.c_double)), n, n, C.byref(opts),
+                                  order.ctypes.data_as(C.POINTER(C.c_int32)), None))
+    return order

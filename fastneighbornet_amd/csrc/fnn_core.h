@@ -1,0 +1,528 @@
+// fnn_core.h -- per-thread bodies of the Canonical Neighbor-Net engine.
+//
+// Everything here is a __host__ __device__ function over plain pointers: the HIP
+// kernels in fnn_kernels.hip are thin wrappers that map (block, thread) to the
+// arguments of these bodies, and tests/emu/fnn_emu.cpp drives the SAME bodies in
+// loops on the CPU so that the slot bookkeeping can be checked against the oracle
+// without a GPU.  The emulation driver is test infrastructure; the product path
+// is the HIP build only.
+//
+// ---------------------------------------------------------------------------
+// Layout ("slots").  The reference keeps nodes in a packed array netNodes[0..m)
+// (NetMakerOriginal.java:141-150) and addresses the matrix through node.distID.
+// We keep the n x n fp64 matrix in SLOT order instead: live nodes occupy slots
+// [0, m); slots [0, 2P) hold the P two-node clusters, the cluster's smaller id
+// (its representative, NeighborNetCanonical.java:153) in the even slot and its
+// partner (NetNode.nbr) in the odd slot; slots [2P, m) hold singletons.  A
+// cluster pair therefore owns a dense 2x2 / 1x2 / 1x1 block of the matrix and the
+// scan streams the lower triangle of the leading m x m block with no indirection.
+// The reference's own position of a node (NetNode.positionID) decides tie-breaks
+// and the order of the three sequential sums, so it is carried per slot (spos)
+// together with its inverse (pslot).
+//
+// All fp64 expressions are written in the reference's evaluation order and the
+// translation units are compiled with -ffp-contract=off.
+// ---------------------------------------------------------------------------
+#ifndef FNN_CORE_H
+#define FNN_CORE_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FNN_HD __host__ __device__ __forceinline__
+#else
+#define FNN_HD inline
+#endif
+
+namespace fnn {
+
+constexpr int OP_NONE = 0;
+constexpr int OP_SWAP = 1;  // exchange slots a <-> b
+constexpr int OP_MOVE = 2;  // move slot a into dead slot b
+constexpr int OP_AGG3 = 3;  // agg3way: rows X=a, Y=b, Z=c -> new rows U=d, V=e
+constexpr int MAX_OPS = 6;
+
+constexpr int KIND_2WAY = 2, KIND_3WAY = 3, KIND_4WAY = 4, KIND_FINISH = 5;
+
+struct Op {
+    int32_t kind, a, b, c, d, e;
+    int32_t mcur;  // slots [0, mcur) are swept
+    int32_t flag;  // AGG3: 1 if pos(u) < pos(v) (aliasing rule, see agg3_special)
+};
+
+// scan candidate: q = +inf means "none"; key = (i << 32) | j, i > j reference positions
+struct Cand {
+    double q;
+    uint64_t key;
+};
+
+struct Event {  // == fnn_event / nno_event
+    int32_t m_before, c_before, cx_id, cy_id, x_id, y_id, kind, u_id;
+    double best;
+    int64_t entries;
+};
+
+struct Agg3Rec {  // one agg3way call: u = (x,y), v = (y,z); v.id = u_id + 1
+    int32_t u_id, x_id, y_id, z_id;
+};
+
+struct State {
+    int32_t n, m, c, P, num_nodes, done, n_agg3, record_events;
+    int64_t n_events, sum_entries;
+    int32_t error;  // non-zero if an "unreachable" branch was taken
+    // ---- current event ----
+    int32_t ev_active, ev_finish, need_rx;
+    int32_t sa, sap, sb, sbp;  // slots of Cx, Cx.nbr, Cy, Cy.nbr (-1: none)
+    int32_t m_old, P_old, c_old;
+    int32_t xs, ys;            // slots (old layout) of the chosen x, y
+    int32_t U;                 // slot (new layout) of the node u returned by the merge
+    int32_t nops;
+    Op ops[MAX_OPS];
+    Event cur;
+};
+
+struct Dev {
+    double* D;       // slot-ordered matrix, row stride ld
+    int64_t ld;
+    int32_t n;
+    double* Sx;      // per slot: NetNode.Sx
+    int32_t* sid;    // per slot: NetNode.id
+    int32_t* spos;   // per slot: NetNode.positionID
+    int32_t* pslot;  // reference position -> slot (-1 if empty)
+    double* chain;   // 4 buffers of n doubles, indexed by reference position
+    Cand* recs;      // per-block scan records
+    State* st;
+    Event* evlog;    // n records (if record_events)
+    Agg3Rec* agglog; // n records
+};
+
+FNN_HD double inf_f64() {
+    union { uint64_t u; double d; } v;
+    v.u = 0x7FF0000000000000ULL;
+    return v.d;
+}
+
+FNN_HD bool cand_better(const Cand& a, const Cand& b) {
+    // total order (Q, i, j): the reference keeps the FIRST strict minimum of its
+    // (i asc, j asc) scan (NeighborNetCanonical.java:173), i.e. the argmin on this order
+    return a.q < b.q || (a.q == b.q && a.key < b.key);
+}
+
+FNN_HD void consider(double q, int32_t pa, int32_t pb, Cand& best) {
+    uint32_t i = (uint32_t)(pa > pb ? pa : pb), j = (uint32_t)(pa > pb ? pb : pa);
+    Cand c;
+    c.q = q;
+    c.key = ((uint64_t)i << 32) | (uint64_t)j;
+    if (cand_better(c, best)) best = c;
+}
+
+// Qpq = ((double)num_clusters - 2.0) * Dpq - p.Sx - q.Sx with p the node at the
+// LARGER reference position (NeighborNetCanonical.java:152,156,170)
+FNN_HD double qval(double cm2, double dpq, double sxa, int32_t pa, double sxb, int32_t pb) {
+    double sp = pa > pb ? sxa : sxb;
+    double sq = pa > pb ? sxb : sxa;
+    return (cm2 * dpq - sp) - sq;
+}
+
+// One 2x2 micro-tile of the scan: rows r0, r0+1 (r0 even), columns c0, c0+1
+// (c0 even, c0 <= r0).  e[r][c] are the four matrix entries.  Sx / pos of the two
+// rows and two columns are passed in.  Follows NeighborNetCanonical.java:151-178.
+FNN_HD void scan_micro(int32_t r0, int32_t c0, int32_t m, int32_t twoP, double cm2,
+                       double e00, double e01, double e10, double e11,
+                       double sxr0, double sxr1, int32_t pr0, int32_t pr1,
+                       double sxc0, double sxc1, int32_t pc0, int32_t pc1, Cand& best) {
+    if (r0 >= m || c0 >= m) return;
+    if (r0 < twoP) {
+        // rows are one two-node cluster; c0 <= r0 < 2P so the columns are one too
+        if (r0 == c0) return;  // same cluster (q.nbr == p, :160)
+        // p = representative at the larger reference position; 4-term mean in the
+        // order D[p][q] + D[p][q.nbr] + D[p.nbr][q] + D[p.nbr][q.nbr]  (:169)
+        double dpq;
+        if (pr0 > pc0) dpq = (((e00 + e01) + e10) + e11) / 4.0;
+        else dpq = (((e00 + e10) + e01) + e11) / 4.0;
+        consider(qval(cm2, dpq, sxr0, pr0, sxc0, pc0), pr0, pc0, best);
+    } else if (c0 < twoP) {
+        // rows are singletons, columns one two-node cluster: 2-term mean (:165/:167,
+        // the two forms add the same two entries in the same order)
+        double d0 = (e00 + e01) / 2.0;
+        consider(qval(cm2, d0, sxr0, pr0, sxc0, pc0), pr0, pc0, best);
+        if (r0 + 1 < m) {
+            double d1 = (e10 + e11) / 2.0;
+            consider(qval(cm2, d1, sxr1, pr1, sxc0, pc0), pr1, pc0, best);
+        }
+    } else {
+        // singletons x singletons: Dpq = D[p][q] (:163); only row > column
+        bool c1ok = (c0 + 1 < m), r1ok = (r0 + 1 < m);
+        if (r0 > c0) {
+            consider(qval(cm2, e00, sxr0, pr0, sxc0, pc0), pr0, pc0, best);
+            if (c1ok) consider(qval(cm2, e01, sxr0, pr0, sxc1, pc1), pr0, pc1, best);
+            if (r1ok) {
+                consider(qval(cm2, e10, sxr1, pr1, sxc0, pc0), pr1, pc0, best);
+                if (c1ok) consider(qval(cm2, e11, sxr1, pr1, sxc1, pc1), pr1, pc1, best);
+            }
+        } else {  // diagonal micro-tile: only (r0+1, c0)
+            if (r1ok) consider(qval(cm2, e10, sxr1, pr1, sxc0, pc0), pr1, pc0, best);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// plan building (single thread)
+// ---------------------------------------------------------------------------
+FNN_HD void emit(State& st, int32_t kind, int32_t a, int32_t b, int32_t c, int32_t d, int32_t e,
+                 int32_t flag) {
+    if (st.nops >= MAX_OPS) { st.error = 2; return; }
+    Op& o = st.ops[st.nops++];
+    o.kind = kind; o.a = a; o.b = b; o.c = c; o.d = d; o.e = e;
+    o.mcur = st.m_old;
+    o.flag = flag;
+}
+
+FNN_HD void swap_slots(const Dev& d, int32_t s1, int32_t s2) {
+    int32_t t = d.sid[s1]; d.sid[s1] = d.sid[s2]; d.sid[s2] = t;
+    t = d.spos[s1]; d.spos[s1] = d.spos[s2]; d.spos[s2] = t;
+    d.pslot[d.spos[s1]] = s1;
+    d.pslot[d.spos[s2]] = s2;
+    emit(*d.st, OP_SWAP, s1, s2, 0, 0, 0, 0);
+}
+
+FNN_HD void move_slot(const Dev& d, int32_t src, int32_t dst) {
+    d.sid[dst] = d.sid[src];
+    d.spos[dst] = d.spos[src];
+    d.pslot[d.spos[dst]] = dst;
+    emit(*d.st, OP_MOVE, src, dst, 0, 0, 0, 0);
+}
+
+// Integer side of agg3way(x, y, z, ..., num_nodes = nn, num_active = mc)
+// (NetMakerOriginal.java:608-648): nodes x, y, z sit in slots X, Y, Z; the new
+// nodes u (id nn+1) and v (id nn+2) are put in slots U and V, both in {X,Y,Z}.
+FNN_HD void agg3_plan(const Dev& d, int32_t X, int32_t Y, int32_t Z, int32_t U, int32_t V,
+                      int32_t nn, int32_t mc) {
+    State& st = *d.st;
+    int32_t px = d.spos[X], py = d.spos[Y], pz = d.spos[Z];
+    Agg3Rec& r = d.agglog[st.n_agg3++];
+    r.u_id = nn + 1; r.x_id = d.sid[X]; r.y_id = d.sid[Y]; r.z_id = d.sid[Z];
+    d.sid[U] = nn + 1;  // u replaces x in the list (:623-625)
+    d.sid[V] = nn + 2;  // v replaces z (:630-632)
+    d.spos[U] = px;
+    d.spos[V] = pz;
+    d.pslot[px] = U;
+    d.pslot[pz] = V;
+    // remove y: netNodes[y.pos] = netNodes[mc-1] (:641-643)
+    int32_t last = d.pslot[mc - 1];
+    if (py != mc - 1) {
+        d.spos[last] = py;
+        d.pslot[py] = last;
+    }
+    d.pslot[mc - 1] = -1;
+    emit(st, OP_AGG3, X, Y, Z, U, V, d.spos[U] < d.spos[V] ? 1 : 0);
+}
+
+// Special finish, NetMakerOriginal.java:343-360 (num_active == 4, num_clusters == 2)
+FNN_HD void finish_plan(const Dev& d) {
+    State& st = *d.st;
+    const double* D = d.D; const int64_t ld = d.ld;
+    st.ev_finish = 1;
+    st.need_rx = 0;
+    int32_t ps = d.pslot[0];
+    int32_t qs = d.pslot[1];
+    if (qs == (ps ^ 1)) qs = d.pslot[2];
+    int32_t pn = ps ^ 1, qn = qs ^ 1;
+    int32_t X = ps, Y, Z;
+    if (D[ps * ld + qs] + D[pn * ld + qn] < D[ps * ld + qn] + D[pn * ld + qs]) { Y = qs; Z = qn; }
+    else { Y = qn; Z = qs; }
+    st.cur.kind = KIND_FINISH;
+    st.cur.x_id = d.sid[ps];
+    st.cur.y_id = d.sid[Y];
+    st.cur.u_id = st.num_nodes + 1;
+    int32_t k = qs >> 1;
+    agg3_plan(d, X, Y, Z, 2 * k, 2 * k + 1, st.num_nodes, 4);
+    st.num_nodes += 2;
+    st.U = 2 * k;
+}
+
+// After the scan: turn the best candidate into Cx, Cy (NetMakerOriginal.java:376-380)
+FNN_HD void pick(const Dev& d, Cand best) {
+    State& st = *d.st;
+    st.ev_active = 0;
+    if (st.done) return;
+    if (st.m <= 3) { st.done = 1; return; }
+    st.ev_active = 1;
+    st.ev_finish = 0;
+    st.nops = 0;
+    st.m_old = st.m; st.P_old = st.P; st.c_old = st.c;
+    Event& cur = st.cur;
+    cur.m_before = st.m; cur.c_before = st.c;
+    cur.cx_id = cur.cy_id = cur.x_id = cur.y_id = cur.kind = cur.u_id = 0;
+    cur.best = 0.0; cur.entries = 0;
+    if (st.m == 4 && st.c == 2) { finish_plan(d); return; }
+    cur.entries = (int64_t)st.m * (st.m - 1) / 2 - (st.m - st.c);
+    cur.best = best.q;
+    int32_t i = (int32_t)(best.key >> 32), j = (int32_t)(best.key & 0xFFFFFFFFu);
+    int32_t a = d.pslot[i], b = d.pslot[j];  // Cx = p, Cy = q
+    if (d.sid[a] > d.sid[b]) { int32_t t = a; a = b; b = t; }
+    int32_t twoP = 2 * st.P;
+    st.sa = a; st.sb = b;
+    st.sap = a < twoP ? (a ^ 1) : -1;
+    st.sbp = b < twoP ? (b ^ 1) : -1;
+    st.need_rx = (st.sap >= 0 || st.sbp >= 0) ? 1 : 0;
+    cur.cx_id = d.sid[a];
+    cur.cy_id = d.sid[b];
+}
+
+// ComputeRx term for slot s (NetMakerOriginal.java:555-558), written to the chain
+// buffer at the node's reference position
+FNN_HD void rx_fill_thread(const Dev& d, int32_t s) {
+    const State& st = *d.st;
+    if (s >= st.m_old) return;
+    int32_t twoP = 2 * st.P_old;
+    bool full = (s == st.sa || s == st.sap || s == st.sb || s == st.sbp || s >= twoP);
+    int32_t pos = d.spos[s];
+    int32_t z[4] = {st.sa, st.sap, st.sb, st.sbp};
+    for (int k = 0; k < 4; k++) {
+        if (z[k] < 0) continue;
+        double v = d.D[(int64_t)z[k] * d.ld + s];
+        d.chain[(int64_t)k * d.n + pos] = full ? v : v / 2.0;
+    }
+}
+
+// Rx = 0.0; for i in position order: Rx += term  (sequential, :551-560)
+FNN_HD double chain_sum(const double* buf, int32_t m) {
+    double s = 0.0;
+    for (int32_t i = 0; i < m; i++) s += buf[i];
+    return s;
+}
+
+// handleAgglomerationEvent: candidate choice (:422-452), bookkeeping of the merge
+// (:462-488) and the micro-op plan for the matrix.  rx = {Rx(Cx), Rx(Cx.nbr),
+// Rx(Cy), Rx(Cy.nbr)}, 0.0 where the reference leaves the 0.0 initialiser.
+FNN_HD void decide(const Dev& d, const double rx[4]) {
+    State& st = *d.st;
+    const double* D = d.D; const int64_t ld = d.ld;
+    Event& cur = st.cur;
+    int32_t a = st.sa, ap = st.sap, b = st.sb, bp = st.sbp;
+    int32_t mm = st.c;
+    if (ap >= 0) mm++;
+    if (bp >= 0) mm++;
+    double f = (double)mm - 2.0;
+    int32_t x = a, y = b;
+    double best = f * D[a * ld + b] - rx[0] - rx[2];
+    if (ap >= 0) {
+        double q = f * D[ap * ld + b] - rx[1] - rx[2];
+        if (q < best) { x = ap; y = b; best = q; }
+    }
+    if (bp >= 0) {
+        double q = f * D[a * ld + bp] - rx[0] - rx[3];
+        if (q < best) { x = a; y = bp; best = q; }
+    }
+    if (ap >= 0 && bp >= 0) {
+        double q = f * D[ap * ld + bp] - rx[1] - rx[3];
+        if (q < best) { x = ap; y = bp; best = q; }
+    }
+    int32_t twoP = 2 * st.P;
+    int32_t xn = x < twoP ? (x ^ 1) : -1;
+    int32_t yn = y < twoP ? (y ^ 1) : -1;
+    st.xs = x; st.ys = y;
+    cur.x_id = d.sid[x];
+    cur.y_id = d.sid[y];
+    int32_t m = st.m, P = st.P, nn = st.num_nodes;
+
+    if (xn < 0 && yn < 0) {
+        // agg2way (:570-577): both isolated. New two-node cluster goes to slots 2P, 2P+1,
+        // smaller id in the even slot.
+        cur.kind = KIND_2WAY;
+        int32_t lo = d.sid[x] < d.sid[y] ? x : y;
+        int32_t hi = (lo == x) ? y : x;
+        cur.u_id = d.sid[x];  // agg2way returns x
+        int32_t t0 = 2 * P, t1 = 2 * P + 1;
+        if (lo != t0) { swap_slots(d, lo, t0); if (hi == t0) hi = lo; }
+        if (hi != t1) swap_slots(d, hi, t1);
+        st.P = P + 1;
+        st.c -= 1;
+        st.U = t0;  // u = x, and x always has the smaller id (Cx.id < Cy.id, :376-380)
+        if (d.sid[t0] != cur.u_id) st.error = 3;
+    } else if (xn < 0 || yn < 0) {
+        // agg3way(x, y, y.nbr) (:466) or agg3way(y, x, x.nbr) (:476)
+        cur.kind = KIND_3WAY;
+        int32_t X, Y, Z;
+        if (xn < 0) { X = x; Y = y; Z = yn; }
+        else { X = y; Y = x; Z = xn; }
+        int32_t k = Y >> 1;
+        cur.u_id = nn + 1;
+        agg3_plan(d, X, Y, Z, 2 * k, 2 * k + 1, nn, m);
+        if (X != m - 1) move_slot(d, m - 1, X);  // close the hole in the singleton region
+        st.num_nodes = nn + 2;
+        st.m = m - 1;
+        st.c -= 1;
+        st.U = 2 * k;
+    } else {
+        if (m == 4) st.error = 4;  // (:474) unreachable: m == 4 with two pairs is the special finish
+        // agg4way(x.nbr, x, y, y.nbr) (:484, :707-726): two agg3way calls
+        cur.kind = KIND_4WAY;
+        int32_t kx = x >> 1, ky = y >> 1;
+        int32_t U = 2 * kx, V = 2 * kx + 1;
+        agg3_plan(d, xn, x, y, U, V, nn, m);          // u1 = (x2,x), v1 = (x,y)
+        agg3_plan(d, U, V, yn, U, V, nn + 2, m - 1);  // u2 = (u1,v1), v2 = (v1,y2)
+        cur.u_id = nn + 3;
+        // slots 2ky, 2ky+1 are now empty: refill from the last pair, then shrink the pair
+        // region by one and refill its last two slots from the end of the singleton region
+        int32_t lastp = P - 1;
+        if (ky != lastp) {
+            move_slot(d, 2 * lastp, 2 * ky);
+            move_slot(d, 2 * lastp + 1, 2 * ky + 1);
+            if (kx == lastp) U = 2 * ky;
+        }
+        int32_t h0 = 2 * lastp, h1 = 2 * lastp + 1;
+        int32_t S = m - 2 * P;
+        if (S >= 1) move_slot(d, m - 1, h0);
+        if (S >= 2) move_slot(d, m - 2, h1);
+        st.P = P - 1;
+        st.num_nodes = nn + 4;
+        st.m = m - 2;
+        st.c -= 1;
+        st.U = U;
+    }
+}
+
+// subtractClusterDistance(p, x); subtractClusterDistance(p, y) for p = node in slot s
+// (NetMakerOriginal.java:455-461, 681-696).  Old layout.
+FNN_HD void subtract_thread(const Dev& d, int32_t s) {
+    const State& st = *d.st;
+    if (s >= st.m_old) return;
+    if (s == st.xs || s == st.ys) return;  // i != x.positionID && i != y.positionID
+    int32_t twoP = 2 * st.P_old;
+    bool sp = s < twoP;
+    if (sp && (s & 1)) return;  // not the representative
+    const double* D = d.D; const int64_t ld = d.ld;
+    double sx = d.Sx[s];
+    double sxn = sp ? d.Sx[s ^ 1] : 0.0;
+    for (int k = 0; k < 2; k++) {
+        int32_t t = k == 0 ? st.xs : st.ys;
+        int32_t tn = t < twoP ? (t ^ 1) : -1;
+        if (s == t || s == tn) continue;
+        double v;
+        if (!sp && tn < 0) v = D[t * ld + s];
+        else if (sp && tn < 0) v = (D[t * ld + s] + D[t * ld + (s ^ 1)]) / 2.0;
+        else if (!sp && tn >= 0) v = (D[t * ld + s] + D[tn * ld + s]) / 2.0;
+        else v = (((D[t * ld + s] + D[tn * ld + s]) + D[t * ld + (s ^ 1)]) + D[tn * ld + (s ^ 1)]) / 4.0;
+        sx -= v;   // p.Sx -= Dpx
+        sxn -= v;  // p.nbr.Sx -= Dpx
+    }
+    d.Sx[s] = sx;
+    if (sp) d.Sx[s ^ 1] = sxn;
+}
+
+// Bulk + special parts of one micro-op for slot k
+FNN_HD void op_thread(const Dev& d, const Op& op, int32_t k) {
+    if (k >= op.mcur) return;
+    double* D = d.D; const int64_t ld = d.ld;
+    if (op.kind == OP_SWAP) {
+        int32_t a = op.a, b = op.b;
+        if (k == a) {
+            double t = d.Sx[a]; d.Sx[a] = d.Sx[b]; d.Sx[b] = t;
+        } else if (k != b) {
+            double ta = D[a * ld + k], tb = D[b * ld + k];
+            D[a * ld + k] = tb; D[k * ld + a] = tb;
+            D[b * ld + k] = ta; D[k * ld + b] = ta;
+        }
+    } else if (op.kind == OP_MOVE) {
+        int32_t src = op.a, dst = op.b;
+        if (k == src) {
+            D[dst * ld + dst] = 0.0;
+            d.Sx[dst] = d.Sx[src];
+        } else if (k != dst) {
+            double t = D[src * ld + k];
+            D[dst * ld + k] = t; D[k * ld + dst] = t;
+        }
+    } else if (op.kind == OP_AGG3) {
+        int32_t X = op.a, Y = op.b, Z = op.c, U = op.d, V = op.e;
+        if (k == X) {
+            // the aliased entry D[u][v] and the diagonal (NetMakerOriginal.java:653-656, 670):
+            // the in-place loop writes D[u][v] twice, once at p = u and once at p = v, the
+            // second write reading the first
+            double dxz = D[X * ld + Z], dyx = D[Y * ld + X], dyz = D[Y * ld + Z];
+            double uv;
+            if (op.flag) uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + dyx / 3.0) + dyz / 3.0;
+            else uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + dyz / 3.0) + dyx / 3.0;
+            D[U * ld + U] = 0.0; D[V * ld + V] = 0.0;
+            D[U * ld + V] = uv; D[V * ld + U] = uv;
+        } else if (k != Y && k != Z) {
+            double dx = D[X * ld + k], dy = D[Y * ld + k], dz = D[Z * ld + k];
+            double nu = (2.0 / 3.0) * dx + dy / 3.0;
+            double nv = (2.0 / 3.0) * dz + dy / 3.0;
+            D[U * ld + k] = nu; D[k * ld + U] = nu;
+            D[V * ld + k] = nv; D[k * ld + V] = nv;
+        }
+    }
+}
+
+// updateClusterDistances(u), per-node part (NetMakerOriginal.java:520-533). New layout.
+FNN_HD void add_thread(const Dev& d, int32_t s) {
+    const State& st = *d.st;
+    if (s >= st.m) return;
+    int32_t twoP = 2 * st.P;
+    int32_t U = st.U, V = st.U + 1;
+    const double* D = d.D; const int64_t ld = d.ld;
+    double val = 0.0;
+    bool sp = s < twoP;
+    bool rep = !sp || !(s & 1);
+    if (rep && s != U) {
+        double dpu;
+        if (!sp) dpu = (D[U * ld + s] + D[V * ld + s]) / 2.0;
+        else dpu = (((D[U * ld + s] + D[V * ld + s]) + D[U * ld + s + 1]) + D[V * ld + s + 1]) / 4.0;
+        d.Sx[s] += dpu;
+        if (sp) d.Sx[s + 1] += dpu;
+        val = dpu;
+    }
+    d.chain[d.spos[s]] = val;  // adding +0.0 to a running sum that starts at +0.0 changes no bit
+}
+
+// u.Sx = sequential sum; u.nbr.Sx = u.Sx (:518-519, 532, 535); close the event
+FNN_HD void finalize(const Dev& d, double usx) {
+    State& st = *d.st;
+    if (!st.ev_finish) {
+        d.Sx[st.U] = usx;
+        d.Sx[st.U + 1] = usx;
+    } else {  // special finish: u, v are fresh nodes whose Sx keeps its default (NetNode.java:15)
+        d.Sx[st.U] = 0.0;
+        d.Sx[st.U + 1] = 0.0;
+    }
+    if (st.record_events) d.evlog[st.n_events] = st.cur;
+    st.n_events += 1;
+    st.sum_entries += st.cur.entries;
+    if (st.ev_finish || st.m <= 3) st.done = 1;
+}
+
+// NetMakerOriginal.initialize (:164-191) for the all-singleton start: node k receives
+// D[0][k], ..., D[k-1][k] (as q of the outer nodes p < k) and then D[k][k+1..n-1] (as p),
+// i.e. one sequential sum over j != k in ascending j.  Also sets up the identity layout.
+FNN_HD void init_thread(const Dev& d, int32_t k) {
+    if (k >= d.n) return;
+    const double* D = d.D; const int64_t ld = d.ld;
+    double s = 0.0;
+    for (int32_t j = 0; j < d.n; j++)
+        if (j != k) s += D[j * ld + k];  // == D[k][j] (symmetric input); column walk coalesces across k
+    d.Sx[k] = s;
+    d.sid[k] = k + 1;
+    d.spos[k] = k;
+    d.pslot[k] = k;
+}
+
+// SplitMix64, k-th output for a given seed
+FNN_HD uint64_t splitmix64_at(uint64_t seed, uint64_t k) {
+    uint64_t z = seed + (k + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// synthetic entry (i < j) of the generator; index k = i*n - i(i+1)/2 + (j-i-1)
+FNN_HD double synth_entry(int64_t n, int64_t i, int64_t j, uint64_t seed, int32_t dist) {
+    uint64_t k = (uint64_t)(i * n - i * (i + 1) / 2 + (j - i - 1));
+    double u = (double)(splitmix64_at(seed, k) >> 11) * 0x1.0p-53;
+    if (dist == 1) return (double)((int64_t)(u * 1e4) + 1) / 1e4;
+    return u + 0x1.0p-10;
+}
+
+}  // namespace fnn
+#endif

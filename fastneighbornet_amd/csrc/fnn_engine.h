@@ -1,0 +1,355 @@
+// fnn_engine.h -- host side of the engine, shared by the HIP backend
+// (fnn_hip.hip -> libfastnn_hip.so, the product) and by the CPU emulation backend
+// used only by tests (tests/emu/fnn_emu.cpp).  The template parameter B supplies
+// memory management and the per-event kernel sequence; everything here is
+// integer / control logic: handle lifecycle, matrix upload, the event loop,
+// and expandNodes (NetMakerOriginal.java:246-325), which is Theta(n) pointer
+// relinking on the host.
+#ifndef FNN_ENGINE_H
+#define FNN_ENGINE_H
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fastnn.h"
+#include "fnn_core.h"
+
+namespace fnn {
+
+static_assert(sizeof(Event) == sizeof(fnn_event), "event layout");
+
+inline thread_local std::string g_last_error;
+inline int32_t fail(int32_t code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+inline double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+template <class B>
+class Engine {
+  public:
+    B be;
+    Dev dev{};
+    int32_t n = 0;
+    int64_t ld = 0, nrows = 0;
+    fnn_opts opts{};
+    bool have_matrix = false, begun = false, ended = false;
+    State hst{};           // host copy of the device state
+    int32_t m_bound = 0;   // upper bound of num_active known to the host
+    fnn_stats stats{};
+    std::vector<fnn_event> events;  // trajectory of the last run
+    std::vector<Agg3Rec> agglog;
+    int32_t last3[3] = {0, 0, 0};
+    int32_t batch = 32;    // events enqueued between host round trips in run()
+
+    int32_t create(int32_t n_, const fnn_opts* o) {
+        if (n_ < 0) return fail(FNN_EINVAL, "fnn_create: n < 0");
+        n = n_;
+        if (o) opts = *o;
+        int32_t rc = be.open(opts.device);
+        if (rc != FNN_OK) return rc;
+        // padded geometry: rows to a multiple of the scan tile height, row stride to a
+        // multiple of the tile width plus 32 doubles so that column sweeps (stride ld)
+        // do not hammer one HBM channel
+        nrows = round_up(n > 0 ? n : 1, B::kRowPad);
+        ld = round_up(n > 0 ? n : 1, B::kColPad) + 32;
+        dev.n = n;
+        dev.ld = ld;
+        size_t nn = (size_t)(n > 0 ? n : 1);
+        if (!(dev.D = (double*)be.alloc(sizeof(double) * (size_t)nrows * (size_t)ld)) ||
+            !(dev.Sx = (double*)be.alloc(sizeof(double) * (nn + 8))) ||
+            !(dev.sid = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
+            !(dev.spos = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
+            !(dev.pslot = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
+            !(dev.chain = (double*)be.alloc(sizeof(double) * 4 * nn)) ||
+            !(dev.recs = (Cand*)be.alloc(sizeof(Cand) * be.max_records(n))) ||
+            !(dev.st = (State*)be.alloc(sizeof(State))) ||
+            !(dev.evlog = (Event*)be.alloc(sizeof(Event) * (nn + 8))) ||
+            !(dev.agglog = (Agg3Rec*)be.alloc(sizeof(Agg3Rec) * (nn + 8))))
+            return fail(FNN_ENOMEM, "fnn_create: device allocation failed (" + be.err() + ")");
+        // zero the padding once so that stray loads never see signalling patterns
+        if (be.memset(dev.D, 0, sizeof(double) * (size_t)nrows * (size_t)ld) != FNN_OK)
+            return fail(FNN_EHIP, "fnn_create: memset failed (" + be.err() + ")");
+        return FNN_OK;
+    }
+
+    void destroy() {
+        be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
+        be.free(dev.chain); be.free(dev.recs); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        dev = Dev{};
+        be.close();
+    }
+
+    int32_t set_rows(int32_t row0, int32_t cnt, const double* rows, int64_t ld_in) {
+        if (!rows || row0 < 0 || cnt < 0 || (int64_t)row0 + cnt > n || ld_in < n)
+            return fail(FNN_EINVAL, "fnn_set_rows: bad arguments");
+        if (cnt == 0) return FNN_OK;
+        if (be.h2d_2d(dev.D + (int64_t)row0 * ld, ld, rows, ld_in, n, cnt) != FNN_OK)
+            return fail(FNN_EHIP, "fnn_set_rows: copy failed (" + be.err() + ")");
+        if ((int64_t)row0 + cnt == n) have_matrix = true;  // rows are expected in order
+        begun = ended = false;
+        return FNN_OK;
+    }
+
+    int32_t set_matrix_device(const double* dmat, int64_t ld_in) {
+        if (!dmat || ld_in < n) return fail(FNN_EINVAL, "fnn_set_matrix_device: bad arguments");
+        if (n > 0 && be.d2d_2d(dev.D, ld, dmat, ld_in, n, n) != FNN_OK)
+            return fail(FNN_EHIP, "fnn_set_matrix_device: copy failed (" + be.err() + ")");
+        have_matrix = true;
+        begun = ended = false;
+        return FNN_OK;
+    }
+
+    int32_t synth(uint64_t seed, int32_t dist) {
+        if (dist != 0 && dist != 1) return fail(FNN_EINVAL, "fnn_synth: dist must be 0 or 1");
+        if (n > 0 && be.launch_synth(dev, seed, dist) != FNN_OK)
+            return fail(FNN_EHIP, "fnn_synth: launch failed (" + be.err() + ")");
+        have_matrix = true;
+        begun = ended = false;
+        return FNN_OK;
+    }
+
+    int32_t pull_state() {
+        if (be.d2h(&hst, dev.st, sizeof(State)) != FNN_OK)
+            return fail(FNN_EHIP, "state download failed (" + be.err() + ")");
+        if (hst.error) return fail(FNN_ESTATE, "engine reached an unreachable branch, code " + std::to_string(hst.error));
+        return FNN_OK;
+    }
+
+    // runNeighborNet up to and including initialize() (NetMakerOriginal.java:141-159)
+    int32_t begin() {
+        if (!have_matrix) return fail(FNN_ESTATE, "fnn_begin: no matrix uploaded");
+        stats = fnn_stats{};
+        events.clear();
+        agglog.clear();
+        double t0 = now_s();
+        if (n > 0 && opts.validate) {
+            int32_t bad = 0;
+            if (be.launch_validate(dev, &bad) != FNN_OK)
+                return fail(FNN_EHIP, "fnn_begin: validate failed (" + be.err() + ")");
+            if (bad) return fail(FNN_EINVAL, "fnn_begin: matrix must be finite, symmetric, with zero diagonal");
+        }
+        std::memset(&hst, 0, sizeof(hst));
+        hst.n = n; hst.m = n; hst.c = n; hst.P = 0; hst.num_nodes = n;
+        hst.done = (n <= 3) ? 1 : 0;  // :133-140
+        hst.record_events = opts.record_events ? 1 : 0;
+        if (be.h2d(dev.st, &hst, sizeof(State)) != FNN_OK)
+            return fail(FNN_EHIP, "fnn_begin: state upload failed (" + be.err() + ")");
+        if (n > 3) {
+            if (be.launch_init(dev) != FNN_OK || be.sync() != FNN_OK)
+                return fail(FNN_EHIP, "fnn_begin: init failed (" + be.err() + ")");
+        }
+        m_bound = n;
+        have_matrix = false;  // consumed
+        begun = true;
+        ended = (n <= 3);
+        stats.t_init_s = now_s() - t0;
+        return FNN_OK;
+    }
+
+    // one event with a host round trip (tests / diagnostics)
+    int32_t step(fnn_event* ev) {
+        if (!begun) return fail(FNN_ESTATE, "fnn_step: call fnn_begin first");
+        if (ended) return 0;
+        if (be.launch_event(dev, m_bound) != FNN_OK || be.sync() != FNN_OK)
+            return fail(FNN_EHIP, "fnn_step: launch failed (" + be.err() + ")");
+        int32_t rc = pull_state();
+        if (rc != FNN_OK) return rc;
+        m_bound = hst.m;
+        if (std::getenv("FNN_DEBUG")) {
+            std::fprintf(stderr, "[fnn] m=%d c=%d P=%d nn=%d done=%d active=%d finish=%d need_rx=%d sa=%d sap=%d sb=%d sbp=%d xs=%d ys=%d U=%d nops=%d m_old=%d P_old=%d err=%d\n",
+                         hst.m, hst.c, hst.P, hst.num_nodes, hst.done, hst.ev_active, hst.ev_finish, hst.need_rx, hst.sa,
+                         hst.sap, hst.sb, hst.sbp, hst.xs, hst.ys, hst.U, hst.nops, hst.m_old, hst.P_old, hst.error);
+            for (int i = 0; i < hst.nops; i++)
+                std::fprintf(stderr, "[fnn]   op%d kind=%d a=%d b=%d c=%d d=%d e=%d mcur=%d flag=%d\n", i, hst.ops[i].kind,
+                             hst.ops[i].a, hst.ops[i].b, hst.ops[i].c, hst.ops[i].d, hst.ops[i].e, hst.ops[i].mcur, hst.ops[i].flag);
+        }
+        if (!hst.ev_active) { ended = true; return 0; }
+        if (ev) std::memcpy(ev, &hst.cur, sizeof(fnn_event));
+        if (hst.done) ended = true;
+        return 1;
+    }
+
+    // the whole agglomNodes loop without per-event round trips
+    int32_t agglomerate() {
+        if (!begun) return fail(FNN_ESTATE, "agglomerate: call fnn_begin first");
+        double t0 = now_s();
+        while (!ended) {
+            for (int i = 0; i < batch; i++)
+                if (be.launch_event(dev, m_bound) != FNN_OK)
+                    return fail(FNN_EHIP, "fnn_run: launch failed (" + be.err() + ")");
+            if (be.sync() != FNN_OK) return fail(FNN_EHIP, "fnn_run: sync failed (" + be.err() + ")");
+            int32_t rc = pull_state();
+            if (rc != FNN_OK) return rc;
+            m_bound = hst.m;
+            if (hst.done) ended = true;
+        }
+        stats.t_agglom_s = now_s() - t0;
+        return FNN_OK;
+    }
+
+    // expandNodes (NetMakerOriginal.java:246-325) from the merge log
+    int32_t finish(int32_t* order_out) {
+        if (!order_out) return fail(FNN_EINVAL, "fnn_finish: order_out is NULL");
+        if (!begun) return fail(FNN_ESTATE, "fnn_finish: call fnn_begin first");
+        if (n <= 3) {  // :133-140
+            for (int32_t i = 0; i <= n; i++) order_out[i] = i;
+            return FNN_OK;
+        }
+        if (!ended) return fail(FNN_ESTATE, "fnn_finish: agglomeration has not ended");
+        double t0 = now_s();
+        int32_t rc = pull_state();
+        if (rc != FNN_OK) return rc;
+        agglog.resize((size_t)hst.n_agg3);
+        if (hst.n_agg3 > 0 && be.d2h(agglog.data(), dev.agglog, sizeof(Agg3Rec) * (size_t)hst.n_agg3) != FNN_OK)
+            return fail(FNN_EHIP, "fnn_finish: log download failed (" + be.err() + ")");
+        if (hst.record_events) {
+            events.resize((size_t)hst.n_events);
+            if (hst.n_events > 0 && be.d2h(events.data(), dev.evlog, sizeof(Event) * (size_t)hst.n_events) != FNN_OK)
+                return fail(FNN_EHIP, "fnn_finish: event download failed (" + be.err() + ")");
+        }
+        // netNodes[0..2]: ids of the nodes at reference positions 0, 1, 2
+        std::vector<int32_t> pslot((size_t)n), sid((size_t)n);
+        if (be.d2h(pslot.data(), dev.pslot, sizeof(int32_t) * (size_t)n) != FNN_OK ||
+            be.d2h(sid.data(), dev.sid, sizeof(int32_t) * (size_t)n) != FNN_OK)
+            return fail(FNN_EHIP, "fnn_finish: layout download failed (" + be.err() + ")");
+        for (int k = 0; k < 3; k++) {
+            int32_t s = pslot[(size_t)k];
+            if (s < 0 || s >= n) return fail(FNN_ESTATE, "fnn_finish: corrupt layout");
+            last3[k] = sid[(size_t)s];
+        }
+        rc = expand(order_out);
+        stats.t_expand_s = now_s() - t0;
+        stats.n_events = hst.n_events;
+        stats.sum_entries = hst.sum_entries;
+        stats.scan_bytes = 8 * hst.sum_entries;
+        be.collect_timing(stats);
+        return rc;
+    }
+
+    int32_t expand(int32_t* ordering) {
+        // ids run up to num_nodes; index 0 unused
+        size_t N = (size_t)hst.num_nodes + 1;
+        std::vector<int32_t> next(N, 0), prev(N, 0), ch1(N, 0), ch2(N, 0), nbr(N, 0);
+        for (const Agg3Rec& r : agglog) {
+            int32_t u = r.u_id, v = r.u_id + 1;
+            if (u <= 0 || (size_t)v >= N) return fail(FNN_ESTATE, "fnn_finish: corrupt merge log");
+            ch1[(size_t)u] = r.x_id; ch2[(size_t)u] = r.y_id;  // :610-611
+            ch1[(size_t)v] = r.y_id; ch2[(size_t)v] = r.z_id;  // :615-616
+            nbr[(size_t)u] = v; nbr[(size_t)v] = u;            // :647-648
+        }
+        int32_t x = last3[0], y = last3[1], z = last3[2];
+        next[(size_t)x] = y; next[(size_t)y] = z; next[(size_t)z] = x;
+        prev[(size_t)x] = z; prev[(size_t)y] = x; prev[(size_t)z] = y;
+        for (size_t k = agglog.size(); k-- > 0;) {  // while (!amalgs.empty()) pop
+            int32_t u = agglog[k].u_id;
+            int32_t v = nbr[(size_t)u];
+            x = ch1[(size_t)u]; y = ch2[(size_t)u]; z = ch2[(size_t)v];
+            if (v != next[(size_t)u]) {
+                int32_t t = u; u = v; v = t;
+                t = x; x = z; z = t;
+            }
+            prev[(size_t)x] = prev[(size_t)u];
+            next[(size_t)prev[(size_t)x]] = x;
+            next[(size_t)x] = y;
+            prev[(size_t)y] = x;
+            next[(size_t)y] = z;
+            prev[(size_t)z] = y;
+            next[(size_t)z] = next[(size_t)v];
+            prev[(size_t)next[(size_t)z]] = z;
+        }
+        int64_t guard = 0;
+        while (x != 1) {
+            x = next[(size_t)x];
+            if (++guard > (int64_t)N) return fail(FNN_ESTATE, "fnn_finish: ring does not contain taxon 1");
+        }
+        int32_t a = x, t = 0;
+        ordering[0] = 0;
+        do {
+            if (t >= n) return fail(FNN_ESTATE, "fnn_finish: ring longer than ntax");
+            ordering[++t] = a;
+            a = next[(size_t)a];
+        } while (a != x);
+        if (t != n) return fail(FNN_ESTATE, "fnn_finish: ring shorter than ntax");
+        return FNN_OK;
+    }
+
+    int32_t run(int32_t* order_out, fnn_stats* out) {
+        double t0 = now_s();
+        int32_t rc = begin();
+        if (rc != FNN_OK) return rc;
+        if (n > 3) {
+            rc = agglomerate();
+            if (rc != FNN_OK) return rc;
+        }
+        rc = finish(order_out);
+        if (rc != FNN_OK) return rc;
+        stats.t_total_s = now_s() - t0;
+        if (out) *out = stats;
+        return FNN_OK;
+    }
+
+    int32_t get_nodes(int32_t* id, int32_t* nbr_id, double* Sx) {
+        if (!begun) return fail(FNN_ESTATE, "fnn_get_nodes: call fnn_begin first");
+        int32_t rc = pull_state();
+        if (rc != FNN_OK) return rc;
+        if (n <= 3) return FNN_OK;
+        std::vector<int32_t> pslot((size_t)n), sid((size_t)n);
+        std::vector<double> sx((size_t)n);
+        if (be.d2h(pslot.data(), dev.pslot, sizeof(int32_t) * (size_t)n) != FNN_OK ||
+            be.d2h(sid.data(), dev.sid, sizeof(int32_t) * (size_t)n) != FNN_OK ||
+            be.d2h(sx.data(), dev.Sx, sizeof(double) * (size_t)n) != FNN_OK)
+            return fail(FNN_EHIP, "fnn_get_nodes: download failed (" + be.err() + ")");
+        for (int32_t i = 0; i < hst.m; i++) {
+            int32_t s = pslot[(size_t)i];
+            if (s < 0) {  // only after the special finish (netNodes[3] == null)
+                if (id) id[i] = 0;
+                if (nbr_id) nbr_id[i] = 0;
+                if (Sx) Sx[i] = 0.0;
+                continue;
+            }
+            if (id) id[i] = sid[(size_t)s];
+            if (nbr_id) nbr_id[i] = s < 2 * hst.P ? sid[(size_t)(s ^ 1)] : 0;
+            if (Sx) Sx[i] = sx[(size_t)s];
+        }
+        return FNN_OK;
+    }
+
+    int32_t get_live_matrix(double* out) {
+        if (!begun) return fail(FNN_ESTATE, "fnn_get_live_matrix: call fnn_begin first");
+        int32_t rc = pull_state();
+        if (rc != FNN_OK) return rc;
+        int32_t m = hst.m;
+        if (n <= 3 || m <= 0) return FNN_OK;
+        std::vector<int32_t> pslot((size_t)n);
+        if (be.d2h(pslot.data(), dev.pslot, sizeof(int32_t) * (size_t)n) != FNN_OK)
+            return fail(FNN_EHIP, "fnn_get_live_matrix: download failed (" + be.err() + ")");
+        std::vector<double> rows((size_t)m * (size_t)m);
+        if (be.d2h_2d(rows.data(), m, dev.D, ld, m, m) != FNN_OK)
+            return fail(FNN_EHIP, "fnn_get_live_matrix: download failed (" + be.err() + ")");
+        for (int32_t i = 0; i < m; i++)
+            for (int32_t j = 0; j < m; j++) {
+                int32_t si = pslot[(size_t)i], sj = pslot[(size_t)j];
+                out[(size_t)i * m + j] = (si < 0 || sj < 0) ? 0.0 : rows[(size_t)si * m + sj];
+            }
+        return FNN_OK;
+    }
+
+    int64_t get_events(fnn_event* out, int64_t maxn) {
+        int64_t k = (int64_t)events.size();
+        if (out && maxn > 0) std::memcpy(out, events.data(), sizeof(fnn_event) * (size_t)(k < maxn ? k : maxn));
+        return k;
+    }
+};
+
+}  // namespace fnn
+#endif

@@ -1,0 +1,148 @@
+/*
+ * fastnn.h -- C ABI of libfastnn_hip.so, the MI355X-native Canonical Neighbor-Net
+ * agglomeration engine.
+ *
+ * The reference (JacobPorter/FastNeighborNet, Java) has no FFI layer; its seam for
+ * this path is the abstract class NetMakerOriginal:
+ *     ctor  (double[][] d, int numTaxa, int numThreads, ExecutorService pool)
+ *                                                 NetMakerOriginal.java:51-56
+ *     public int[] runNeighborNet()               NetMakerOriginal.java:129-162
+ * as instantiated by FastNN.main for -mode Canonical (FastNN.java:324-328) and
+ * called once (FastNN.java:378 / :391).  The entry points below are exactly what a
+ * JNI binding of that seam needs (see INTEGRATION.md for the Java stub); plain
+ * pointers and sizes only.
+ *
+ * All arithmetic on the path is IEEE binary64, one rounding per source-level
+ * operation, no FMA contraction, in the reference's evaluation order, so the
+ * circular order is bit-identical to the Java `-threads 1` result.
+ *
+ * Thread-safety: a handle is single-caller; different handles may be used from
+ * different threads.  Functions return FNN_OK (0) or a negative fnn_status;
+ * fnn_last_error() gives a thread-local message.  The library never aborts the
+ * process and has NO CPU fallback: without a usable HIP device every call that
+ * needs one fails with FNN_EHIP.
+ */
+#ifndef FASTNN_H
+#define FASTNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FASTNN_ABI_VERSION 1
+
+typedef enum fnn_status {
+    FNN_OK      = 0,
+    FNN_EINVAL  = -1,  /* bad argument / matrix not symmetric, not finite, non-zero diagonal */
+    FNN_ENOMEM  = -2,  /* host or device allocation failed */
+    FNN_EHIP    = -3,  /* HIP runtime error or no device */
+    FNN_ERCCL   = -4,  /* reserved: collective error (multi-GPU) */
+    FNN_ESTATE  = -5   /* call sequence error (e.g. run before the matrix is set) */
+} fnn_status;
+
+/* Kind of agglomeration event (NetMakerOriginal.java:462-488; special finish :343-360). */
+enum { FNN_KIND_2WAY = 2, FNN_KIND_3WAY = 3, FNN_KIND_4WAY = 4, FNN_KIND_FINISH = 5 };
+
+/* Options.  Zero-initialise, then set what you need. */
+typedef struct fnn_opts {
+    int32_t device;        /* HIP device ordinal (default 0) */
+    int32_t validate;      /* 1: check symmetry / zero diagonal / finiteness on device before running */
+    int32_t record_events; /* 1: keep the per-event trajectory (fnn_get_events) */
+    int32_t reserved[13];
+} fnn_opts;
+
+/* One agglomeration event == one iteration of the loop of
+ * NetMakerOriginal.agglomNodes (:339-393).  Same fields as the test oracle's
+ * nno_event so trajectories can be compared field by field. */
+typedef struct fnn_event {
+    int32_t m_before;      /* num_active at loop entry */
+    int32_t c_before;      /* num_clusters at loop entry */
+    int32_t cx_id, cy_id;  /* Cx.id, Cy.id after the id swap (:376-380); 0 for FINISH */
+    int32_t x_id, y_id;    /* nodes chosen among the <=4 candidates (:428-452) */
+    int32_t kind;          /* FNN_KIND_* */
+    int32_t u_id;          /* id of the node returned by agg2way/agg3way/agg4way */
+    double  best;          /* scan minimum Qpq (NeighborNetCanonical.java:170-177) */
+    int64_t entries;       /* E_t = m(m-1)/2 - (m-c): matrix entries the scan must read */
+} fnn_event;
+
+typedef struct fnn_stats {
+    int64_t n_events;        /* agglomeration events executed */
+    int64_t sum_entries;     /* sum_t E_t  (algorithmic entries; x8 = algorithmic bytes) */
+    double  t_init_s;        /* initial row sums (NetMakerOriginal.initialize :164-191) */
+    double  t_agglom_s;      /* agglomNodes loop, device time incl. launches */
+    double  t_expand_s;      /* expandNodes on the host (:246-325) */
+    double  t_total_s;       /* matrix resident on device -> order on host */
+    double  t_scan_s;        /* sum of scan-kernel durations (HIP events), 0 unless timing enabled */
+    int64_t scan_launches;   /* number of scan-kernel launches */
+    int64_t scan_bytes;      /* algorithmic bytes of those launches (8 * sum E_t) */
+    int64_t reserved[8];
+} fnn_stats;
+
+typedef struct fnn_handle fnn_handle;
+
+/* Library / device probing. */
+int32_t     fnn_abi_version(void);
+const char* fnn_last_error(void);
+int32_t     fnn_device_count(void);                 /* <0 on error */
+
+/* Handle lifecycle.  n = number of taxa (ntax of NetMakerOriginal.java:52). */
+int32_t fnn_create(int32_t n, const fnn_opts* opts, fnn_handle** out);
+int32_t fnn_destroy(fnn_handle* h);
+
+/* Matrix upload: rows [row0, row0+nrows) of the symmetric n x n fp64 matrix, host
+ * memory, row stride ld_in doubles.  Plays the role of the `double[][] d`
+ * constructor argument; the caller's buffer is never written (the reference
+ * destroys its argument in place, NetMakerOriginal.java:653-656). */
+int32_t fnn_set_rows(fnn_handle* h, int32_t row0, int32_t nrows, const double* rows, int64_t ld_in);
+/* Same from DEVICE memory (whole matrix, row stride ld_in doubles). */
+int32_t fnn_set_matrix_device(fnn_handle* h, const double* d_matrix, int64_t ld_in);
+/* Fill the device matrix with the synthetic generator of SURVEY.md 8(d)
+ * (SplitMix64; dist 0 = uniform53, 1 = dec4), bit-identical to the host generator. */
+int32_t fnn_synth(fnn_handle* h, uint64_t seed, int32_t dist);
+
+/* runNeighborNet (NetMakerOriginal.java:129-162): order_out has n+1 entries,
+ * order_out[0] = 0, order_out[1] = 1, 1-based taxon ids in circular order; n <= 3
+ * gives the identity (:133-140).  Consumes the device matrix (a new upload or
+ * fnn_synth is needed before another run).  stats may be NULL. */
+int32_t fnn_run(fnn_handle* h, int32_t* order_out, fnn_stats* stats);
+
+/* Test/diagnostic stepping: fnn_begin computes the initial row sums; fnn_step
+ * executes exactly one event and returns 1 (ev filled), or 0 when the loop has
+ * ended; fnn_finish expands the merge stack into the order.  fnn_run ==
+ * begin + step* + finish without the per-event host round trip. */
+int32_t fnn_begin(fnn_handle* h);
+int32_t fnn_step(fnn_handle* h, fnn_event* ev);
+int32_t fnn_finish(fnn_handle* h, int32_t* order_out);
+
+/* Trajectory of the last run (needs opts.record_events). Copies up to max_events
+ * records; returns the number of events of the run (may exceed max_events). */
+int64_t fnn_get_events(fnn_handle* h, fnn_event* out, int64_t max_events);
+
+/* State inspection for parity tests.  For reference position i in
+ * [0, num_active): node id, partner id (0 if none), Sx.  Arrays of length >= n. */
+int32_t fnn_get_counts(fnn_handle* h, int32_t* num_active, int32_t* num_clusters, int32_t* num_nodes);
+int32_t fnn_get_nodes(fnn_handle* h, int32_t* id, int32_t* nbr_id, double* Sx);
+/* Sub-matrix of live nodes in reference position order: out[i*m + j] =
+ * D[N[i].distID][N[j].distID], m = num_active. */
+int32_t fnn_get_live_matrix(fnn_handle* h, double* out);
+
+/* Enable per-launch HIP-event timing of the scan kernel (bench.py's roofline
+ * figure).  Adds two event records per scan launch. */
+int32_t fnn_set_scan_timing(fnn_handle* h, int32_t enable);
+
+/* One-call convenience == create + set_rows + run + destroy
+ * (FastNN.java:326 + :378). */
+int32_t fnn_canonical_order_f64(const double* D, int32_t n, int64_t ld, const fnn_opts* opts,
+                                int32_t* order_out, fnn_stats* stats);
+
+/* Device-side read-only streaming probe: reads `bytes` bytes `reps` times and
+ * returns the achieved GB/s (the "measured stream" line next to the nominal
+ * 8 TB/s peak). */
+int32_t fnn_stream_probe(int32_t device, int64_t bytes, int32_t reps, double* gbps_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTNN_H */

@@ -1,0 +1,185 @@
+// fnn_emu.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// CPU emulation backend for fnn::Engine: runs the per-thread bodies of
+// fastneighbornet_amd/csrc/fnn_core.h in loops (in forward, reverse or shuffled
+// "thread" order, to expose any dependence on execution order that would be a
+// race on the GPU).  It lets the `-m "not gpu"` tests check the slot layout
+// bookkeeping and the host logic (event loop, expandNodes) against the oracle in
+// a container without a GPU.  It is NOT part of the product and libfastnn_hip.so
+// never falls back to it.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../fastneighbornet_amd/csrc/fnn_engine.h"
+
+namespace {
+
+int g_order_mode = 0;  // 0 forward, 1 reverse, 2 shuffled
+uint64_t g_shuffle_state = 0x12345678ULL;
+
+std::vector<int32_t> thread_order(int32_t count) {
+    std::vector<int32_t> v((size_t)count);
+    std::iota(v.begin(), v.end(), 0);
+    if (g_order_mode == 1) std::reverse(v.begin(), v.end());
+    else if (g_order_mode == 2) {
+        for (int32_t i = count - 1; i > 0; i--) {
+            g_shuffle_state = g_shuffle_state * 6364136223846793005ULL + 1442695040888963407ULL;
+            int32_t j = (int32_t)((g_shuffle_state >> 33) % (uint64_t)(i + 1));
+            std::swap(v[(size_t)i], v[(size_t)j]);
+        }
+    }
+    return v;
+}
+
+struct EmuBackend {
+    static constexpr int64_t kRowPad = 32;
+    static constexpr int64_t kColPad = 512;
+    std::string err() const { return "emu"; }
+    int32_t open(int32_t) { return FNN_OK; }
+    void close() {}
+    void* alloc(size_t b) { return std::malloc(b ? b : 1); }
+    void free(void* p) { std::free(p); }
+    size_t max_records(int32_t) { return 1; }
+    int32_t memset(void* p, int v, size_t b) { std::memset(p, v, b); return FNN_OK; }
+    int32_t h2d(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return FNN_OK; }
+    int32_t d2h(void* d, const void* s, size_t b) { std::memcpy(d, s, b); return FNN_OK; }
+    int32_t h2d_2d(double* d, int64_t ldd, const double* s, int64_t lds, int64_t w, int64_t h) {
+        for (int64_t r = 0; r < h; r++) std::memcpy(d + r * ldd, s + r * lds, sizeof(double) * (size_t)w);
+        return FNN_OK;
+    }
+    int32_t d2d_2d(double* d, int64_t ldd, const double* s, int64_t lds, int64_t w, int64_t h) {
+        return h2d_2d(d, ldd, s, lds, w, h);
+    }
+    int32_t d2h_2d(double* d, int64_t ldd, const double* s, int64_t lds, int64_t w, int64_t h) {
+        return h2d_2d(d, ldd, s, lds, w, h);
+    }
+    int32_t sync() { return FNN_OK; }
+    void collect_timing(fnn_stats&) {}
+
+    int32_t launch_synth(const fnn::Dev& d, uint64_t seed, int32_t dist) {
+        for (int64_t i = 0; i < d.n; i++) {
+            d.D[i * d.ld + i] = 0.0;
+            for (int64_t j = i + 1; j < d.n; j++) {
+                double v = fnn::synth_entry(d.n, i, j, seed, dist);
+                d.D[i * d.ld + j] = v;
+                d.D[j * d.ld + i] = v;
+            }
+        }
+        return FNN_OK;
+    }
+
+    int32_t launch_validate(const fnn::Dev& d, int32_t* bad) {
+        *bad = 0;
+        for (int64_t i = 0; i < d.n; i++)
+            for (int64_t j = 0; j <= i; j++) {
+                double a = d.D[i * d.ld + j], b = d.D[j * d.ld + i];
+                uint64_t ua, ub;
+                std::memcpy(&ua, &a, 8); std::memcpy(&ub, &b, 8);
+                bool fin = ((ua >> 52) & 0x7FF) != 0x7FF;
+                if (ua != ub || !fin || (i == j && ua != 0)) *bad = 1;
+            }
+        return FNN_OK;
+    }
+
+    int32_t launch_init(const fnn::Dev& d) {
+        for (int32_t k : thread_order(d.n)) fnn::init_thread(d, k);
+        return FNN_OK;
+    }
+
+    int32_t launch_event(const fnn::Dev& d, int32_t m_bound) {
+        fnn::State& st = *d.st;
+        // k_scan
+        fnn::Cand best;
+        best.q = fnn::inf_f64();
+        best.key = ~0ULL;
+        if (!st.done) {
+            int32_t m = st.m, twoP = 2 * st.P;
+            double cm2 = (double)st.c - 2.0;
+            std::vector<std::pair<int32_t, int32_t>> tiles;
+            for (int32_t r0 = 0; r0 < m; r0 += 2)
+                for (int32_t c0 = 0; c0 <= r0; c0 += 2) tiles.emplace_back(r0, c0);
+            for (int32_t t : thread_order((int32_t)tiles.size())) {
+                int32_t r0 = tiles[(size_t)t].first, c0 = tiles[(size_t)t].second;
+                const double* R0 = d.D + (int64_t)r0 * d.ld;
+                const double* R1 = d.D + (int64_t)(r0 + 1) * d.ld;
+                bool r1 = r0 + 1 < m, c1 = c0 + 1 < m;
+                fnn::scan_micro(r0, c0, m, twoP, cm2, R0[c0], R0[c0 + 1], R1[c0], R1[c0 + 1],
+                                d.Sx[r0], r1 ? d.Sx[r0 + 1] : 0.0, d.spos[r0], r1 ? d.spos[r0 + 1] : 0,
+                                d.Sx[c0], c1 ? d.Sx[c0 + 1] : 0.0, d.spos[c0], c1 ? d.spos[c0 + 1] : 0, best);
+            }
+        }
+        // k_pick
+        fnn::pick(d, best);
+        if (!st.ev_active) return FNN_OK;
+        if (!st.ev_finish) {
+            // k_rx_fill + k_decide
+            double rx[4] = {0.0, 0.0, 0.0, 0.0};
+            if (st.need_rx) {
+                for (int32_t s : thread_order(m_bound)) fnn::rx_fill_thread(d, s);
+                int32_t z[4] = {st.sa, st.sap, st.sb, st.sbp};
+                for (int k = 0; k < 4; k++)
+                    if (z[k] >= 0) rx[k] = fnn::chain_sum(d.chain + (int64_t)k * d.n, st.m_old);
+            }
+            fnn::decide(d, rx);
+            // k_subtract
+            for (int32_t s : thread_order(m_bound)) fnn::subtract_thread(d, s);
+        }
+        // k_op x nops
+        for (int32_t i = 0; i < st.nops; i++) {
+            fnn::Op op = st.ops[i];
+            for (int32_t k : thread_order(m_bound)) fnn::op_thread(d, op, k);
+        }
+        double usx = 0.0;
+        if (!st.ev_finish) {
+            // k_add + chain
+            for (int32_t s : thread_order(m_bound)) fnn::add_thread(d, s);
+            usx = fnn::chain_sum(d.chain, st.m);
+        }
+        fnn::finalize(d, usx);
+        return FNN_OK;
+    }
+};
+
+using EmuEngine = fnn::Engine<EmuBackend>;
+
+}  // namespace
+
+extern "C" {
+
+void emu_set_order_mode(int32_t mode) { g_order_mode = mode; }
+const char* emu_last_error(void) { return fnn::g_last_error.c_str(); }
+
+int32_t emu_create(int32_t n, const fnn_opts* opts, void** out) {
+    auto* e = new EmuEngine();
+    int32_t rc = e->create(n, opts);
+    if (rc != FNN_OK) { e->destroy(); delete e; return rc; }
+    *out = e;
+    return FNN_OK;
+}
+int32_t emu_destroy(void* h) { auto* e = (EmuEngine*)h; e->destroy(); delete e; return FNN_OK; }
+int32_t emu_set_rows(void* h, int32_t row0, int32_t nrows, const double* rows, int64_t ld) {
+    return ((EmuEngine*)h)->set_rows(row0, nrows, rows, ld);
+}
+int32_t emu_synth(void* h, uint64_t seed, int32_t dist) { return ((EmuEngine*)h)->synth(seed, dist); }
+int32_t emu_run(void* h, int32_t* order, fnn_stats* st) { return ((EmuEngine*)h)->run(order, st); }
+int32_t emu_begin(void* h) { return ((EmuEngine*)h)->begin(); }
+int32_t emu_step(void* h, fnn_event* ev) { return ((EmuEngine*)h)->step(ev); }
+int32_t emu_finish(void* h, int32_t* order) { return ((EmuEngine*)h)->finish(order); }
+int64_t emu_get_events(void* h, fnn_event* out, int64_t maxn) { return ((EmuEngine*)h)->get_events(out, maxn); }
+int32_t emu_get_counts(void* h, int32_t* m, int32_t* c, int32_t* nn) {
+    auto* e = (EmuEngine*)h;
+    int32_t rc = e->pull_state();
+    if (rc != FNN_OK) return rc;
+    if (m) *m = e->hst.m;
+    if (c) *c = e->hst.c;
+    if (nn) *nn = e->hst.num_nodes;
+    return FNN_OK;
+}
+int32_t emu_get_nodes(void* h, int32_t* id, int32_t* nbr, double* sx) { return ((EmuEngine*)h)->get_nodes(id, nbr, sx); }
+int32_t emu_get_live_matrix(void* h, double* out) { return ((EmuEngine*)h)->get_live_matrix(out); }
+
+}  // extern "C"

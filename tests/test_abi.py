@@ -1,0 +1,54 @@
+"""CPU checks of the drop-in boundary: the shared library loads without a GPU and
+exports every symbol include/fastnn.h declares; no compute is attempted."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    txt = open(os.path.join(ROOT, "include", "fastnn.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fnn_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for must in ("fnn_create", "fnn_set_rows", "fnn_run", "fnn_step", "fnn_destroy",
+                 "fnn_canonical_order_f64", "fnn_last_error"):
+        assert must in names
+
+
+def test_library_builds_loads_and_exports_all_symbols():
+    from fastneighbornet_amd import build
+    lib = C.CDLL(build.build())
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in fastnn.h but not exported"
+    lib.fnn_abi_version.restype = C.c_int32
+    assert lib.fnn_abi_version() == 1
+
+
+def test_fails_loudly_without_device():
+    """No CPU fallback: on a box without a HIP device create() must fail with FNN_EHIP."""
+    import fastneighbornet_amd as fa
+    from fastneighbornet_amd._capi import FnnError, Handle
+    a = fa.api()
+    if a.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(FnnError) as ei:
+        Handle(a, 16)
+    assert ei.value.code == -3
+    import numpy as np
+    with pytest.raises(FnnError):
+        fa.canonical_order(np.zeros((8, 8)))
+
+
+def test_struct_layouts_match_header():
+    from fastneighbornet_amd import _capi
+    assert C.sizeof(_capi.FnnEvent) == 48
+    assert C.sizeof(_capi.FnnOpts) == 64
+    assert C.sizeof(_capi.FnnStats) == 9 * 8 + 8 * 8
+    assert _capi.EVENT_DTYPE.itemsize == 48

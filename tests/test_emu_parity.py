@@ -1,0 +1,69 @@
+"""CPU tests of the engine's host logic and per-thread bodies through the emulation
+driver (tests/emu): slot layout bookkeeping, micro-op plans, expandNodes.  The
+thread bodies are the ones the HIP kernels wrap; running them in reverse and
+shuffled order exposes order dependence (= races on the GPU)."""
+import numpy as np
+import pytest
+
+from common import check_order, compare_trajectory
+from fastneighbornet_amd._capi import Handle
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("dist", ["uniform53", "dec4"])
+def test_small_sizes_deep(emu_api, oracle, dist, mode):
+    emu_api.set_order_mode(mode)
+    for n in [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 31, 32, 33, 64, 65]:
+        for seed in (1, 2, 3):
+            compare_trajectory(emu_api, oracle, oracle.synth(n, seed, dist), deep=True)
+
+
+@pytest.mark.parametrize("n,seed,dist,mode", [(257, 1, "uniform53", 2), (300, 2, "dec4", 1),
+                                              (400, 3, "uniform53", 0)])
+def test_medium_sizes(emu_api, oracle, n, seed, dist, mode):
+    emu_api.set_order_mode(mode)
+    k, order = compare_trajectory(emu_api, oracle, oracle.synth(n, seed, dist), deep=True, deep_every=37)
+    check_order(order, n)
+
+
+def test_tiny_identity(emu_api, oracle):
+    # ntax <= 3: identity ordering (NetMakerOriginal.java:133-140)
+    emu_api.set_order_mode(0)
+    for n in (1, 2, 3):
+        with Handle(emu_api, n) as h:
+            h.set_matrix(oracle.synth(n, 1))
+            order, _ = h.run()
+            assert order.tolist() == list(range(n + 1))
+
+
+def test_run_matches_stepping(emu_api, oracle):
+    emu_api.set_order_mode(0)
+    n = 150
+    D = oracle.synth(n, 5)
+    o_ref, ev_ref, se = oracle.run(D)
+    with Handle(emu_api, n, record_events=True) as h:
+        h.set_matrix(D, chunk_rows=17)
+        order, st = h.run()
+        ev = h.events()
+    assert (order == o_ref).all()
+    assert st.sum_entries == se and st.n_events == len(ev_ref)
+    for f in ("m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id", "entries"):
+        assert (ev[f] == ev_ref[f]).all(), f
+    assert (ev["best"].view(np.int64) == ev_ref["best"].view(np.int64)).all()
+
+
+def test_validate_rejects_bad_matrix(emu_api, oracle):
+    from fastneighbornet_amd._capi import FnnError
+    D = oracle.synth(8, 1)
+    for bad in ("asym", "diag", "nan"):
+        E = D.copy()
+        if bad == "asym":
+            E[2, 5] += 1e-9
+        elif bad == "diag":
+            E[3, 3] = 0.5
+        else:
+            E[1, 4] = E[4, 1] = np.nan
+        with Handle(emu_api, 8, validate=True) as h:
+            h.set_matrix(E)
+            with pytest.raises(FnnError):
+                h.run()

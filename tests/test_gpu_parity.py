@@ -1,0 +1,134 @@
+"""GPU parity tests proper: libfastnn_hip.so through its C ABI against the oracle on the
+same seeded inputs (bit-exact: event records, Sx bits, live matrix bits, final order)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import bits, check_order, compare_trajectory
+from fastneighbornet_amd._capi import FnnError, Handle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_present(hip_api):
+    assert hip_api.device_count() >= 1
+
+
+@pytest.mark.parametrize("dist", ["uniform53", "dec4"])
+def test_small_sizes_deep(hip_api, oracle, dist):
+    for n in [4, 5, 6, 7, 8, 9, 10, 13, 16, 17, 31, 32, 33, 63, 64, 65]:
+        for seed in (1, 2):
+            compare_trajectory(hip_api, oracle, oracle.synth(n, seed, dist), deep=True)
+
+
+@pytest.mark.parametrize("n,seed,dist", [(257, 1, "uniform53"), (513, 2, "dec4"), (700, 3, "uniform53"),
+                                         (1030, 4, "dec4")])
+def test_medium_trajectory(hip_api, oracle, n, seed, dist):
+    # crosses the 512-column / 32-row scan tile boundaries and the 1024 threshold of
+    # NetMakerOriginal.java:361
+    k, order = compare_trajectory(hip_api, oracle, oracle.synth(n, seed, dist), deep=True, deep_every=101)
+    check_order(order, n)
+
+
+@pytest.mark.parametrize("n,seed", [(1500, 1), (2048, 7)])
+def test_run_matches_oracle(hip_api, oracle, n, seed):
+    D = oracle.synth(n, seed)
+    o_ref, ev_ref, se = oracle.run(D, threads=8)
+    with Handle(hip_api, n, validate=True, record_events=True) as h:
+        h.set_matrix(D, chunk_rows=333)
+        order, st = h.run()
+        ev = h.events()
+    assert (order == o_ref).all()
+    assert st.sum_entries == se and st.n_events == len(ev_ref)
+    for f in ("m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id", "entries"):
+        assert (ev[f] == ev_ref[f]).all(), f
+    assert (bits(ev["best"]) == bits(ev_ref["best"])).all()
+
+
+def test_device_synth_is_bit_identical(hip_api, oracle):
+    for n, seed, dist in [(100, 1, "uniform53"), (777, 9, "dec4")]:
+        D = oracle.synth(n, seed, dist)
+        o_ref, _, _ = oracle.run(D, threads=8)
+        with Handle(hip_api, n) as h:
+            h.synth(seed, dist)
+            h.begin()
+            assert (bits(h.live_matrix()) == bits(D)).all()
+            while h.step() is not None:
+                pass
+            assert (h.finish() == o_ref).all()
+
+
+def test_one_call_and_host_mirror(hip_api, oracle):
+    import fastneighbornet_amd as fa
+    n = 300
+    D = oracle.synth(n, 11)
+    o_ref, _, _ = oracle.run(D)
+    D0 = D.copy()
+    assert (fa.canonical_order(D) == o_ref).all()
+    nn = fa.NeighborNetCanonical(D, n, 1, None)
+    assert (nn.runNeighborNet() == o_ref).all()
+    assert (D == D0).all()  # the caller's matrix is not consumed
+    for k in (1, 2, 3):
+        assert fa.NeighborNetCanonical(D[:k, :k], k).runNeighborNet().tolist() == list(range(k + 1))
+
+
+def test_validate_rejects_bad_matrix(hip_api, oracle):
+    D = oracle.synth(40, 1)
+    for bad in ("asym", "diag", "inf"):
+        E = D.copy()
+        if bad == "asym":
+            E[2, 35] += 1e-9
+        elif bad == "diag":
+            E[33, 33] = 0.5
+        else:
+            E[1, 4] = E[4, 1] = np.inf
+        with Handle(hip_api, 40, validate=True) as h:
+            h.set_matrix(E)
+            with pytest.raises(FnnError):
+                h.run()
+
+
+def test_call_sequence_errors(hip_api):
+    with Handle(hip_api, 10) as h:
+        with pytest.raises(FnnError):
+            h.run()  # no matrix
+    with pytest.raises(FnnError):
+        Handle(hip_api, -1)
+
+
+def test_tie_rich_input(hip_api, oracle):
+    # all distances equal: every Q ties, the result is decided purely by scan order
+    n = 67
+    D = np.full((n, n), 0.25)
+    np.fill_diagonal(D, 0.0)
+    compare_trajectory(hip_api, oracle, D, deep=True)
+    # two-valued matrix
+    rng = np.random.default_rng(5)
+    A = rng.integers(1, 3, size=(n, n)).astype(np.float64)
+    A = np.triu(A, 1)
+    A = A + A.T
+    compare_trajectory(hip_api, oracle, A, deep=True)
+
+
+def test_full_size_invariants(hip_api):
+    """BASELINE.json size (32768 taxa, 8 GiB fp64): size-independent properties."""
+    n = 32768
+    with Handle(hip_api, n, record_events=True) as h:
+        h.synth(1, "uniform53")
+        order, st = h.run()
+        ev = h.events()
+    check_order(order, n)
+    assert st.n_events == len(ev)
+    # clusters drop by exactly one per event; c <= m <= 2c; counters follow the event kinds
+    assert (np.diff(ev["c_before"]) == -1).all()
+    assert (ev["c_before"] <= ev["m_before"]).all() and (ev["m_before"] <= 2 * ev["c_before"]).all()
+    dm = {2: 0, 3: -1, 4: -2}
+    for k in (2, 3, 4):
+        sel = np.nonzero(ev["kind"][:-1] == k)[0]
+        assert (ev["m_before"][sel + 1] - ev["m_before"][sel] == dm[k]).all()
+    m, c = ev["m_before"].astype(np.int64), ev["c_before"].astype(np.int64)
+    e = m * (m - 1) // 2 - (m - c)
+    e[ev["kind"] == 5] = 0
+    assert (ev["entries"] == e).all() and st.sum_entries == e.sum()
+    assert n ** 3 / 6 <= st.sum_entries <= n ** 3 / 3

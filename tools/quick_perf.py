@@ -1,0 +1,20 @@
+"""Quick on-GPU timing of whole runs at a few sizes (development aid, not the bench)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fastneighbornet_amd as fa
+from fastneighbornet_amd._capi import Handle
+
+a = fa.api()
+sizes = [int(x) for x in sys.argv[1:]] or [4096]
+for n in sizes:
+    with Handle(a, n) as h:
+        a.set_scan_timing(h._h, 1)
+        h.synth(1, "uniform53")
+        t = time.time()
+        order, st = h.run()
+        dt = time.time() - t
+        gb = st.scan_bytes / 1e9
+        print(f"n={n} total={st.t_total_s:.3f}s init={st.t_init_s:.4f} agglom={st.t_agglom_s:.3f} "
+              f"scan={st.t_scan_s:.3f}s events={st.n_events} sumE/n^3={st.sum_entries / n**3:.4f} "
+              f"scan_GBps={gb / max(st.t_scan_s, 1e-9):.1f} whole_GBps={gb / st.t_total_s:.1f} "
+              f"per_event_overhead_us={(st.t_agglom_s - st.t_scan_s) / max(st.n_events, 1) * 1e6:.1f}", flush=True)
