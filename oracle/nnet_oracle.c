@@ -539,8 +539,11 @@ static inline uint64_t splitmix64_at(uint64_t seed, uint64_t k) {
 }
 
 void nno_synth(double* D, int32_t n, uint64_t seed, int32_t dist) {
-    uint64_t k = 0;
+    /* upper triangle, row-major generator order (rows are independent: the k-th value
+     * is a pure function of k) ... */
+#pragma omp parallel for schedule(dynamic, 64)
     for (int i = 0; i < n; i++) {
+        uint64_t k = (uint64_t)i * (uint64_t)n - (uint64_t)i * ((uint64_t)i + 1) / 2;
         D[(size_t)i * n + i] = 0.0;
         for (int j = i + 1; j < n; j++, k++) {
             double u = (double)(splitmix64_at(seed, k) >> 11) * 0x1.0p-53;
@@ -548,7 +551,13 @@ void nno_synth(double* D, int32_t n, uint64_t seed, int32_t dist) {
             if (dist == 1) d = (double)((int64_t)(u * 1e4) + 1) / 1e4;
             else d = u + 0x1.0p-10;
             D[(size_t)i * n + j] = d;
-            D[(size_t)j * n + i] = d;
         }
     }
+    /* ... then mirrored into the lower triangle in 64 x 64 blocks */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int bi = 0; bi < n; bi += 64)
+        for (int bj = 0; bj <= bi; bj += 64)
+            for (int i = bi; i < bi + 64 && i < n; i++)
+                for (int j = bj; j < bj + 64 && j < i; j++)
+                    D[(size_t)i * n + j] = D[(size_t)j * n + i];
 }
