@@ -38,6 +38,9 @@ def api() -> _capi.Api:
         a._fn("canonical_order_f64", _C.c_int32,
               [_C.POINTER(_C.c_double), _C.c_int32, _C.c_int64, _C.POINTER(_capi.FnnOpts),
                _C.POINTER(_C.c_int32), _C.POINTER(_capi.FnnStats)])
+        a._fn("test_chain_sum", _C.c_int32,
+              [_C.c_int32, _C.POINTER(_C.c_double), _C.c_int32, _C.c_int32, _C.c_int32,
+               _C.POINTER(_C.c_double), _C.POINTER(_C.c_int32)])
         a._fn("stream_probe", _C.c_int32, [_C.c_int32, _C.c_int64, _C.c_int32, _C.POINTER(_C.c_double)])
         _api = a
     return _api

@@ -79,6 +79,7 @@ struct State {
     int32_t nops;
     Op ops[MAX_OPS];
     Event cur;
+    double rx[4];  // ComputeRx results for Cx, Cx.nbr, Cy, Cy.nbr (k_rx_chain -> k_decide)
 };
 
 struct Dev {
@@ -89,7 +90,8 @@ struct Dev {
     int32_t* sid;    // per slot: NetNode.id
     int32_t* spos;   // per slot: NetNode.positionID
     int32_t* pslot;  // reference position -> slot (-1 if empty)
-    double* chain;   // 4 buffers of n doubles, indexed by reference position
+    double* chain;   // 4 buffers of cstride doubles, indexed by reference position
+    int64_t cstride; // n rounded up to 16 (keeps every buffer 16-byte aligned)
     Cand* recs;      // per-block scan records
     State* st;
     Event* evlog;    // n records (if record_events)
@@ -282,7 +284,7 @@ FNN_HD void rx_fill_thread(const Dev& d, int32_t s) {
     for (int k = 0; k < 4; k++) {
         if (z[k] < 0) continue;
         double v = d.D[(int64_t)z[k] * d.ld + s];
-        d.chain[(int64_t)k * d.n + pos] = full ? v : v / 2.0;
+        d.chain[(int64_t)k * d.cstride + pos] = full ? v : v / 2.0;
     }
 }
 

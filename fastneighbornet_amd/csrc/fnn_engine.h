@@ -64,13 +64,14 @@ class Engine {
         ld = round_up(n > 0 ? n : 1, B::kColPad) + 32;
         dev.n = n;
         dev.ld = ld;
+        dev.cstride = round_up(n > 0 ? n : 1, 16);
         size_t nn = (size_t)(n > 0 ? n : 1);
         if (!(dev.D = (double*)be.alloc(sizeof(double) * (size_t)nrows * (size_t)ld)) ||
             !(dev.Sx = (double*)be.alloc(sizeof(double) * (nn + 8))) ||
             !(dev.sid = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
             !(dev.spos = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
             !(dev.pslot = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
-            !(dev.chain = (double*)be.alloc(sizeof(double) * 4 * nn)) ||
+            !(dev.chain = (double*)be.alloc(sizeof(double) * 4 * (size_t)dev.cstride)) ||
             !(dev.recs = (Cand*)be.alloc(sizeof(Cand) * be.max_records(n))) ||
             !(dev.st = (State*)be.alloc(sizeof(State))) ||
             !(dev.evlog = (Event*)be.alloc(sizeof(Event) * (nn + 8))) ||

@@ -23,6 +23,7 @@
 #include <cmath>
 #include <new>
 
+#include "fnn_chain.h"
 #include "fnn_engine.h"
 
 namespace fnn {
@@ -126,45 +127,207 @@ __global__ __launch_bounds__(256) void k_rx_fill(Dev d) {
     rx_fill_thread(d, blockIdx.x * 256 + threadIdx.x);
 }
 
-// Sequential sum of buf[0..m) in index order, exactly as a scalar loop would do it.
-// One wave: the lanes stage 512 values at a time in LDS, then every lane runs the
-// same dependent add chain over the staged values (LDS broadcast reads).
-constexpr int CHAIN_CHUNK = 512;
-__device__ __forceinline__ double wave_chain_sum(const double* buf, int m, double* lds, bool active) {
-    double s = 0.0;
-    const int lane = threadIdx.x & 63;
-    for (int base = 0; base < m; base += CHAIN_CHUNK) {
-        __syncthreads();
-        if (active) {
-#pragma unroll
-            for (int i = lane; i < CHAIN_CHUNK; i += 64) lds[i] = (base + i < m) ? buf[base + i] : 0.0;
-        }
-        __syncthreads();
-        if (active) {
-#pragma unroll 16
-            for (int i = 0; i < CHAIN_CHUNK; i++) s += lds[i];  // + 0.0 padding changes no bit
-        }
-    }
-    return s;
+// ------------------------------------------------------------------ exact block-parallel chain sum
+// Sequential fp64 sum of buf[0..m) in index order, bit-identical to a scalar loop, evaluated by
+// one 1024-thread workgroup (algorithm and proof sketch: fnn_chain.h; CPU model: tests/emu).
+//   1. every thread loads EPT consecutive addends; a block-wide prefix sum of the thread totals
+//      gives each thread a PREDICTED partial sum in front of its chunk;
+//   2. the thread turns its addends into parity automata relative to the predicted binade and
+//      composes them; a chunk whose addends do not all sit in one binade is "mixed" and its
+//      addends are parked in LDS;
+//   3. a segmented scan over the lanes of each wave composes runs of chunks of equal binade;
+//   4. wave 0 walks over the runs: one exact O(1) update per run, ordinary additions for mixed
+//      chunks, and retries at finer granularity where the binade assumption is refuted.
+constexpr int CH_T = 1024;
+constexpr int CH_NSLOT = 48;
+
+template <int EPT>
+struct ChainLds {
+    double wtot[CH_T / 64];
+    double s;
+    int slot_count;
+    int32_t E[CH_T];
+    int32_t flags[CH_T];  // bit0 pure, bit1 last chunk of its run
+    int32_t slot[CH_T];
+    uint64_t own0[CH_T], own1[CH_T], sc0[CH_T], sc1[CH_T];
+    double vals[CH_NSLOT][EPT];
+};
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
+    return (uint64_t)__shfl_up((unsigned long long)v, d, 64);
+}
+__device__ __forceinline__ int readlane_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
 }
 
-// ------------------------------------------------------------------ k_decide
-__global__ __launch_bounds__(256) void k_decide(Dev d) {
-    __shared__ double lds[4][CHAIN_CHUNK];
-    __shared__ double rx[4];
-    State* st = d.st;
-    if (!st->ev_active || st->ev_finish) return;
-    const int w = threadIdx.x >> 6;
-    if (threadIdx.x < 4) rx[threadIdx.x] = 0.0;
-    if (st->need_rx) {
-        int z = (w == 0) ? st->sa : (w == 1) ? st->sap : (w == 2) ? st->sb : st->sbp;
-        double s = wave_chain_sum(d.chain + (size_t)w * d.n, st->m_old, lds[w], z >= 0);
+__device__ __forceinline__ void chain_serial_global(double& s, const double* buf, int start, int cnt, int m) {
+    for (int i = 0; i < cnt; i++)
+        if (start + i < m) s += buf[start + i];
+}
+
+template <int EPT>
+__device__ double block_chain_sum(const double* __restrict__ buf, int m, int guard_bits, ChainLds<EPT>& L,
+                                  ChainStats* stats) {
+    static_assert(EPT % 2 == 0 && EPT <= 64, "EPT");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    ChainStats cs{0, 0, 0, 0};
+    if (tid == 0) L.s = 0.0;
+    for (int base = 0; base < m; base += CH_T * EPT) {
+        if (tid == 0) L.slot_count = 0;
+        // 1. addends of this thread (buf is 16-byte aligned, chunks start at even indices)
+        double a[EPT];
+        const int idx0 = base + tid * EPT;
+#pragma unroll
+        for (int i = 0; i < EPT; i += 2) {
+            if (idx0 + i + 1 < m) {
+                const double2 v = *reinterpret_cast<const double2*>(buf + idx0 + i);
+                a[i] = v.x; a[i + 1] = v.y;
+            } else {
+                a[i] = (idx0 + i < m) ? buf[idx0 + i] : 0.0;
+                a[i + 1] = 0.0;
+            }
+        }
+        double loc = 0.0;
+#pragma unroll
+        for (int i = 0; i < EPT; i++) loc += a[i];
+        double inc = loc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) L.wtot[w] = inc;
         __syncthreads();
-        if ((threadIdx.x & 63) == 0 && z >= 0) rx[w] = s;
+        double wpre = 0.0;
+        for (int k = 0; k < w; k++) wpre += L.wtot[k];
+        const double s_in = L.s;
+        double A = s_in + (wpre + (inc - loc));  // predicted partial sum in front of this chunk
+        // 2. automata
+        bool pure = true;
+        int32_t E = -1;
+        Mono mt = mono_identity();
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            const double A1 = A + a[i];
+            int32_t e;
+            Mono mo;
+            if (!chain_classify(a[i], A, A1, guard_bits, e, mo)) pure = false;
+            else {
+                if (E < 0) E = e;
+                if (e != E) pure = false;
+                mt = mono_compose(mt, mo);
+            }
+            A = A1;
+        }
+        int slot = -1;
+        if (!pure && idx0 < m) {
+            slot = atomicAdd(&L.slot_count, 1);
+            if (slot < CH_NSLOT) {
+#pragma unroll
+                for (int i = 0; i < EPT; i++) L.vals[slot][i] = a[i];
+            } else slot = -1;
+        }
+        // 3. runs inside the wave: segmented inclusive scan of the chunk automata
+        const int pure_prev = __shfl_up((int)pure, 1, 64);
+        const int E_prev = __shfl_up(E, 1, 64);
+        const bool head = (lane == 0) || !pure || !pure_prev || (E != E_prev);
+        Mono sc = mt;
+        int f = head ? 1 : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            Mono o;
+            o.i0 = shfl_up_u64(sc.i0, d);
+            o.i1 = shfl_up_u64(sc.i1, d);
+            const int fo = __shfl_up(f, d, 64);
+            if (lane >= d && !f) { sc = mono_compose(o, sc); f = fo; }
+        }
+        const int head_next = __shfl_down((int)head, 1, 64);
+        const bool endf = (lane == 63) || head_next || (idx0 + EPT >= m);
+        L.E[tid] = E;
+        L.flags[tid] = (pure ? 1 : 0) | (endf ? 2 : 0);
+        L.slot[tid] = slot;
+        L.own0[tid] = mt.i0; L.own1[tid] = mt.i1;
+        L.sc0[tid] = sc.i0; L.sc1[tid] = sc.i1;
+        __syncthreads();
+        // 4. the walk (every lane of wave 0 carries the same s)
+        if (w == 0) {
+            double s = s_in;
+            for (int ww = 0; ww < CH_T / 64; ww++) {
+                const int first = base + ww * 64 * EPT;
+                if (first >= m) break;
+                const int nvalid = min(64, (m - first + EPT - 1) / EPT);
+                const int id = ww * 64 + lane;
+                const int rE = L.E[id], rf = L.flags[id], rslot = L.slot[id];
+                const uint64_t ro0 = L.own0[id], ro1 = L.own1[id], rs0 = L.sc0[id], rs1 = L.sc1[id];
+                uint64_t endmask = __ballot((rf & 2) != 0);
+                if (nvalid < 64) endmask &= (1ULL << nvalid) - 1;
+                int prev_end = -1;
+                while (endmask) {
+                    const int e = __builtin_ctzll(endmask);
+                    endmask &= endmask - 1;
+                    const int fe = readlane_i32(rf, e);
+                    if (fe & 1) {
+                        Mono mr;
+                        mr.i0 = readlane_u64(rs0, e);
+                        mr.i1 = readlane_u64(rs1, e);
+                        if (mono_apply(s, readlane_i32(rE, e), mr)) cs.runs++;
+                        else {
+                            cs.run_fail++;
+                            for (int j = prev_end + 1; j <= e; j++) {
+                                Mono mj;
+                                mj.i0 = readlane_u64(ro0, j);
+                                mj.i1 = readlane_u64(ro1, j);
+                                if (!mono_apply(s, readlane_i32(rE, j), mj)) {
+                                    cs.thread_fail++;
+                                    chain_serial_global(s, buf, first + j * EPT, EPT, m);
+                                }
+                            }
+                        }
+                    } else {
+                        cs.mixed++;
+                        const int sl = readlane_i32(rslot, e);
+                        if (sl >= 0) {
+                            const uint64_t v = f2u(lane < EPT ? L.vals[sl][lane] : 0.0);
+#pragma unroll
+                            for (int j = 0; j < EPT; j++) s += u2f(readlane_u64(v, j));
+                        } else chain_serial_global(s, buf, first + e * EPT, EPT, m);
+                    }
+                    prev_end = e;
+                }
+            }
+            if (lane == 0) L.s = s;
+        }
+        __syncthreads();
     }
     __syncthreads();
+    if (stats && tid == 0) *stats = cs;
+    return L.s;
+}
+
+constexpr int CH_EPT = 16;
+
+// ------------------------------------------------------------------ k_rx_chain / k_decide
+// the <=4 sequential ComputeRx sums, one workgroup each (NetMakerOriginal.java:413-420)
+__global__ __launch_bounds__(CH_T) void k_rx_chain(Dev d) {
+    __shared__ ChainLds<CH_EPT> L;
+    State* st = d.st;
+    if (!st->ev_active || st->ev_finish || !st->need_rx) return;
+    const int b = blockIdx.x;
+    const int z = (b == 0) ? st->sa : (b == 1) ? st->sap : (b == 2) ? st->sb : st->sbp;
+    double r = 0.0;
+    if (z >= 0) r = block_chain_sum<CH_EPT>(d.chain + (size_t)b * d.cstride, st->m_old, CH_GUARD_BITS, L, nullptr);
+    if (threadIdx.x == 0) st->rx[b] = r;
+}
+
+__global__ __launch_bounds__(64) void k_decide(Dev d) {
+    State* st = d.st;
+    if (!st->ev_active || st->ev_finish) return;
     if (threadIdx.x == 0) {
-        double r[4] = {rx[0], rx[1], rx[2], rx[3]};
+        double r[4] = {0.0, 0.0, 0.0, 0.0};
+        if (st->need_rx) { r[0] = st->rx[0]; r[1] = st->rx[1]; r[2] = st->rx[2]; r[3] = st->rx[3]; }
         decide(d, r);
     }
 }
@@ -190,13 +353,21 @@ __global__ __launch_bounds__(256) void k_add(Dev d) {
 }
 
 // ------------------------------------------------------------------ k_finalize
-__global__ __launch_bounds__(64) void k_finalize(Dev d) {
-    __shared__ double lds[CHAIN_CHUNK];
+__global__ __launch_bounds__(CH_T) void k_finalize(Dev d) {
+    __shared__ ChainLds<CH_EPT> L;
     State* st = d.st;
     if (!st->ev_active) return;
     double usx = 0.0;
-    if (!st->ev_finish) usx = wave_chain_sum(d.chain, st->m, lds, true);
+    if (!st->ev_finish) usx = block_chain_sum<CH_EPT>(d.chain, st->m, CH_GUARD_BITS, L, nullptr);
     if (threadIdx.x == 0) finalize(d, usx);
+}
+
+// diagnostic entry: the block chain sum on an arbitrary buffer (tests)
+template <int EPT>
+__global__ __launch_bounds__(CH_T) void k_test_chain(const double* buf, int m, int guard_bits, double* out, ChainStats* stats) {
+    __shared__ ChainLds<EPT> L;
+    double r = block_chain_sum<EPT>(buf, m, guard_bits, L, stats);
+    if (threadIdx.x == 0) *out = r;
 }
 
 // ------------------------------------------------------------------ setup kernels
@@ -395,11 +566,12 @@ struct HipBackend {
         scan_launches++;
         hipLaunchKernelGGL(k_pick, dim3(1), dim3(1024), 0, stream, d, (int)(gs.x * gs.y));
         hipLaunchKernelGGL(k_rx_fill, g1, dim3(256), 0, stream, d);
-        hipLaunchKernelGGL(k_decide, dim3(1), dim3(256), 0, stream, d);
+        hipLaunchKernelGGL(k_rx_chain, dim3(4), dim3(CH_T), 0, stream, d);
+        hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, stream, d);
         hipLaunchKernelGGL(k_subtract, g1, dim3(256), 0, stream, d);
         for (int i = 0; i < MAX_OPS; i++) hipLaunchKernelGGL(k_op, g1, dim3(256), 0, stream, d, i);
         hipLaunchKernelGGL(k_add, g1, dim3(256), 0, stream, d);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, stream, d);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
 };
@@ -532,6 +704,33 @@ int32_t fnn_canonical_order_f64(const double* D, int32_t n, int64_t ld, const fn
     fnn_destroy(h);
     fnn::g_last_error = keep;
     return rc;
+}
+
+int32_t fnn_test_chain_sum(int32_t device, const double* host_buf, int32_t m, int32_t guard_bits, int32_t ept,
+                           double* out, int32_t* stats4) {
+    if (!host_buf || m < 0 || !out || (ept != 8 && ept != 16 && ept != 32))
+        return fnn::fail(FNN_EINVAL, "fnn_test_chain_sum: bad arguments");
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return fnn::fail(FNN_EHIP, hipGetErrorString(e));
+    double* dbuf = nullptr; double* dout = nullptr; fnn::ChainStats* dst = nullptr;
+    size_t bytes = sizeof(double) * (size_t)(m + 2);
+    if (hipMalloc((void**)&dbuf, bytes) != hipSuccess || hipMalloc((void**)&dout, 8) != hipSuccess ||
+        hipMalloc((void**)&dst, sizeof(fnn::ChainStats)) != hipSuccess) {
+        (void)hipFree(dbuf); (void)hipFree(dout); (void)hipFree(dst);
+        return fnn::fail(FNN_ENOMEM, "fnn_test_chain_sum: hipMalloc failed");
+    }
+    (void)hipMemcpy(dbuf, host_buf, sizeof(double) * (size_t)m, hipMemcpyHostToDevice);
+    if (ept == 8) hipLaunchKernelGGL(fnn::k_test_chain<8>, dim3(1), dim3(fnn::CH_T), 0, 0, dbuf, m, guard_bits, dout, dst);
+    else if (ept == 16) hipLaunchKernelGGL(fnn::k_test_chain<16>, dim3(1), dim3(fnn::CH_T), 0, 0, dbuf, m, guard_bits, dout, dst);
+    else hipLaunchKernelGGL(fnn::k_test_chain<32>, dim3(1), dim3(fnn::CH_T), 0, 0, dbuf, m, guard_bits, dout, dst);
+    e = hipDeviceSynchronize();
+    fnn::ChainStats hs{0, 0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(out, dout, 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&hs, dst, sizeof(hs), hipMemcpyDeviceToHost);
+    (void)hipFree(dbuf); (void)hipFree(dout); (void)hipFree(dst);
+    if (e != hipSuccess) return fnn::fail(FNN_EHIP, std::string("fnn_test_chain_sum: ") + hipGetErrorString(e));
+    if (stats4) { stats4[0] = hs.runs; stats4[1] = hs.mixed; stats4[2] = hs.run_fail; stats4[3] = hs.thread_fail; }
+    return FNN_OK;
 }
 
 int32_t fnn_stream_probe(int32_t device, int64_t bytes, int32_t reps, double* gbps_out) {

@@ -137,6 +137,14 @@ int32_t fnn_set_scan_timing(fnn_handle* h, int32_t enable);
 int32_t fnn_canonical_order_f64(const double* D, int32_t n, int64_t ld, const fnn_opts* opts,
                                 int32_t* order_out, fnn_stats* stats);
 
+/* Diagnostic: the exact block-parallel evaluation of the sequential fp64 sum
+ * (((0 + b[0]) + b[1]) + ...) used for ComputeRx / u.Sx (NetMakerOriginal.java:551-560,
+ * :532), run on an arbitrary host buffer.  ept in {8,16,32} = addends per thread;
+ * guard_bits = 22 in production, 0 to provoke the fallback paths.  stats4 (may be NULL)
+ * = {runs applied, chunks added one by one, rejected runs, rejected chunks}. */
+int32_t fnn_test_chain_sum(int32_t device, const double* host_buf, int32_t m, int32_t guard_bits,
+                           int32_t ept, double* out, int32_t* stats4);
+
 /* Device-side read-only streaming probe: reads `bytes` bytes `reps` times and
  * returns the achieved GB/s (the "measured stream" line next to the nominal
  * 8 TB/s peak). */

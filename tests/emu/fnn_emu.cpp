@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../fastneighbornet_amd/csrc/fnn_engine.h"
+#include "../../fastneighbornet_amd/csrc/fnn_chain.h"
 
 namespace {
 
@@ -122,7 +123,7 @@ struct EmuBackend {
                 for (int32_t s : thread_order(m_bound)) fnn::rx_fill_thread(d, s);
                 int32_t z[4] = {st.sa, st.sap, st.sb, st.sbp};
                 for (int k = 0; k < 4; k++)
-                    if (z[k] >= 0) rx[k] = fnn::chain_sum(d.chain + (int64_t)k * d.n, st.m_old);
+                    if (z[k] >= 0) rx[k] = fnn::chain_sum(d.chain + (int64_t)k * d.cstride, st.m_old);
             }
             fnn::decide(d, rx);
             // k_subtract
@@ -148,7 +149,77 @@ using EmuEngine = fnn::Engine<EmuBackend>;
 
 }  // namespace
 
+// CPU model of the block-parallel exact chain sum (fnn_hip.hip: block_chain_sum): same
+// primitives (fnn_chain.h), same unit structure (thread chunks of `ept` addends, waves of
+// 64 threads, runs of equal predicted binade, walker with the two fallback levels).  The
+// predicted prefix is computed in long double so that it differs from the true sequential
+// partial sums the way the GPU's tree-ordered prefix does.
+static double chain_model(const double* buf, int m, int ept, int guard_bits, fnn::ChainStats* cs) {
+    using namespace fnn;
+    const int T = 1024;
+    double s = 0.0;
+    ChainStats st{0, 0, 0, 0};
+    for (int base = 0; base < m; base += T * ept) {
+        std::vector<int> pure(T), E(T);
+        std::vector<Mono> own(T);
+        long double pre = 0.0L;
+        for (int t = 0; t < T; t++) {
+            bool ok = true;
+            int Et = -1;
+            Mono mt = mono_identity();
+            for (int i = 0; i < ept; i++) {
+                int idx = base + t * ept + i;
+                double a = idx < m ? buf[idx] : 0.0;
+                double A0 = (double)((long double)s + pre);
+                pre += (long double)a;
+                double A1 = (double)((long double)s + pre);
+                int32_t e;
+                Mono mo;
+                if (!chain_classify(a, A0, A1, guard_bits, e, mo)) { ok = false; continue; }
+                if (Et < 0) Et = e;
+                if (e != Et) ok = false;
+                mt = mono_compose(mt, mo);
+            }
+            pure[t] = ok;
+            E[t] = Et;
+            own[t] = mt;
+        }
+        auto serial = [&](int t) {
+            for (int i = 0; i < ept; i++) {
+                int idx = base + t * ept + i;
+                if (idx < m) s += buf[idx];
+            }
+        };
+        for (int w = 0; w < T / 64; w++) {
+            int t = w * 64;
+            while (t < (w + 1) * 64) {
+                if (!pure[t]) { serial(t); st.mixed++; t++; continue; }
+                int e = t;
+                Mono run = own[t];
+                while (e + 1 < (w + 1) * 64 && pure[e + 1] && E[e + 1] == E[t]) { e++; run = mono_compose(run, own[e]); }
+                if (mono_apply(s, E[t], run)) st.runs++;
+                else {
+                    st.run_fail++;
+                    for (int j = t; j <= e; j++)
+                        if (!mono_apply(s, E[j], own[j])) { st.thread_fail++; serial(j); }
+                }
+                t = e + 1;
+            }
+        }
+    }
+    if (cs) *cs = st;
+    return s;
+}
+
 extern "C" {
+
+double emu_chain_model(const double* buf, int32_t m, int32_t ept, int32_t guard_bits, int32_t* stats4) {
+    fnn::ChainStats cs;
+    double r = chain_model(buf, m, ept, guard_bits, &cs);
+    if (stats4) { stats4[0] = cs.runs; stats4[1] = cs.mixed; stats4[2] = cs.run_fail; stats4[3] = cs.thread_fail; }
+    return r;
+}
+double emu_chain_serial(const double* buf, int32_t m) { return fnn::chain_sum(buf, m); }
 
 void emu_set_order_mode(int32_t mode) { g_order_mode = mode; }
 const char* emu_last_error(void) { return fnn::g_last_error.c_str(); }
