@@ -17,12 +17,19 @@
 // A run of addends can therefore be reduced in any tree order to a pair of integers
 // (increment if S enters even, increment if S enters odd) and applied to the exact s in
 // O(1) -- provided the binade assumption holds, which is checked exactly when the pair is
-// applied: s must have exponent E at the start of the run and S + increment must stay
+// applied: s must lie in binade E at the start of the run and S + increment must stay
 // below 2^53 (monotonicity then covers every intermediate partial sum).  Where the check
 // fails, and for every addend that is negative, non-finite or crosses a binade, the
 // ordinary fp64 addition is executed instead.  The binade each addend will see is only
 // PREDICTED (from an approximate parallel prefix sum); exactness never depends on the
 // prediction, only speed does.
+//
+// Representation.  All integers of the scheme are < 2^53 when the run is valid, so they are
+// carried as doubles in units of u: scaling by the power of two 1/u is exact, floor / fract /
+// sums of such integers are exact, and a sum that leaves the exact range can only come out
+// >= 2^53 (fp addition of non-negative terms is monotone), which the validity check rejects.
+// Every operation below is a single correctly rounded IEEE operation whose result is exact
+// in the cases that are accepted; nothing depends on FMA contraction being on or off.
 #ifndef FNN_CHAIN_H
 #define FNN_CHAIN_H
 
@@ -33,88 +40,112 @@
 namespace fnn {
 
 struct Mono {
-    uint64_t i0, i1;  // increment of S (in ulps of the run's binade) for S entering even / odd
+    double i0, i1;  // increment of S (in ulps of the run's binade) for S entering even / odd
 };
 
-constexpr uint64_t CH_MANT = (1ULL << 52) - 1;
-constexpr uint64_t CH_IMPL = 1ULL << 52;
-constexpr uint64_t CH_SAT = 1ULL << 62;  // saturation keeps mispredicted runs from wrapping
-constexpr int CH_GUARD_BITS = 22;        // predicted prefix must be 2^-30 (relative) away from a power of two
+constexpr int CH_E_MIN = 128, CH_E_MAX = 1900;  // biased binades served by the integer path
+constexpr int CH_GUARD_BITS = 1;  // non-zero: keep the 2^-20 guard band around powers of two
+constexpr double CH_TWO52 = 4503599627370496.0;
+constexpr double CH_TWO53 = 9007199254740992.0;
 
 FNN_HD uint64_t f2u(double x) { return __builtin_bit_cast(uint64_t, x); }
 FNN_HD double u2f(uint64_t x) { return __builtin_bit_cast(double, x); }
+FNN_HD uint32_t hi32(double x) { return (uint32_t)(f2u(x) >> 32); }
 
-FNN_HD uint64_t sat_add(uint64_t a, uint64_t b) {  // a, b <= CH_SAT
-    uint64_t c = a + b;
-    return c > CH_SAT ? CH_SAT : c;
+// exact power of two 2^k, k in [-1022, 1023]
+FNN_HD double pow2i(int k) { return u2f((uint64_t)(k + 1023) << 52); }
+// 1 / ulp of binade E (biased): ulp = 2^(E - 1075)
+FNN_HD double inv_ulp(int32_t E) { return pow2i(1075 - E); }
+FNN_HD double ulp_of(int32_t E) { return pow2i(E - 1075); }
+
+FNN_HD double ch_floor(double x) { return __builtin_floor(x); }
+// x is a non-negative integer < 2^53 held in a double: is it odd?
+FNN_HD bool ch_odd(double x) {
+    const double h = x * 0.5;
+    return h != ch_floor(h);
 }
 
 FNN_HD Mono mono_identity() {
     Mono m;
-    m.i0 = 0;
-    m.i1 = 0;
+    m.i0 = 0.0;
+    m.i1 = 0.0;
     return m;
-}
-
-// branch-free select (also keeps hipcc from forming a scalar select on a vector compare)
-FNN_HD uint64_t sel_by_parity(uint64_t parity_src, uint64_t even_v, uint64_t odd_v) {
-    uint64_t mask = 0 - (parity_src & 1ULL);
-    return (even_v & ~mask) | (odd_v & mask);
 }
 
 // A then B
 FNN_HD Mono mono_compose(Mono A, Mono B) {
     Mono r;
-    r.i0 = sat_add(A.i0, sel_by_parity(A.i0, B.i0, B.i1));
-    r.i1 = sat_add(A.i1, sel_by_parity(A.i1 + 1, B.i0, B.i1));
+    r.i0 = A.i0 + (ch_odd(A.i0) ? B.i1 : B.i0);
+    r.i1 = A.i1 + (ch_odd(A.i1) ? B.i0 : B.i1);  // entering odd: parity after A is odd + A.i1
     return r;
 }
 
-// Addend a, with the PREDICTED partial sums before (A0) and after (A1) it.  Returns true
-// and the addend's automaton relative to the binade E (biased exponent of A0) when the
-// addend can be treated on the integer path.
-FNN_HD bool chain_classify(double a, double A0, double A1, int guard_bits, int32_t& E, Mono& mo) {
-    const uint64_t ua = f2u(a), u0 = f2u(A0), u1 = f2u(A1);
-    if ((ua | u0 | u1) >> 63) return false;  // negative (or -0.0) anywhere: ordinary addition
-    const uint32_t eab = (uint32_t)(ua >> 52) & 0x7FF;
-    const uint32_t e0 = (uint32_t)(u0 >> 52) & 0x7FF, e1 = (uint32_t)(u1 >> 52) & 0x7FF;
-    if (eab == 0x7FF || e0 == 0 || e0 == 0x7FF || e1 != e0) return false;
-    if (guard_bits > 0) {
-        const uint64_t g = 1ULL << guard_bits;
-        const uint64_t f0 = u0 & CH_MANT, f1 = u1 & CH_MANT;
-        if (f0 < g || f0 > CH_MANT - g || f1 < g || f1 > CH_MANT - g) return false;
-    }
-    const uint32_t ea = eab ? eab : 1;                      // subnormals share the exponent of DBL_MIN
-    const uint64_t Ma = (ua & CH_MANT) | (eab ? CH_IMPL : 0);  // a = Ma * 2^(ea - 1075)
-    const int shift = (int)e0 - (int)ea;                    // a / u = Ma / 2^shift
-    if (shift < 0) return false;
-    uint64_t q, up0, up1;
-    if (shift == 0) {
-        q = Ma; up0 = up1 = 0;
-    } else if (shift >= 64) {
-        q = 0; up0 = up1 = 0;  // a < u / 2
-    } else {
-        q = Ma >> shift;
-        const uint64_t rem = Ma & ((1ULL << shift) - 1), half = 1ULL << (shift - 1);
-        if (rem < half) up0 = up1 = 0;
-        else if (rem > half) up0 = up1 = 1;
-        else { up0 = q & 1; up1 = (q & 1) ^ 1; }  // tie: S + q + r must be even
+// Binade prediction from the approximate partial sums in front of (A0) and behind (A1) an
+// addend: true and E when both lie in the same served binade and neither is within 2^-20
+// (relative) of a power of two.  Uses the high words only.
+FNN_HD bool chain_predict(double A0, double A1, bool guard, int32_t& E) {
+    const uint32_t h0 = hi32(A0), h1 = hi32(A1);
+    const uint32_t e0 = h0 >> 20, e1 = h1 >> 20;  // sign bit included: negative -> e >= 2048
+    if (e0 != e1 || e0 < (uint32_t)CH_E_MIN || e0 > (uint32_t)CH_E_MAX) return false;
+    if (guard) {
+        const uint32_t f0 = h0 & 0xFFFFFu, f1 = h1 & 0xFFFFFu;
+        if (f0 == 0u || f0 == 0xFFFFFu || f1 == 0u || f1 == 0xFFFFFu) return false;
     }
     E = (int32_t)e0;
+    return true;
+}
+
+// Automaton of addend a relative to binade E (invu = inv_ulp(E)).  False for addends that
+// must go through the ordinary addition (negative, -0.0, NaN, too large for the binade).
+FNN_HD bool chain_automaton(double a, double invu, Mono& mo) {
+    if (!(a >= 0.0) || (f2u(a) >> 63)) return false;  // NaN, negative, -0.0
+    const double t = a * invu;                         // a in ulps; exact (see header)
+    if (!(t < CH_TWO53)) return false;                 // a >= 2^(E+1) (or inf): crosses the binade
+    const double q = ch_floor(t);
+    const double f = t - q;                            // exact
+    double up0, up1;
+    if (f < 0.5) { up0 = 0.0; up1 = 0.0; }
+    else if (f > 0.5) { up0 = 1.0; up1 = 1.0; }
+    else {  // tie: S + q + r must be even
+        const bool qodd = ch_odd(q);
+        up0 = qodd ? 1.0 : 0.0;
+        up1 = qodd ? 0.0 : 1.0;
+    }
     mo.i0 = q + up0;
     mo.i1 = q + up1;
+    return true;
+}
+
+// mt := mt then automaton(a), with the common case (no tie: the addend's automaton is the
+// constant q + r) reduced to two additions.  False when a must go through ordinary addition.
+FNN_HD bool chain_accumulate(double a, double invu, Mono& mt) {
+    const double t = a * invu;                   // a in ulps; exact (see header); -0.0 counts as 0
+    if (!(t >= 0.0 && t < CH_TWO53)) return false;  // NaN, negative, or a >= 2^(E+1)
+    const double q = ch_floor(t);
+    const double f = t - q;                      // exact
+    if (f == 0.5) {                              // tie: S + q + r must be even
+        Mono mo;
+        const bool qodd = ch_odd(q);
+        mo.i0 = q + (qodd ? 1.0 : 0.0);
+        mo.i1 = q + (qodd ? 0.0 : 1.0);
+        mt = mono_compose(mt, mo);
+    } else {
+        const double c = q + (f > 0.5 ? 1.0 : 0.0);
+        mt.i0 += c;
+        mt.i1 += c;
+    }
     return true;
 }
 
 // Apply a composed automaton to the exact running sum.  False (s untouched) when the
 // binade assumption does not hold.
 FNN_HD bool mono_apply(double& s, int32_t E, Mono mo) {
-    const uint64_t us = f2u(s);
-    if ((us >> 52) != (uint64_t)E) return false;  // sign bit clear and biased exponent == E
-    const uint64_t S = (us & CH_MANT) | CH_IMPL;
-    const uint64_t S2 = S + sel_by_parity(S, mo.i0, mo.i1);
-    if (S2 >= (1ULL << 53)) return false;
-    s = u2f(((uint64_t)E << 52) | (S2 & CH_MANT));
+    if (E < CH_E_MIN || E > CH_E_MAX) return false;
+    const double S = s * inv_ulp(E);  // exact scaling; in [2^52, 2^53) iff s is in binade E
+    if (!(S >= CH_TWO52 && S < CH_TWO53)) return false;
+    const double S2 = S + (ch_odd(S) ? mo.i1 : mo.i0);
+    if (!(S2 < CH_TWO53)) return false;
+    s = S2 * ulp_of(E);               // exact
     return true;
 }
 

@@ -90,13 +90,27 @@ struct Dev {
     int32_t* sid;    // per slot: NetNode.id
     int32_t* spos;   // per slot: NetNode.positionID
     int32_t* pslot;  // reference position -> slot (-1 if empty)
-    double* chain;   // 4 buffers of cstride doubles, indexed by reference position
-    int64_t cstride; // n rounded up to 16 (keeps every buffer 16-byte aligned)
+    double* chain;   // 4 buffers of cstride doubles, addressed through chain_addr(position)
+    int64_t cstride; // n rounded up to a whole super-chunk
     Cand* recs;      // per-block scan records
     State* st;
     Event* evlog;    // n records (if record_events)
     Agg3Rec* agglog; // n records
 };
+
+// Chain buffers (addends of the sequential sums, indexed by reference position e) are
+// stored chunk-interleaved: the chain kernel gives thread t of a 1024-thread workgroup the
+// CH_EPT consecutive addends [t*CH_EPT, (t+1)*CH_EPT) of a 32768-addend super-chunk; with the
+// j-th PAIR of every chunk stored contiguously over t, each of the thread's 16-byte loads is
+// perfectly coalesced across the wave.  The producers scatter by position anyway.
+constexpr int CH_T = 1024;               // threads of the chain workgroup
+constexpr int CH_EPT = 32;               // addends per thread
+constexpr int CH_SC = CH_T * CH_EPT;     // addends per super-chunk
+FNN_HD int64_t chain_addr(int32_t e) {
+    const int32_t sc = e / CH_SC, r = e % CH_SC;
+    const int32_t t = r / CH_EPT, j = r % CH_EPT;
+    return (int64_t)sc * CH_SC + (int64_t)(j >> 1) * (2 * CH_T) + 2 * t + (j & 1);
+}
 
 FNN_HD double inf_f64() {
     union { uint64_t u; double d; } v;
@@ -284,14 +298,14 @@ FNN_HD void rx_fill_thread(const Dev& d, int32_t s) {
     for (int k = 0; k < 4; k++) {
         if (z[k] < 0) continue;
         double v = d.D[(int64_t)z[k] * d.ld + s];
-        d.chain[(int64_t)k * d.cstride + pos] = full ? v : v / 2.0;
+        d.chain[(int64_t)k * d.cstride + chain_addr(pos)] = full ? v : v / 2.0;
     }
 }
 
 // Rx = 0.0; for i in position order: Rx += term  (sequential, :551-560)
 FNN_HD double chain_sum(const double* buf, int32_t m) {
     double s = 0.0;
-    for (int32_t i = 0; i < m; i++) s += buf[i];
+    for (int32_t i = 0; i < m; i++) s += buf[chain_addr(i)];
     return s;
 }
 
@@ -476,7 +490,7 @@ FNN_HD void add_thread(const Dev& d, int32_t s) {
         if (sp) d.Sx[s + 1] += dpu;
         val = dpu;
     }
-    d.chain[d.spos[s]] = val;  // adding +0.0 to a running sum that starts at +0.0 changes no bit
+    d.chain[chain_addr(d.spos[s])] = val;  // adding +0.0 to a running sum that starts at +0.0 changes no bit
 }
 
 // u.Sx = sequential sum; u.nbr.Sx = u.Sx (:518-519, 532, 535); close the event

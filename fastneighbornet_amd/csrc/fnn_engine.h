@@ -64,7 +64,7 @@ class Engine {
         ld = round_up(n > 0 ? n : 1, B::kColPad) + 32;
         dev.n = n;
         dev.ld = ld;
-        dev.cstride = round_up(n > 0 ? n : 1, 16);
+        dev.cstride = round_up(n > 0 ? n : 1, CH_SC);
         size_t nn = (size_t)(n > 0 ? n : 1);
         if (!(dev.D = (double*)be.alloc(sizeof(double) * (size_t)nrows * (size_t)ld)) ||
             !(dev.Sx = (double*)be.alloc(sizeof(double) * (nn + 8))) ||

@@ -59,49 +59,85 @@ __device__ __forceinline__ Cand block_reduce(Cand c, Cand* sh) {
 }
 
 // ------------------------------------------------------------------ k_scan
+// Tiles of SCAN_TH rows x SCAN_TW columns cover the lower triangle of the live m x m block.
+// Row tiles come in bands of R = SCAN_TW / SCAN_TH; every row tile of band g owns g + 1 column
+// tiles, so the tiles in front of band g number R * g * (g + 1) / 2.  A fixed-size grid strides
+// over the linear tile index (no empty workgroups, at most gridDim.x records for k_pick).
+constexpr int SCAN_R = SCAN_TW / SCAN_TH;
+
+__host__ __device__ inline int scan_tile_count(int m) {
+    const int nrt = (m + SCAN_TH - 1) / SCAN_TH;
+    const int G = nrt / SCAN_R, rr = nrt % SCAN_R;
+    return (SCAN_R / 2) * G * (G + 1) + rr * (G + 1);
+}
+
+__device__ __forceinline__ void scan_tile_decode(int t, int& rt, int& ct) {
+    int g = (int)((sqrtf(1.0f + (float)t * (8.0f / SCAN_R)) - 1.0f) * 0.5f);
+    while ((SCAN_R / 2) * (g + 1) * (g + 2) <= t) g++;
+    while ((SCAN_R / 2) * g * (g + 1) > t) g--;
+    const int r = t - (SCAN_R / 2) * g * (g + 1);
+    rt = SCAN_R * g + r / (g + 1);
+    ct = r % (g + 1);
+}
+
+typedef double fnn_v2f64 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ double2 ld16(const double* p) {
+    if (NT) {
+        const fnn_v2f64 v = __builtin_nontemporal_load(reinterpret_cast<const fnn_v2f64*>(p));
+        return make_double2(v.x, v.y);
+    }
+    return *reinterpret_cast<const double2*>(p);
+}
+
+template <bool NT>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan(Dev d) {
     __shared__ Cand sh[SCAN_THREADS / 64];
     const State* st = d.st;
     Cand best;
     best.q = inf_f64();
     best.key = ~0ULL;
-    const int rt = blockIdx.y, ct = blockIdx.x;
-    const int m = st->m;
-    const int rbase = rt * SCAN_TH;
-    if (!st->done && rbase < m && ct * SCAN_TW <= rbase + SCAN_TH - 1) {
+    if (!st->done) {
+        const int m = st->m;
         const int twoP = 2 * st->P;
         const double cm2 = (double)st->c - 2.0;
-        const int c0 = ct * SCAN_TW + 2 * (int)threadIdx.x;
-        if (c0 < m && c0 <= rbase + SCAN_TH - 2) {
-            const double2 sxc = *reinterpret_cast<const double2*>(d.Sx + c0);
-            const int2 pc = *reinterpret_cast<const int2*>(d.spos + c0);
-            const double* colbase = d.D + c0;
+        const int ntiles = scan_tile_count(m);
+        for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+            int rt, ct;
+            scan_tile_decode(t, rt, ct);
+            const int rbase = rt * SCAN_TH;
+            const int c0 = ct * SCAN_TW + 2 * (int)threadIdx.x;
+            if (c0 < m && c0 <= rbase + SCAN_TH - 2) {
+                const double2 sxc = *reinterpret_cast<const double2*>(d.Sx + c0);
+                const int2 pc = *reinterpret_cast<const int2*>(d.spos + c0);
+                const double* colbase = d.D + c0;
 #pragma unroll 1
-            for (int half = 0; half < SCAN_TH / 16; half++) {
-                const int rb = rbase + 16 * half;
-                if (rb >= m) break;
-                double2 a[8], b[8];
+                for (int half = 0; half < SCAN_TH / 16; half++) {
+                    const int rb = rbase + 16 * half;
+                    if (rb >= m) break;
+                    double2 a[8], b[8];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int r0 = rb + 2 * k;  // r0 + 1 < nrows (padded), c0 + 1 < ld: always in bounds
-                    a[k] = *reinterpret_cast<const double2*>(colbase + (int64_t)r0 * d.ld);
-                    b[k] = *reinterpret_cast<const double2*>(colbase + (int64_t)(r0 + 1) * d.ld);
-                }
+                    for (int k = 0; k < 8; k++) {
+                        const int r0 = rb + 2 * k;  // r0 + 1 < nrows (padded), c0 + 1 < ld: always in bounds
+                        a[k] = ld16<NT>(colbase + (int64_t)r0 * d.ld);
+                        b[k] = ld16<NT>(colbase + (int64_t)(r0 + 1) * d.ld);
+                    }
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int r0 = rb + 2 * k;
-                    if (c0 <= r0) {
-                        const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + r0);
-                        const int2 pr = *reinterpret_cast<const int2*>(d.spos + r0);
-                        scan_micro(r0, c0, m, twoP, cm2, a[k].x, a[k].y, b[k].x, b[k].y,
-                                   sxr.x, sxr.y, pr.x, pr.y, sxc.x, sxc.y, pc.x, pc.y, best);
+                    for (int k = 0; k < 8; k++) {
+                        const int r0 = rb + 2 * k;
+                        if (c0 <= r0) {
+                            const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + r0);
+                            const int2 pr = *reinterpret_cast<const int2*>(d.spos + r0);
+                            scan_micro(r0, c0, m, twoP, cm2, a[k].x, a[k].y, b[k].x, b[k].y,
+                                       sxr.x, sxr.y, pr.x, pr.y, sxc.x, sxc.y, pc.x, pc.y, best);
+                        }
                     }
                 }
             }
         }
     }
     best = block_reduce<SCAN_THREADS / 64>(best, sh);
-    if (threadIdx.x == 0) d.recs[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = best;
+    if (threadIdx.x == 0) d.recs[blockIdx.x] = best;
 }
 
 // ------------------------------------------------------------------ k_pick
@@ -138,7 +174,6 @@ __global__ __launch_bounds__(256) void k_rx_fill(Dev d) {
 //   3. a segmented scan over the lanes of each wave composes runs of chunks of equal binade;
 //   4. wave 0 walks over the runs: one exact O(1) update per run, ordinary additions for mixed
 //      chunks, and retries at finer granularity where the binade assumption is refuted.
-constexpr int CH_T = 1024;
 constexpr int CH_NSLOT = 48;
 
 template <int EPT>
@@ -149,7 +184,7 @@ struct ChainLds {
     int32_t E[CH_T];
     int32_t flags[CH_T];  // bit0 pure, bit1 last chunk of its run
     int32_t slot[CH_T];
-    uint64_t own0[CH_T], own1[CH_T], sc0[CH_T], sc1[CH_T];
+    double own0[CH_T], own1[CH_T], sc0[CH_T], sc1[CH_T];
     double vals[CH_NSLOT][EPT];
 };
 
@@ -165,30 +200,33 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
 
 __device__ __forceinline__ void chain_serial_global(double& s, const double* buf, int start, int cnt, int m) {
     for (int i = 0; i < cnt; i++)
-        if (start + i < m) s += buf[start + i];
+        if (start + i < m) s += buf[chain_addr(start + i)];
 }
+
+__device__ int g_chain_stop_after = 0;  // diagnostic: 1 loads+prefix, 2 +automata, 3 +segmented scan (0 = full)
 
 template <int EPT>
 __device__ double block_chain_sum(const double* __restrict__ buf, int m, int guard_bits, ChainLds<EPT>& L,
                                   ChainStats* stats) {
+    const int stop_after = stats ? g_chain_stop_after : 0;
     static_assert(EPT % 2 == 0 && EPT <= 64, "EPT");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     ChainStats cs{0, 0, 0, 0};
     if (tid == 0) L.s = 0.0;
     for (int base = 0; base < m; base += CH_T * EPT) {
         if (tid == 0) L.slot_count = 0;
-        // 1. addends of this thread (buf is 16-byte aligned, chunks start at even indices)
+        // 1. addends of this thread: chunk-interleaved buffer (fnn_core.h chain_addr), so the j-th
+        //    16-byte load of all lanes of a wave is one contiguous 1 KiB segment
+        static_assert(EPT == CH_EPT, "the buffer layout is fixed to CH_EPT addends per thread");
         double a[EPT];
         const int idx0 = base + tid * EPT;
+        const double* src = buf + base + 2 * tid;
 #pragma unroll
         for (int i = 0; i < EPT; i += 2) {
-            if (idx0 + i + 1 < m) {
-                const double2 v = *reinterpret_cast<const double2*>(buf + idx0 + i);
-                a[i] = v.x; a[i + 1] = v.y;
-            } else {
-                a[i] = (idx0 + i < m) ? buf[idx0 + i] : 0.0;
-                a[i + 1] = 0.0;
-            }
+            double2 v = make_double2(0.0, 0.0);
+            if (idx0 + i < m) v = *reinterpret_cast<const double2*>(src + (i >> 1) * (2 * CH_T));
+            a[i] = v.x;
+            a[i + 1] = (idx0 + i + 1 < m) ? v.y : 0.0;
         }
         double loc = 0.0;
 #pragma unroll
@@ -205,23 +243,18 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
         for (int k = 0; k < w; k++) wpre += L.wtot[k];
         const double s_in = L.s;
         double A = s_in + (wpre + (inc - loc));  // predicted partial sum in front of this chunk
-        // 2. automata
-        bool pure = true;
+        if (stop_after == 1) { if (tid == 0) L.s = A; __syncthreads(); continue; }
+        // 2. automaton of the chunk: the binade is predicted once per chunk (partial sums are
+        //    monotone over non-negative addends; a negative addend makes the chunk "mixed")
         int32_t E = -1;
+        bool pure = chain_predict(A, A + loc, guard_bits != 0, E);
         Mono mt = mono_identity();
+        if (pure) {
+            const double invu = inv_ulp(E);
 #pragma unroll
-        for (int i = 0; i < EPT; i++) {
-            const double A1 = A + a[i];
-            int32_t e;
-            Mono mo;
-            if (!chain_classify(a[i], A, A1, guard_bits, e, mo)) pure = false;
-            else {
-                if (E < 0) E = e;
-                if (e != E) pure = false;
-                mt = mono_compose(mt, mo);
-            }
-            A = A1;
+            for (int i = 0; i < EPT; i++) pure = pure && chain_accumulate(a[i], invu, mt);
         }
+        if (stop_after == 2) { if (tid == 0) L.s = mt.i0 + (double)E + (pure ? 1.0 : 0.0); __syncthreads(); continue; }
         int slot = -1;
         if (!pure && idx0 < m) {
             slot = atomicAdd(&L.slot_count, 1);
@@ -239,8 +272,8 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             Mono o;
-            o.i0 = shfl_up_u64(sc.i0, d);
-            o.i1 = shfl_up_u64(sc.i1, d);
+            o.i0 = __shfl_up(sc.i0, d, 64);
+            o.i1 = __shfl_up(sc.i1, d, 64);
             const int fo = __shfl_up(f, d, 64);
             if (lane >= d && !f) { sc = mono_compose(o, sc); f = fo; }
         }
@@ -252,6 +285,7 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
         L.own0[tid] = mt.i0; L.own1[tid] = mt.i1;
         L.sc0[tid] = sc.i0; L.sc1[tid] = sc.i1;
         __syncthreads();
+        if (stop_after == 3) { if (tid == 0) L.s = sc.i0; __syncthreads(); continue; }
         // 4. the walk (every lane of wave 0 carries the same s)
         if (w == 0) {
             double s = s_in;
@@ -261,7 +295,7 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
                 const int nvalid = min(64, (m - first + EPT - 1) / EPT);
                 const int id = ww * 64 + lane;
                 const int rE = L.E[id], rf = L.flags[id], rslot = L.slot[id];
-                const uint64_t ro0 = L.own0[id], ro1 = L.own1[id], rs0 = L.sc0[id], rs1 = L.sc1[id];
+                const uint64_t ro0 = f2u(L.own0[id]), ro1 = f2u(L.own1[id]), rs0 = f2u(L.sc0[id]), rs1 = f2u(L.sc1[id]);
                 uint64_t endmask = __ballot((rf & 2) != 0);
                 if (nvalid < 64) endmask &= (1ULL << nvalid) - 1;
                 int prev_end = -1;
@@ -271,15 +305,15 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
                     const int fe = readlane_i32(rf, e);
                     if (fe & 1) {
                         Mono mr;
-                        mr.i0 = readlane_u64(rs0, e);
-                        mr.i1 = readlane_u64(rs1, e);
+                        mr.i0 = u2f(readlane_u64(rs0, e));
+                        mr.i1 = u2f(readlane_u64(rs1, e));
                         if (mono_apply(s, readlane_i32(rE, e), mr)) cs.runs++;
                         else {
                             cs.run_fail++;
                             for (int j = prev_end + 1; j <= e; j++) {
                                 Mono mj;
-                                mj.i0 = readlane_u64(ro0, j);
-                                mj.i1 = readlane_u64(ro1, j);
+                                mj.i0 = u2f(readlane_u64(ro0, j));
+                                mj.i1 = u2f(readlane_u64(ro1, j));
                                 if (!mono_apply(s, readlane_i32(rE, j), mj)) {
                                     cs.thread_fail++;
                                     chain_serial_global(s, buf, first + j * EPT, EPT, m);
@@ -307,7 +341,6 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
     return L.s;
 }
 
-constexpr int CH_EPT = 16;
 
 // ------------------------------------------------------------------ k_rx_chain / k_decide
 // the <=4 sequential ComputeRx sums, one workgroup each (NetMakerOriginal.java:413-420)
@@ -437,6 +470,8 @@ struct HipBackend {
     double scan_ms = 0.0;
     int64_t scan_launches = 0;
     int* d_bad = nullptr;
+    int scan_grid = 8192;   // workgroups of the scan (FNN_SCAN_GRID)
+    bool scan_nt = true;    // non-temporal matrix loads in the scan (FNN_SCAN_NT)
 
     std::string err() const { return std::string(hipGetErrorString(last)); }
 
@@ -449,6 +484,8 @@ struct HipBackend {
         if (!HIPOK(hipSetDevice(device))) return fail(FNN_EHIP, "hipSetDevice failed (" + err() + ")");
         if (!HIPOK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)))
             return fail(FNN_EHIP, "hipStreamCreate failed (" + err() + ")");
+        if (const char* e = std::getenv("FNN_SCAN_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) scan_grid = v; }
+        if (const char* e = std::getenv("FNN_SCAN_NT")) scan_nt = std::atoi(e) != 0;
         opened = true;
         return FNN_OK;
     }
@@ -472,10 +509,7 @@ struct HipBackend {
     void free(void* p) {
         if (p) (void)hipFree(p);
     }
-    size_t max_records(int32_t n) {
-        size_t nn = (size_t)(n > 0 ? n : 1);
-        return ((nn + SCAN_TW - 1) / SCAN_TW) * ((nn + SCAN_TH - 1) / SCAN_TH);
-    }
+    size_t max_records(int32_t) { return 65536; }
     int32_t memset(void* p, int v, size_t b) {
         return HIPOK(hipMemsetAsync(p, v, b, stream)) && HIPOK(hipStreamSynchronize(stream)) ? FNN_OK : FNN_EHIP;
     }
@@ -556,15 +590,17 @@ struct HipBackend {
 
     int32_t launch_event(const Dev& d, int32_t m_bound) {
         if (m_bound < 1) m_bound = 1;
-        dim3 gs((unsigned)((m_bound + SCAN_TW - 1) / SCAN_TW), (unsigned)((m_bound + SCAN_TH - 1) / SCAN_TH));
+        int nt = scan_tile_count(m_bound);
+        dim3 gs((unsigned)(nt < scan_grid ? (nt > 0 ? nt : 1) : scan_grid));
         dim3 g1 = grid1(m_bound);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timing) { e0 = next_event(); e1 = next_event(); }
         if (e0) (void)hipEventRecord(e0, stream);
-        hipLaunchKernelGGL(k_scan, gs, dim3(SCAN_THREADS), 0, stream, d);
+        if (scan_nt) hipLaunchKernelGGL(k_scan<true>, gs, dim3(SCAN_THREADS), 0, stream, d);
+        else hipLaunchKernelGGL(k_scan<false>, gs, dim3(SCAN_THREADS), 0, stream, d);
         if (e1) (void)hipEventRecord(e1, stream);
         scan_launches++;
-        hipLaunchKernelGGL(k_pick, dim3(1), dim3(1024), 0, stream, d, (int)(gs.x * gs.y));
+        hipLaunchKernelGGL(k_pick, dim3(1), dim3(1024), 0, stream, d, (int)gs.x);
         hipLaunchKernelGGL(k_rx_fill, g1, dim3(256), 0, stream, d);
         hipLaunchKernelGGL(k_rx_chain, dim3(4), dim3(CH_T), 0, stream, d);
         hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, stream, d);
@@ -708,21 +744,27 @@ int32_t fnn_canonical_order_f64(const double* D, int32_t n, int64_t ld, const fn
 
 int32_t fnn_test_chain_sum(int32_t device, const double* host_buf, int32_t m, int32_t guard_bits, int32_t ept,
                            double* out, int32_t* stats4) {
-    if (!host_buf || m < 0 || !out || (ept != 8 && ept != 16 && ept != 32))
-        return fnn::fail(FNN_EINVAL, "fnn_test_chain_sum: bad arguments");
+    if (!host_buf || m < 0 || !out || ept != fnn::CH_EPT)
+        return fnn::fail(FNN_EINVAL, "fnn_test_chain_sum: bad arguments (ept must be 32)");
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return fnn::fail(FNN_EHIP, hipGetErrorString(e));
+    // the kernel reads the chunk-interleaved layout the engine's producers write
+    const size_t cap = (size_t)fnn::round_up(m > 0 ? m : 1, fnn::CH_SC);
+    std::vector<double> perm(cap, 0.0);
+    for (int32_t i = 0; i < m; i++) perm[(size_t)fnn::chain_addr(i)] = host_buf[i];
     double* dbuf = nullptr; double* dout = nullptr; fnn::ChainStats* dst = nullptr;
-    size_t bytes = sizeof(double) * (size_t)(m + 2);
-    if (hipMalloc((void**)&dbuf, bytes) != hipSuccess || hipMalloc((void**)&dout, 8) != hipSuccess ||
+    if (hipMalloc((void**)&dbuf, sizeof(double) * cap) != hipSuccess || hipMalloc((void**)&dout, 8) != hipSuccess ||
         hipMalloc((void**)&dst, sizeof(fnn::ChainStats)) != hipSuccess) {
         (void)hipFree(dbuf); (void)hipFree(dout); (void)hipFree(dst);
         return fnn::fail(FNN_ENOMEM, "fnn_test_chain_sum: hipMalloc failed");
     }
-    (void)hipMemcpy(dbuf, host_buf, sizeof(double) * (size_t)m, hipMemcpyHostToDevice);
-    if (ept == 8) hipLaunchKernelGGL(fnn::k_test_chain<8>, dim3(1), dim3(fnn::CH_T), 0, 0, dbuf, m, guard_bits, dout, dst);
-    else if (ept == 16) hipLaunchKernelGGL(fnn::k_test_chain<16>, dim3(1), dim3(fnn::CH_T), 0, 0, dbuf, m, guard_bits, dout, dst);
-    else hipLaunchKernelGGL(fnn::k_test_chain<32>, dim3(1), dim3(fnn::CH_T), 0, 0, dbuf, m, guard_bits, dout, dst);
+    (void)hipMemcpy(dbuf, perm.data(), sizeof(double) * cap, hipMemcpyHostToDevice);
+    {
+        int stop = 0;
+        if (const char* ev = std::getenv("FNN_CHAIN_STOP")) stop = std::atoi(ev);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(fnn::g_chain_stop_after), &stop, sizeof(int));
+    }
+    hipLaunchKernelGGL(fnn::k_test_chain<fnn::CH_EPT>, dim3(1), dim3(fnn::CH_T), 0, 0, dbuf, m, guard_bits, dout, dst);
     e = hipDeviceSynchronize();
     fnn::ChainStats hs{0, 0, 0, 0};
     if (e == hipSuccess) e = hipMemcpy(out, dout, 8, hipMemcpyDeviceToHost);

@@ -139,8 +139,8 @@ int32_t fnn_canonical_order_f64(const double* D, int32_t n, int64_t ld, const fn
 
 /* Diagnostic: the exact block-parallel evaluation of the sequential fp64 sum
  * (((0 + b[0]) + b[1]) + ...) used for ComputeRx / u.Sx (NetMakerOriginal.java:551-560,
- * :532), run on an arbitrary host buffer.  ept in {8,16,32} = addends per thread;
- * guard_bits = 22 in production, 0 to provoke the fallback paths.  stats4 (may be NULL)
+ * :532), run on an arbitrary host buffer.  ept = addends per thread (32, fixed by the
+ * buffer layout); guard_bits != 0 in production, 0 to provoke the fallback paths.  stats4 (may be NULL)
  * = {runs applied, chunks added one by one, rejected runs, rejected chunks}. */
 int32_t fnn_test_chain_sum(int32_t device, const double* host_buf, int32_t m, int32_t guard_bits,
                            int32_t ept, double* out, int32_t* stats4);

@@ -164,21 +164,25 @@ static double chain_model(const double* buf, int m, int ept, int guard_bits, fnn
         std::vector<Mono> own(T);
         long double pre = 0.0L;
         for (int t = 0; t < T; t++) {
-            bool ok = true;
-            int Et = -1;
-            Mono mt = mono_identity();
+            // (same per-thread logic as block_chain_sum in fnn_hip.hip)
+            double A0 = (double)((long double)s + pre);
+            long double pre_end = pre;
             for (int i = 0; i < ept; i++) {
                 int idx = base + t * ept + i;
-                double a = idx < m ? buf[idx] : 0.0;
-                double A0 = (double)((long double)s + pre);
-                pre += (long double)a;
-                double A1 = (double)((long double)s + pre);
-                int32_t e;
-                Mono mo;
-                if (!chain_classify(a, A0, A1, guard_bits, e, mo)) { ok = false; continue; }
-                if (Et < 0) Et = e;
-                if (e != Et) ok = false;
-                mt = mono_compose(mt, mo);
+                pre_end += (long double)(idx < m ? buf[idx] : 0.0);
+            }
+            double A1 = (double)((long double)s + pre_end);
+            pre = pre_end;
+            int32_t Et = -1;
+            bool ok = chain_predict(A0, A1, guard_bits != 0, Et);
+            Mono mt = mono_identity();
+            if (ok) {
+                const double invu = inv_ulp(Et);
+                for (int i = 0; i < ept; i++) {
+                    int idx = base + t * ept + i;
+                    double a = idx < m ? buf[idx] : 0.0;
+                    if (!chain_accumulate(a, invu, mt)) { ok = false; break; }
+                }
             }
             pure[t] = ok;
             E[t] = Et;
@@ -219,7 +223,11 @@ double emu_chain_model(const double* buf, int32_t m, int32_t ept, int32_t guard_
     if (stats4) { stats4[0] = cs.runs; stats4[1] = cs.mixed; stats4[2] = cs.run_fail; stats4[3] = cs.thread_fail; }
     return r;
 }
-double emu_chain_serial(const double* buf, int32_t m) { return fnn::chain_sum(buf, m); }
+double emu_chain_serial(const double* buf, int32_t m) {
+    double s = 0.0;
+    for (int32_t i = 0; i < m; i++) s += buf[i];
+    return s;
+}
 
 void emu_set_order_mode(int32_t mode) { g_order_mode = mode; }
 const char* emu_last_error(void) { return fnn::g_last_error.c_str(); }
