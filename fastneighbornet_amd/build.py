@@ -59,11 +59,31 @@ def check_isa() -> None:
             raise RuntimeError("suspicious SCC use in device ISA (compiler miscompile?):\n" + "\n".join(bad))
 
 
+HOST_DIR = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(HERE, "libfastnn_host.so")
+CLI = os.path.join(HERE, "bin", "fastnn")
+
+
+def build_host(force: bool = False) -> None:
+    """C++ host side: Phylip reader / formatting library (g++) and the `fastnn` CLI."""
+    srcs = [os.path.join(HOST_DIR, f) for f in ("fastnn_host.cpp", "fastnn_host.hpp", "fastnn_main.cpp")]
+    newest = max(os.path.getmtime(p) for p in srcs + [os.path.join(ROOT, "include", "fastnn.h")])
+    if force or not os.path.exists(HOST_LIB) or os.path.getmtime(HOST_LIB) < newest:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", HOST_LIB,
+                               os.path.join(HOST_DIR, "fastnn_host.cpp")])
+    if force or not os.path.exists(CLI) or os.path.getmtime(CLI) < max(newest, os.path.getmtime(LIB)):
+        os.makedirs(os.path.dirname(CLI), exist_ok=True)
+        subprocess.check_call([hipcc(), "-O2", "-std=c++17", "-o", CLI, os.path.join(HOST_DIR, "fastnn_main.cpp"),
+                               os.path.join(HOST_DIR, "fastnn_host.cpp"), "-L" + HERE, "-lfastnn_hip",
+                               "-Wl,-rpath,$ORIGIN/.."])
+
+
 def build(force: bool = False) -> str:
     if force or stale():
         check_isa()
         cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC]
         subprocess.check_call(cmd)
+    build_host(force)
     return LIB
 
 

@@ -1,0 +1,95 @@
+// fastnn_host.hpp -- C++ host side above the C ABI (include/fastnn.h), mirroring the
+// reference's own interface for the Canonical path so that a FastNN user finds the same
+// names and argument meanings:
+//
+//   nnet::DistancesAndNames      Phylip reader          DistancesAndNames.java:12-153
+//   nnet::NetMakerOriginal       abstract engine seam   NetMakerOriginal.java:17-162
+//   nnet::NeighborNetCanonical   -mode Canonical        NeighborNetCanonical.java:29-36
+//
+// The Java toolchain is not available in the build image (no JDK), so the host side is
+// C++; INTEGRATION.md shows the JNI stub a maintainer of the Java code base would add.
+#ifndef FASTNN_HOST_HPP
+#define FASTNN_HOST_HPP
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/fastnn.h"
+
+namespace nnet {
+
+// DistancesAndNames.java:12-153 -- packed strict upper triangle + taxon names
+class DistancesAndNames {
+  public:
+    std::vector<double> distances;  // (n*(n-1))/2, row-major upper triangle
+    int nTaxa = 0;
+    std::vector<std::string> names;
+
+    // upperIndex (DistancesAndNames.java:24-38); 64-bit where the Java int would overflow
+    int64_t upperIndex(int i, int j) const {
+        if (i == j) return -1;
+        int64_t a = i < j ? i : j, b = i < j ? j : i;
+        return a * (nTaxa - 1) - a * (a - 1) / 2 + b - (a + 1);
+    }
+    // get(i, j) (:142-149): symmetric accessor, zero diagonal
+    double get(int i, int j) const {
+        int64_t u = upperIndex(i, j);
+        return u < 0 ? 0.0 : distances[(size_t)u];
+    }
+    DistancesAndNames() = default;
+    // ctor (:43-132): throws std::runtime_error where the Java would throw
+    DistancesAndNames(const std::string& fileString, int numTaxa);
+    // the dense matrix FastNN.main builds (FastNN.java:307-312)
+    std::vector<double> toMatrix() const;
+};
+
+// header line: all whitespace removed, Integer.parseInt (FastNN.java:269-274)
+int readTaxaCount(const std::string& fileName);
+
+// Arrays.toString(int[]) as printed by `-order` (FastNN.java:394-397)
+std::string orderingToString(const std::vector<int32_t>& ordering);
+
+// NetMakerOriginal.java:17-162: the seam.  `d` is the dense row-major n x n matrix
+// (`double[][] d`); numThreads / pool are accepted for signature compatibility.
+class NetMakerOriginal {
+  public:
+    enum class NMMode { CANONICAL, RELAXED, RANDOM_N, RANDOM_NLOGN, RANDOM_LOGN, ORIGINAL };  // :19-21
+    NetMakerOriginal(const double* d, int numTaxa, int numThreads, void* pool)
+        : D(d), ntax(numTaxa), numThreads(numThreads), pool(pool) {}
+    virtual ~NetMakerOriginal() = default;
+    virtual std::vector<int32_t> runNeighborNet() = 0;  // :129
+    const std::vector<int32_t>& getOrdering() const { return ordering; }  // :72-74
+
+  protected:
+    const double* D;
+    const int ntax;
+    const int numThreads;
+    void* pool;
+    std::vector<int32_t> ordering;
+};
+
+// -mode Canonical on the GPU engine.  Unlike the reference (NetMakerOriginal.java:653-656)
+// the caller's matrix is not modified.
+class NeighborNetCanonical : public NetMakerOriginal {
+  public:
+    NeighborNetCanonical(const double* d, int numTaxa, int numThreads = 1, void* pool = nullptr, int device = 0)
+        : NetMakerOriginal(d, numTaxa, numThreads, pool), device(device) {}
+    std::vector<int32_t> runNeighborNet() override {
+        ordering.assign((size_t)ntax + 1, 0);
+        fnn_opts o{};
+        o.device = device;
+        o.validate = 1;
+        int32_t rc = fnn_canonical_order_f64(D, ntax, ntax, &o, ordering.data(), &stats);
+        if (rc != FNN_OK) throw std::runtime_error(std::string("fastnn: ") + fnn_last_error());
+        return ordering;
+    }
+    fnn_stats stats{};
+
+  private:
+    int device;
+};
+
+}  // namespace nnet
+#endif

@@ -1,0 +1,124 @@
+// fastnn -- command line front end keeping FastNN's surface for the Canonical path
+// (FastNN.java:110-397): -distFile <file> -mode <string> -threads <int> -mult <int>
+// -order -additive -time -help, banner and progress lines on stderr, the circular order as
+// Arrays.toString on stdout with -order.
+//
+// Not built yet (SURVEY.md section 8(f) "next"): the split-weight / Nexus output of a run
+// without -order (FastNN.java:401-540) and the non-Canonical modes; both end with a message
+// and exit status 2 instead of silently doing something else.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <string>
+
+#include "fastnn_host.hpp"
+
+static void help() {
+    // layout of commons-cli HelpFormatter.printHelp("FastNN", options) (FastNN.java:104-108)
+    std::printf(
+        "usage: FastNN\n"
+        " -additive                  Performs an additivity check for the relaxed\n"
+        "                            search strategy.\n"
+        " -distFile <file_location>  The distance file in Phyllip format\n"
+        " -help                      print this message\n"
+        " -mode <string>             Determines the algorithm mode to run.  The\n"
+        "                            options are: Canonical, Relaxed, Filter,\n"
+        "                            Random_N, Random_NLOGN, Random_LOGN.  Default:\n"
+        "                            Canonical\n"
+        " -mult <integer>            For the random mode, this gives the constant\n"
+        "                            multiplier that multiplies the search amount.\n"
+        "                            Default: 5\n"
+        " -order                     Outputs the circular order only.\n"
+        " -threads <integer>         The number of threads to use.  Default: 1\n"
+        " -time                      Show timing results.\n"
+        " -gpu <integer>             (extension) HIP device ordinal.  Default: 0\n");
+}
+
+int main(int argc, char** argv) {
+    std::fprintf(stderr, "FastNN Version: 0.3.5\n");
+    std::fprintf(stderr, "Engine: fastnn-mi355x (HIP gfx950, C ABI %d)\n", fnn_abi_version());
+    std::string fileName, modeStr = "CANONICAL";
+    bool haveFile = false, order = false, timeMe = false, wantHelp = false;
+    int nThreads = 1, device = 0;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto needArg = [&](const char* name) -> const char* {
+            if (i + 1 >= argc) {
+                std::fprintf(stderr, "Parsing failed.  Reason: Missing argument for option: %s\n", name);
+                help();
+                std::exit(0);
+            }
+            return argv[++i];
+        };
+        if (a == "-help" || a == "--help") wantHelp = true;
+        else if (a == "-distFile" || a == "--distFile") { fileName = needArg("distFile"); haveFile = true; }
+        else if (a == "-threads" || a == "--threads") nThreads = std::atoi(needArg("threads"));
+        else if (a == "-mode" || a == "--mode") modeStr = needArg("mode");
+        else if (a == "-mult" || a == "--mult") (void)needArg("mult");
+        else if (a == "-gpu" || a == "--gpu") device = std::atoi(needArg("gpu"));
+        else if (a == "-order" || a == "--order") order = true;
+        else if (a == "-additive" || a == "--additive") {}
+        else if (a == "-time" || a == "--time") timeMe = true;
+        else {
+            std::fprintf(stderr, "Parsing failed.  Reason: Unrecognized option: %s\n", a.c_str());
+            help();
+            return 0;
+        }
+    }
+    if (wantHelp) { help(); return 0; }
+    if (!haveFile) {  // FastNN.java:235-238
+        std::fprintf(stderr, "The program needs a distance file!!\n");
+        help();
+        return 0;
+    }
+    std::transform(modeStr.begin(), modeStr.end(), modeStr.begin(), [](unsigned char c) { return (char)std::toupper(c); });
+    const char* known[] = {"CANONICAL", "RELAXED", "RANDOM_N", "RANDOM_NLOGN", "RANDOM_LOGN", "ORIGINAL"};
+    if (std::find_if(std::begin(known), std::end(known), [&](const char* k) { return modeStr == k; }) == std::end(known)) {
+        // NMMode.valueOf throws IllegalArgumentException (FastNN.java:263-265)
+        std::fprintf(stderr, "Exception in thread \"main\" java.lang.IllegalArgumentException: No enum constant nnet.NetMakerOriginal.NMMode.%s\n",
+                     modeStr.c_str());
+        return 1;
+    }
+    int nTaxa = 0;
+    try {
+        nTaxa = nnet::readTaxaCount(fileName);
+    } catch (const std::exception& e) {
+        std::string msg = e.what();
+        if (msg.rfind("FileNotFound", 0) == 0) {  // FastNN.java:280-285
+            std::fprintf(stderr, "%s\n", msg.c_str());
+            help();
+            return 0;
+        }
+        std::fprintf(stderr, "Exception in thread \"main\" %s\n", msg.c_str());
+        return 1;
+    }
+    std::fprintf(stderr, "Calculating a tree for %d taxa using %d thread(s).\n", nTaxa, nThreads);
+    std::fprintf(stderr, "Getting distances from the file: %s\n", fileName.c_str());
+    if (modeStr != "CANONICAL" && modeStr != "ORIGINAL") {
+        std::fprintf(stderr, "fastnn-mi355x: -mode %s is not provided by this engine (only Canonical is).\n", modeStr.c_str());
+        return 2;
+    }
+    try {
+        nnet::DistancesAndNames danOrg(fileName, nTaxa);
+        std::vector<double> D = danOrg.toMatrix();
+        nnet::NeighborNetCanonical myNMO(D.data(), nTaxa, nThreads, nullptr, device);
+        std::fprintf(stderr, "Using the canonical implementation.\n");
+        auto t0 = std::chrono::steady_clock::now();
+        std::vector<int32_t> ordering = myNMO.runNeighborNet();
+        auto t1 = std::chrono::steady_clock::now();
+        if (timeMe) std::fprintf(stderr, "Got the order in (s): %.9g\n", std::chrono::duration<double>(t1 - t0).count());
+        if (order) {
+            std::printf("%s\n", nnet::orderingToString(ordering).c_str());
+            return 0;
+        }
+        std::fprintf(stderr,
+                     "fastnn-mi355x: split weights and the Nexus document (a run without -order) are not built yet; "
+                     "use -order.\n");
+        return 2;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "Exception in thread \"main\" %s\n", e.what());
+        return 1;
+    }
+}

@@ -1,0 +1,108 @@
+"""Host side above the C ABI: the Phylip reader (DistancesAndNames.java:43-132 with its
+quirks), the header parse (FastNN.java:269-274) and the CLI surface (FastNN.java:136-268,
+:394-397).  The GPU test runs BASELINE.json configs[0] (64-taxa Phylip, -mode Canonical)
+end to end through the `fastnn` binary."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "fastneighbornet_amd")
+
+
+def write_phylip(path, D, names=None, style="lower", sep=" "):
+    n = D.shape[0]
+    with open(path, "w") as f:
+        f.write(f"{n}\n")
+        for i in range(n):
+            name = names[i] if names else f"t{i + 1}"
+            cols = range(i) if style == "lower" else range(n)
+            vals = [repr(float(D[i, j])) for j in cols]
+            # the reference splits on single spaces first, then on tabs inside a token
+            f.write(name + (" " + sep.join(vals) if vals else "") + "\n")
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    from fastneighbornet_amd import build
+    build.build()
+    lib = C.CDLL(os.path.join(PKG, "libfastnn_host.so"))
+    lib.fnnh_read_taxa_count.argtypes = [C.c_char_p]
+    lib.fnnh_read_phylip.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.c_char_p]
+    return lib
+
+
+def read(hostlib, path, n):
+    out = np.zeros((n, n))
+    names = C.create_string_buffer(256 * n)
+    rc = hostlib.fnnh_read_phylip(path.encode(), n, out.ctypes.data_as(C.POINTER(C.c_double)), names)
+    return rc, out, [names.raw[i * 256:(i + 1) * 256].split(b"\0")[0].decode() for i in range(n)]
+
+
+def test_reader_lower_and_square_and_tabs(hostlib, oracle, tmp_path):
+    D = oracle.synth(9, 3)
+    for style, sep in (("lower", " "), ("square", " "), ("lower", "\t"), ("square", "  ")):
+        p = str(tmp_path / f"{style}{len(sep)}.phy")
+        write_phylip(p, D, style=style, sep=sep)
+        assert hostlib.fnnh_read_taxa_count(p.encode()) == 9
+        rc, out, names = read(hostlib, p, 9)
+        assert rc == 0 and (out == D).all() and names[0] == "t1" and names[8] == "t9"
+
+
+def test_reader_quirks(hostlib, tmp_path):
+    # header with embedded whitespace; only the first `row` values of a line are used; the token
+    # buffer is not cleared between lines (a short line re-uses the previous line's values);
+    # rows beyond numTaxa are ignored
+    p = str(tmp_path / "q.phy")
+    open(p, "w").write(" 4 \t\nA\nB 1.5 99 98\nC 2.5 3.5 77\nD 4.5\nE 9 9 9 9\n")
+    assert hostlib.fnnh_read_taxa_count(p.encode()) == 4
+    rc, out, names = read(hostlib, p, 4)
+    assert rc == 0 and names == ["A", "B", "C", "D"]
+    exp = np.zeros((4, 4))
+    exp[1, 0] = 1.5
+    exp[2, 0], exp[2, 1] = 2.5, 3.5
+    exp[3, 0], exp[3, 1], exp[3, 2] = 4.5, 3.5, 77.0  # stale copy[1], copy[2] from line "C"
+    exp = exp + exp.T
+    assert (out == exp).all()
+    # a number the Java parser rejects
+    open(p, "w").write("2\nA\nB x1\n")
+    assert read(hostlib, p, 2)[0] == -1
+
+
+def test_cli_surface_without_gpu(tmp_path):
+    exe = os.path.join(PKG, "bin", "fastnn")
+    r = subprocess.run([exe, "-help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "usage: FastNN" in r.stdout and "-distFile <file_location>" in r.stdout
+    assert r.stderr.startswith("FastNN Version: 0.3.5\n")
+    r = subprocess.run([exe, "-order"], capture_output=True, text=True)
+    assert "The program needs a distance file!!" in r.stderr and "usage: FastNN" in r.stdout
+    r = subprocess.run([exe, "-distFile", str(tmp_path / "missing.phy"), "-order"], capture_output=True, text=True)
+    assert r.stderr.count("FileNotFound") == 1 and r.stdout.startswith("usage: FastNN")
+    p = tmp_path / "a.phy"
+    p.write_text("3\nA\nB 1\nC 2 3\n")
+    r = subprocess.run([exe, "-distFile", str(p), "-mode", "bogus"], capture_output=True, text=True)
+    assert r.returncode == 1 and "No enum constant nnet.NetMakerOriginal.NMMode.BOGUS" in r.stderr
+    r = subprocess.run([exe, "-distFile", str(p), "-mode", "relaxed", "-order"], capture_output=True, text=True)
+    assert r.returncode == 2 and r.stdout == ""
+    # ntax <= 3: identity order without touching a device (NetMakerOriginal.java:133-140)
+    r = subprocess.run([exe, "-distFile", str(p), "-mode", "Canonical", "-order", "-time"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == "[0, 1, 2, 3]\n"
+    assert "Calculating a tree for 3 taxa using 1 thread(s).\n" in r.stderr
+    assert "Using the canonical implementation.\n" in r.stderr and "Got the order in (s): " in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_config0_64_taxa_phylip(oracle, tmp_path):
+    D = oracle.synth(64, 1)
+    o_ref, _, _ = oracle.run(D)
+    p = str(tmp_path / "c0.phy")
+    write_phylip(p, D)
+    exe = os.path.join(PKG, "bin", "fastnn")
+    r = subprocess.run([exe, "-distFile", p, "-mode", "Canonical", "-threads", "1", "-order", "-time"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == "[" + ", ".join(str(int(v)) for v in o_ref) + "]\n"
+    assert "Got the order in (s): " in r.stderr
