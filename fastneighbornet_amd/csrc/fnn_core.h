@@ -44,6 +44,21 @@ constexpr int MAX_OPS = 6;
 
 constexpr int KIND_2WAY = 2, KIND_3WAY = 3, KIND_4WAY = 4, KIND_FINISH = 5;
 
+// The net effect of an event's micro-ops on one matrix row, as a recipe over the rows of the
+// matrix BEFORE the event ("o[r]" = old row r), used by the fused update kernel for the
+// columns that are not themselves involved in the event:
+//   T_COPY(a)      o[a]                                   (slot swap / move)
+//   T_L1(a,b)      (2/3)*o[a] + o[b]/3                    (agg3way, NetMakerOriginal.java:655-656)
+//   T_L2U(a,b,c)   (2/3)*L1(a,b) + L1(c,b)/3              (agg4way: u of the second agg3way)
+//   T_L2V(d,c,b)   (2/3)*o[d]    + L1(c,b)/3              (agg4way: v of the second agg3way)
+// every intermediate is rounded to fp64 exactly as when the reference stores it in D.
+constexpr int T_COPY = 0, T_L1 = 1, T_L2U = 2, T_L2V = 3;
+constexpr int MAX_TGT = 8;
+constexpr int MAX_S = 8;
+struct Tgt {
+    int32_t dst, kind, a, b, c, d;
+};
+
 struct Op {
     int32_t kind, a, b, c, d, e;
     int32_t mcur;  // slots [0, mcur) are swept
@@ -79,7 +94,14 @@ struct State {
     int32_t nops;
     Op ops[MAX_OPS];
     Event cur;
-    double rx[4];  // ComputeRx results for Cx, Cx.nbr, Cy, Cy.nbr (k_rx_chain -> k_decide)
+    double rx[4];  // exact ComputeRx results for Cx, Cx.nbr, Cy, Cy.nbr (only when not certified)
+    int32_t rx_ticket;          // arrival counter of the exact-chain workgroups
+    int32_t force_exact_rx;     // diagnostic: never certify (tests the exact path)
+    int64_t n_rx_certified, n_rx_exact;  // statistics
+    // fused update (k_update): slots involved in the event, and the recipes of the rows that change
+    int32_t nS, S[MAX_S];
+    int32_t ntgt, tU, tV;  // tU / tV: index in tgt[] of the rows of u and u.nbr
+    Tgt tgt[MAX_TGT];
 };
 
 struct Dev {
@@ -93,6 +115,7 @@ struct Dev {
     double* chain;   // 4 buffers of cstride doubles, addressed through chain_addr(position)
     int64_t cstride; // n rounded up to a whole super-chunk
     Cand* recs;      // per-block scan records
+    double* rxpart;  // per-block partial sums of k_rx_fill: [block][8] = 4 sums + 4 sums of |terms|
     State* st;
     Event* evlog;    // n records (if record_events)
     Agg3Rec* agglog; // n records
@@ -234,6 +257,58 @@ FNN_HD void agg3_plan(const Dev& d, int32_t X, int32_t Y, int32_t Z, int32_t U, 
     emit(st, OP_AGG3, X, Y, Z, U, V, d.spos[U] < d.spos[V] ? 1 : 0);
 }
 
+// Symbolic replay of the event's micro-ops: which old rows does every involved slot hold
+// afterwards?  Fills st.S (involved slots) and st.tgt (rows that change and stay live).
+FNN_HD void build_targets(const Dev& d) {
+    State& st = *d.st;
+    st.nS = 0; st.ntgt = 0; st.tU = -1; st.tV = -1;
+    auto add_slot = [&](int32_t sl) {
+        for (int i = 0; i < st.nS; i++) if (st.S[i] == sl) return;
+        if (st.nS >= MAX_S) { st.error = 5; return; }
+        st.S[st.nS++] = sl;
+    };
+    add_slot(st.U); add_slot(st.U + 1);
+    for (int i = 0; i < st.nops; i++) {
+        const Op& o = st.ops[i];
+        add_slot(o.a); add_slot(o.b);
+        if (o.kind == OP_AGG3) { add_slot(o.c); add_slot(o.d); add_slot(o.e); }
+    }
+    Tgt sym[MAX_S];
+    for (int i = 0; i < st.nS; i++) { sym[i].dst = st.S[i]; sym[i].kind = T_COPY; sym[i].a = st.S[i]; sym[i].b = sym[i].c = sym[i].d = -1; }
+    auto idx = [&](int32_t sl) { for (int i = 0; i < st.nS; i++) if (st.S[i] == sl) return i; return 0; };
+    // value (2/3)*A + B/3
+    auto comb = [&](const Tgt& A, const Tgt& B) {
+        Tgt r; r.dst = -1; r.kind = T_COPY; r.a = r.b = r.c = r.d = -1;
+        if (A.kind == T_COPY && B.kind == T_COPY) { r.kind = T_L1; r.a = A.a; r.b = B.a; }
+        else if (A.kind == T_L1 && B.kind == T_L1 && A.b == B.b) { r.kind = T_L2U; r.a = A.a; r.b = A.b; r.c = B.a; }
+        else if (A.kind == T_COPY && B.kind == T_L1) { r.kind = T_L2V; r.d = A.a; r.c = B.a; r.b = B.b; }
+        else st.error = 6;
+        return r;
+    };
+    for (int i = 0; i < st.nops; i++) {
+        const Op& o = st.ops[i];
+        if (o.kind == OP_SWAP) { int ia = idx(o.a), ib = idx(o.b); Tgt t = sym[ia]; sym[ia] = sym[ib]; sym[ib] = t; }
+        else if (o.kind == OP_MOVE) { sym[idx(o.b)] = sym[idx(o.a)]; }
+        else if (o.kind == OP_AGG3) {
+            Tgt sx = sym[idx(o.a)], sy = sym[idx(o.b)], sz = sym[idx(o.c)];
+            Tgt nu = comb(sx, sy), nv = comb(sz, sy);
+            sym[idx(o.d)] = nu; sym[idx(o.e)] = nv;
+        }
+    }
+    for (int i = 0; i < st.nS; i++) {
+        const int32_t sl = st.S[i];
+        const bool isUV = (sl == st.U || sl == st.U + 1);
+        if (sl >= st.m && !st.ev_finish) continue;  // not live after the event
+        if (!isUV && sym[i].kind == T_COPY && sym[i].a == sl) continue;  // unchanged
+        if (st.ntgt >= MAX_TGT) { st.error = 7; return; }
+        Tgt t = sym[i];
+        t.dst = sl;
+        if (sl == st.U) st.tU = st.ntgt;
+        if (sl == st.U + 1) st.tV = st.ntgt;
+        st.tgt[st.ntgt++] = t;
+    }
+}
+
 // Special finish, NetMakerOriginal.java:343-360 (num_active == 4, num_clusters == 2)
 FNN_HD void finish_plan(const Dev& d) {
     State& st = *d.st;
@@ -255,6 +330,7 @@ FNN_HD void finish_plan(const Dev& d) {
     agg3_plan(d, X, Y, Z, 2 * k, 2 * k + 1, st.num_nodes, 4);
     st.num_nodes += 2;
     st.U = 2 * k;
+    build_targets(d);
 }
 
 // After the scan: turn the best candidate into Cx, Cy (NetMakerOriginal.java:376-380)
@@ -287,9 +363,11 @@ FNN_HD void pick(const Dev& d, Cand best) {
 }
 
 // ComputeRx term for slot s (NetMakerOriginal.java:555-558), written to the chain
-// buffer at the node's reference position
-FNN_HD void rx_fill_thread(const Dev& d, int32_t s) {
+// buffer at the node's reference position; the terms are also returned (0 where absent)
+// so that the kernel can form tree-ordered partial sums for the certified decision.
+FNN_HD void rx_fill_thread(const Dev& d, int32_t s, double term[4]) {
     const State& st = *d.st;
+    term[0] = term[1] = term[2] = term[3] = 0.0;
     if (s >= st.m_old) return;
     int32_t twoP = 2 * st.P_old;
     bool full = (s == st.sa || s == st.sap || s == st.sb || s == st.sbp || s >= twoP);
@@ -298,7 +376,8 @@ FNN_HD void rx_fill_thread(const Dev& d, int32_t s) {
     for (int k = 0; k < 4; k++) {
         if (z[k] < 0) continue;
         double v = d.D[(int64_t)z[k] * d.ld + s];
-        d.chain[(int64_t)k * d.cstride + chain_addr(pos)] = full ? v : v / 2.0;
+        term[k] = full ? v : v / 2.0;
+        d.chain[(int64_t)k * d.cstride + chain_addr(pos)] = term[k];
     }
 }
 
@@ -312,29 +391,69 @@ FNN_HD double chain_sum(const double* buf, int32_t m) {
 // handleAgglomerationEvent: candidate choice (:422-452), bookkeeping of the merge
 // (:462-488) and the micro-op plan for the matrix.  rx = {Rx(Cx), Rx(Cx.nbr),
 // Rx(Cy), Rx(Cy.nbr)}, 0.0 where the reference leaves the 0.0 initialiser.
-FNN_HD void decide(const Dev& d, const double rx[4]) {
-    State& st = *d.st;
+// The <=4 candidate values of NetMakerOriginal.java:428-452 in the reference's order
+// (Cx,Cy), (Cx.nbr,Cy), (Cx,Cy.nbr), (Cx.nbr,Cy.nbr); ok[i] = candidate exists.
+FNN_HD void candidate_q(const Dev& d, const double rx[4], double q[4], bool ok[4], double fd[4]) {
+    const State& st = *d.st;
     const double* D = d.D; const int64_t ld = d.ld;
-    Event& cur = st.cur;
-    int32_t a = st.sa, ap = st.sap, b = st.sb, bp = st.sbp;
+    const int32_t a = st.sa, ap = st.sap, b = st.sb, bp = st.sbp;
     int32_t mm = st.c;
     if (ap >= 0) mm++;
     if (bp >= 0) mm++;
-    double f = (double)mm - 2.0;
+    const double f = (double)mm - 2.0;
+    ok[0] = true; ok[1] = ap >= 0; ok[2] = bp >= 0; ok[3] = ap >= 0 && bp >= 0;
+    q[0] = q[1] = q[2] = q[3] = 0.0;
+    fd[0] = fd[1] = fd[2] = fd[3] = 0.0;
+    fd[0] = f * D[a * ld + b];
+    q[0] = fd[0] - rx[0] - rx[2];
+    if (ok[1]) { fd[1] = f * D[ap * ld + b]; q[1] = fd[1] - rx[1] - rx[2]; }
+    if (ok[2]) { fd[2] = f * D[a * ld + bp]; q[2] = fd[2] - rx[0] - rx[3]; }
+    if (ok[3]) { fd[3] = f * D[ap * ld + bp]; q[3] = fd[3] - rx[1] - rx[3]; }
+}
+
+// Can the 4-candidate choice be made from tree-ordered sums?  rxa = approximate Rx (any
+// summation order), rxs = sums of |terms|.  Both the reference's sequential sum and any other
+// order are within gamma_(m-1) * sum|terms| of the exact sum, so |rxa - Rx_seq| <=
+// 2.1 m eps sum|terms|; the three roundings of `f*D - Rx - Ry` add at most 3 eps (|fD| + |Rx| +
+// |Ry|) on each side.  With a safety factor of ~2 on everything: if every pair of existing
+// candidates is further apart than the sum of their bounds, the strict comparisons of
+// :431-451 come out the same with the exact sums, hence the same (x, y).
+FNN_HD bool rx_certify(const Dev& d, const double rxa[4], const double rxs[4]) {
+    const State& st = *d.st;
+    if (st.force_exact_rx) return false;
+    double q[4], fd[4], bnd[4];
+    bool ok[4];
+    candidate_q(d, rxa, q, ok, fd);
+    const double eps = 1.1102230246251565e-16;  // 2^-53
+    const double mfac = 4.0 * ((double)st.m_old + 8.0) * eps;
+    const int ia[4] = {0, 1, 0, 1}, ib[4] = {2, 2, 3, 3};
+    for (int i = 0; i < 4; i++) {
+        const double sab = rxs[ia[i]] + rxs[ib[i]];
+        const double afd = fd[i] < 0.0 ? -fd[i] : fd[i];
+        bnd[i] = mfac * sab + 16.0 * eps * (afd + sab);
+        if (!(bnd[i] == bnd[i]) || !(q[i] == q[i])) return false;  // NaN anywhere: exact path
+    }
+    for (int i = 0; i < 4; i++)
+        for (int j = i + 1; j < 4; j++) {
+            if (!ok[i] || !ok[j]) continue;
+            const double diff = q[i] < q[j] ? q[j] - q[i] : q[i] - q[j];
+            if (!(diff > bnd[i] + bnd[j])) return false;
+        }
+    return true;
+}
+
+FNN_HD void decide(const Dev& d, const double rx[4]) {
+    State& st = *d.st;
+    Event& cur = st.cur;
+    int32_t a = st.sa, ap = st.sap, b = st.sb, bp = st.sbp;
+    double q[4], fd[4];
+    bool ok[4];
+    candidate_q(d, rx, q, ok, fd);
     int32_t x = a, y = b;
-    double best = f * D[a * ld + b] - rx[0] - rx[2];
-    if (ap >= 0) {
-        double q = f * D[ap * ld + b] - rx[1] - rx[2];
-        if (q < best) { x = ap; y = b; best = q; }
-    }
-    if (bp >= 0) {
-        double q = f * D[a * ld + bp] - rx[0] - rx[3];
-        if (q < best) { x = a; y = bp; best = q; }
-    }
-    if (ap >= 0 && bp >= 0) {
-        double q = f * D[ap * ld + bp] - rx[1] - rx[3];
-        if (q < best) { x = ap; y = bp; best = q; }
-    }
+    double best = q[0];
+    if (ok[1] && q[1] < best) { x = ap; y = b; best = q[1]; }
+    if (ok[2] && q[2] < best) { x = a; y = bp; best = q[2]; }
+    if (ok[3] && q[3] < best) { x = ap; y = bp; best = q[3]; }
     int32_t twoP = 2 * st.P;
     int32_t xn = x < twoP ? (x ^ 1) : -1;
     int32_t yn = y < twoP ? (y ^ 1) : -1;
@@ -398,6 +517,7 @@ FNN_HD void decide(const Dev& d, const double rx[4]) {
         st.c -= 1;
         st.U = U;
     }
+    build_targets(d);
 }
 
 // subtractClusterDistance(p, x); subtractClusterDistance(p, y) for p = node in slot s
@@ -491,6 +611,100 @@ FNN_HD void add_thread(const Dev& d, int32_t s) {
         val = dpu;
     }
     d.chain[chain_addr(d.spos[s])] = val;  // adding +0.0 to a running sum that starts at +0.0 changes no bit
+}
+
+FNN_HD double tgt_value(const Tgt& t, const double* D, int64_t ld, int32_t c) {
+    if (t.kind == T_COPY) return D[t.a * ld + c];
+    if (t.kind == T_L1) return (2.0 / 3.0) * D[t.a * ld + c] + D[t.b * ld + c] / 3.0;
+    const double v1 = (2.0 / 3.0) * D[t.c * ld + c] + D[t.b * ld + c] / 3.0;
+    if (t.kind == T_L2U) {
+        const double u1 = (2.0 / 3.0) * D[t.a * ld + c] + D[t.b * ld + c] / 3.0;
+        return (2.0 / 3.0) * u1 + v1 / 3.0;
+    }
+    return (2.0 / 3.0) * D[t.d * ld + c] + v1 / 3.0;  // T_L2V
+}
+
+// Fused per-event update for a cluster whose slot(s) k (and k+1) are NOT involved in the
+// event: subtract_thread + every op_thread + add_thread for these columns in one pass.
+// Reads only rows of involved slots at its own column(s) and writes only entries with
+// exactly one index equal to its own column(s), so it cannot conflict with any other thread;
+// the involved slots themselves are handled by update_special_*.
+FNN_HD void update_bulk(const Dev& d, int32_t k) {
+    const State& st = *d.st;
+    if (k >= st.m_old) return;
+    const int32_t twoP = 2 * st.P_old;
+    const bool paired = k < twoP;
+    if (paired && (k & 1)) return;  // the even thread of a two-node cluster does both columns
+    for (int i = 0; i < st.nS; i++) if (st.S[i] == k) return;
+    double* D = d.D; const int64_t ld = d.ld;
+    double sx0 = 0.0, sx1 = 0.0;
+    if (!st.ev_finish) {
+        // subtractClusterDistance(p, x); subtractClusterDistance(p, y) (:455-461, 681-696)
+        sx0 = d.Sx[k];
+        sx1 = paired ? d.Sx[k + 1] : 0.0;
+        for (int q = 0; q < 2; q++) {
+            const int32_t t = q == 0 ? st.xs : st.ys;
+            const int32_t tn = t < twoP ? (t ^ 1) : -1;
+            double v;
+            if (!paired && tn < 0) v = D[t * ld + k];
+            else if (paired && tn < 0) v = (D[t * ld + k] + D[t * ld + k + 1]) / 2.0;
+            else if (!paired && tn >= 0) v = (D[t * ld + k] + D[tn * ld + k]) / 2.0;
+            else v = (((D[t * ld + k] + D[tn * ld + k]) + D[t * ld + k + 1]) + D[tn * ld + k + 1]) / 4.0;
+            sx0 -= v;
+            sx1 -= v;
+        }
+    }
+    // all new values first (a changed row may be the source of another), then the stores;
+    // fully unrolled so that tv[][] stays in registers
+    double tv[MAX_TGT][2];
+    double u0 = 0.0, u1 = 0.0, v0 = 0.0, v1 = 0.0;
+#pragma unroll
+    for (int t = 0; t < MAX_TGT; t++) {
+        tv[t][0] = 0.0; tv[t][1] = 0.0;
+        if (t < st.ntgt) {
+            tv[t][0] = tgt_value(st.tgt[t], D, ld, k);
+            if (paired) tv[t][1] = tgt_value(st.tgt[t], D, ld, k + 1);
+            if (t == st.tU) { u0 = tv[t][0]; u1 = tv[t][1]; }
+            if (t == st.tV) { v0 = tv[t][0]; v1 = tv[t][1]; }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MAX_TGT; t++) {
+        if (t < st.ntgt) {
+            const int32_t dst = st.tgt[t].dst;
+            D[dst * ld + k] = tv[t][0];
+            D[k * ld + dst] = tv[t][0];
+            if (paired) {
+                D[dst * ld + k + 1] = tv[t][1];
+                D[(k + 1) * ld + dst] = tv[t][1];
+            }
+        }
+    }
+    if (!st.ev_finish) {
+        // updateClusterDistances, per-node part (:520-531)
+        double dpu;
+        if (!paired) dpu = (u0 + v0) / 2.0;
+        else dpu = (((u0 + v0) + u1) + v1) / 4.0;
+        d.Sx[k] = sx0 + dpu;
+        d.chain[chain_addr(d.spos[k])] = dpu;
+        if (paired) {
+            d.Sx[k + 1] = sx1 + dpu;
+            d.chain[chain_addr(d.spos[k + 1])] = 0.0;
+        }
+    }
+}
+
+// The involved slots (<= MAX_S columns) go through the per-column bodies above in phases:
+// phase 0 subtract, phases 1..nops one micro-op each, last phase add.  Within a phase the
+// columns are independent; phases are separated by a workgroup barrier on the GPU.
+FNN_HD int32_t update_special_phases(const State& st) { return st.nops + 2; }
+FNN_HD void update_special(const Dev& d, int32_t phase, int32_t i) {
+    const State& st = *d.st;
+    if (i >= st.nS) return;
+    const int32_t k = st.S[i];
+    if (phase == 0) { if (!st.ev_finish) subtract_thread(d, k); }
+    else if (phase <= st.nops) { Op op = st.ops[phase - 1]; op_thread(d, op, k); }
+    else { if (!st.ev_finish) add_thread(d, k); }
 }
 
 // u.Sx = sequential sum; u.nbr.Sx = u.Sx (:518-519, 532, 535); close the event

@@ -73,6 +73,7 @@ class Engine {
             !(dev.pslot = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
             !(dev.chain = (double*)be.alloc(sizeof(double) * 4 * (size_t)dev.cstride)) ||
             !(dev.recs = (Cand*)be.alloc(sizeof(Cand) * be.max_records(n))) ||
+            !(dev.rxpart = (double*)be.alloc(sizeof(double) * 8 * (nn / 256 + 2))) ||
             !(dev.st = (State*)be.alloc(sizeof(State))) ||
             !(dev.evlog = (Event*)be.alloc(sizeof(Event) * (nn + 8))) ||
             !(dev.agglog = (Agg3Rec*)be.alloc(sizeof(Agg3Rec) * (nn + 8))))
@@ -85,7 +86,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.recs); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.recs); be.free(dev.rxpart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }
@@ -143,6 +144,7 @@ class Engine {
         hst.n = n; hst.m = n; hst.c = n; hst.P = 0; hst.num_nodes = n;
         hst.done = (n <= 3) ? 1 : 0;  // :133-140
         hst.record_events = opts.record_events ? 1 : 0;
+        hst.force_exact_rx = opts.force_exact_rx ? 1 : 0;
         if (be.h2d(dev.st, &hst, sizeof(State)) != FNN_OK)
             return fail(FNN_EHIP, "fnn_begin: state upload failed (" + be.err() + ")");
         if (n > 3) {
@@ -233,6 +235,8 @@ class Engine {
         stats.n_events = hst.n_events;
         stats.sum_entries = hst.sum_entries;
         stats.scan_bytes = 8 * hst.sum_entries;
+        stats.n_rx_certified = hst.n_rx_certified;
+        stats.n_rx_exact = hst.n_rx_exact;
         be.collect_timing(stats);
         return rc;
     }

@@ -11,12 +11,12 @@
 //               m x m block (NeighborNetCanonical.java:151-178).  HBM-bound: reads
 //               each live matrix entry once, 16 B per lane, 1 KiB per wave-load.
 //   k_pick      reduce the per-block records, form Cx/Cy (NetMakerOriginal.java:376-380)
-//   k_rx_fill   ComputeRx terms in reference position order (:549-561)
-//   k_decide    the <=4 sequential Rx sums + candidate choice + merge plan (:413-488)
-//   k_subtract  subtractClusterDistance x2 per node (:455-461, 681-696)
-//   k_op        one micro-op of the plan: agg3way row/column rewrite (:653-656),
-//               slot swap or slot move (layout maintenance)
-//   k_add       updateClusterDistances per-node part (:520-531)
+//   k_rx_fill   ComputeRx terms in reference position order (:549-561) + tree partial sums
+//   k_decide4   candidate choice (:413-452) certified from the partial sums, else from the <=4
+//               exact sequential Rx sums; merge plan (:462-488)
+//   k_update    fused: subtractClusterDistance x2 per node (:455-461, 681-696), the net effect of
+//               the plan's micro-ops (agg3way row/column rewrite :653-656, slot swaps / moves)
+//               and updateClusterDistances' per-node part (:520-531)
 //   k_finalize  sequential u.Sx sum (:532), event log, loop condition (:339)
 #include <hip/hip_runtime.h>
 
@@ -157,10 +157,32 @@ __global__ __launch_bounds__(1024) void k_pick(Dev d, int nrecs) {
 }
 
 // ------------------------------------------------------------------ k_rx_fill
+// ComputeRx terms into the chain buffers + per-workgroup partial sums (tree order) of the terms
+// and of their magnitudes for the certified 4-candidate decision (fnn_core.h: rx_certify)
 __global__ __launch_bounds__(256) void k_rx_fill(Dev d) {
+    __shared__ double sh[4][8];
     const State* st = d.st;
     if (!st->ev_active || st->ev_finish || !st->need_rx) return;
-    rx_fill_thread(d, blockIdx.x * 256 + threadIdx.x);
+    double term[4];
+    rx_fill_thread(d, blockIdx.x * 256 + threadIdx.x, term);
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = term[k]; v[4 + k] = term[k] < 0.0 ? -term[k] : term[k]; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] += __shfl_down(v[k], off, 64);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) sh[w][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int k = threadIdx.x;
+        d.rxpart[(size_t)blockIdx.x * 8 + k] = ((sh[0][k] + sh[1][k]) + sh[2][k]) + sh[3][k];
+    }
 }
 
 // ------------------------------------------------------------------ exact block-parallel chain sum
@@ -342,47 +364,97 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
 }
 
 
-// ------------------------------------------------------------------ k_rx_chain / k_decide
-// the <=4 sequential ComputeRx sums, one workgroup each (NetMakerOriginal.java:413-420)
-__global__ __launch_bounds__(CH_T) void k_rx_chain(Dev d) {
-    __shared__ ChainLds<CH_EPT> L;
-    State* st = d.st;
-    if (!st->ev_active || st->ev_finish || !st->need_rx) return;
-    const int b = blockIdx.x;
-    const int z = (b == 0) ? st->sa : (b == 1) ? st->sap : (b == 2) ? st->sb : st->sbp;
-    double r = 0.0;
-    if (z >= 0) r = block_chain_sum<CH_EPT>(d.chain + (size_t)b * d.cstride, st->m_old, CH_GUARD_BITS, L, nullptr);
-    if (threadIdx.x == 0) st->rx[b] = r;
-}
-
-__global__ __launch_bounds__(64) void k_decide(Dev d) {
-    State* st = d.st;
-    if (!st->ev_active || st->ev_finish) return;
+// ------------------------------------------------------------------ k_decide4
+// Candidate choice + merge plan (NetMakerOriginal.java:413-488), one workgroup.  Common case:
+// the choice among the <=4 candidates is certified from the tree-ordered partial sums of
+// k_rx_fill.  Otherwise (candidates closer than the error bound, e.g. exact ties) the <=4
+// ComputeRx sums are evaluated exactly (block_chain_sum) first.
+// The plan is built by one thread on an LDS copy of the control block (dozens of dependent
+// accesses at LDS instead of L2 latency) that the workgroup copies in and out.
+__device__ __forceinline__ void decide_on_lds_copy(const Dev& d, State& lst, const double r_in[4], bool use_r,
+                                                   int certified) {
+    State* gst = d.st;
+    constexpr int NW = (int)(sizeof(State) / 4);
+    static_assert(sizeof(State) % 4 == 0, "State must be a whole number of dwords");
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(gst);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&lst);
+        for (int i = threadIdx.x; i < NW; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        Dev dl = d;
+        dl.st = &lst;
         double r[4] = {0.0, 0.0, 0.0, 0.0};
-        if (st->need_rx) { r[0] = st->rx[0]; r[1] = st->rx[1]; r[2] = st->rx[2]; r[3] = st->rx[3]; }
-        decide(d, r);
+        if (use_r) { r[0] = r_in[0]; r[1] = r_in[1]; r[2] = r_in[2]; r[3] = r_in[3]; }
+        if (lst.need_rx) { if (certified) lst.n_rx_certified++; else lst.n_rx_exact++; }
+        decide(dl, r);
+    }
+    __syncthreads();
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&lst);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(gst);
+        for (int i = threadIdx.x; i < NW; i += blockDim.x) dst[i] = src[i];
     }
 }
 
-// ------------------------------------------------------------------ k_subtract / k_op / k_add
-__global__ __launch_bounds__(256) void k_subtract(Dev d) {
-    const State* st = d.st;
+__global__ __launch_bounds__(CH_T) void k_decide4(Dev d, int nparts) {
+    __shared__ ChainLds<CH_EPT> L;
+    __shared__ State lst;
+    __shared__ double red[8];
+    State* st = d.st;
     if (!st->ev_active || st->ev_finish) return;
-    subtract_thread(d, blockIdx.x * 256 + threadIdx.x);
+    const int need_rx = st->need_rx;
+    double rxa[4] = {0.0, 0.0, 0.0, 0.0};
+    int certified = 1;
+    if (need_rx) {
+        if (threadIdx.x < 64) {  // sum the partials of k_rx_fill (<= 128 x 8 doubles)
+            double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int b = threadIdx.x; b < nparts; b += 64)
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] += d.rxpart[(size_t)b * 8 + k];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] += __shfl_down(v[k], off, 64);
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) red[k] = v[k];
+            }
+        }
+        __syncthreads();
+        double rxs[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { rxa[k] = red[k]; rxs[k] = red[4 + k]; }
+        certified = rx_certify(d, rxa, rxs) ? 1 : 0;
+        if (!certified) {
+            // rare: the <=4 sums exactly, one after the other in this workgroup
+            const int z[4] = {st->sa, st->sap, st->sb, st->sbp};
+            const int m_old = st->m_old;
+            for (int b = 0; b < 4; b++) {
+                rxa[b] = 0.0;
+                if (z[b] >= 0) rxa[b] = block_chain_sum<CH_EPT>(d.chain + (size_t)b * d.cstride, m_old, CH_GUARD_BITS, L, nullptr);
+            }
+        }
+    }
+    decide_on_lds_copy(d, lst, rxa, need_rx != 0, certified);
 }
 
-__global__ __launch_bounds__(256) void k_op(Dev d, int idx) {
+// ------------------------------------------------------------------ k_update
+// subtract + every micro-op + add of one event in ONE launch (fnn_core.h: update_bulk /
+// update_special).  The last workgroup handles the <= 8 involved slots in phases.
+__global__ __launch_bounds__(256) void k_update(Dev d) {
     const State* st = d.st;
-    if (!st->ev_active || idx >= st->nops) return;
-    Op op = st->ops[idx];
-    op_thread(d, op, blockIdx.x * 256 + threadIdx.x);
-}
-
-__global__ __launch_bounds__(256) void k_add(Dev d) {
-    const State* st = d.st;
-    if (!st->ev_active || st->ev_finish) return;
-    add_thread(d, blockIdx.x * 256 + threadIdx.x);
+    if (!st->ev_active) return;
+    if (blockIdx.x == gridDim.x - 1) {
+        const int nph = update_special_phases(*st);
+        for (int ph = 0; ph < nph; ph++) {
+            update_special(d, ph, (int)threadIdx.x);
+            __syncthreads();  // a phase's stores are visible to the next phase (same CU, same L1)
+        }
+        return;
+    }
+    update_bulk(d, blockIdx.x * 256 + threadIdx.x);
 }
 
 // ------------------------------------------------------------------ k_finalize
@@ -602,11 +674,8 @@ struct HipBackend {
         scan_launches++;
         hipLaunchKernelGGL(k_pick, dim3(1), dim3(1024), 0, stream, d, (int)gs.x);
         hipLaunchKernelGGL(k_rx_fill, g1, dim3(256), 0, stream, d);
-        hipLaunchKernelGGL(k_rx_chain, dim3(4), dim3(CH_T), 0, stream, d);
-        hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, stream, d);
-        hipLaunchKernelGGL(k_subtract, g1, dim3(256), 0, stream, d);
-        for (int i = 0; i < MAX_OPS; i++) hipLaunchKernelGGL(k_op, g1, dim3(256), 0, stream, d, i);
-        hipLaunchKernelGGL(k_add, g1, dim3(256), 0, stream, d);
+        hipLaunchKernelGGL(k_decide4, dim3(1), dim3(CH_T), 0, stream, d, (int)g1.x);
+        hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d);
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }

@@ -50,7 +50,10 @@ typedef struct fnn_opts {
     int32_t device;        /* HIP device ordinal (default 0) */
     int32_t validate;      /* 1: check symmetry / zero diagonal / finiteness on device before running */
     int32_t record_events; /* 1: keep the per-event trajectory (fnn_get_events) */
-    int32_t reserved[13];
+    int32_t force_exact_rx;/* diagnostic: 1 = always evaluate the ComputeRx sums with the exact
+                              sequential-sum kernel instead of certifying the 4-candidate choice
+                              from tree sums (same result; exercises the rare path) */
+    int32_t reserved[12];
 } fnn_opts;
 
 /* One agglomeration event == one iteration of the loop of
@@ -77,7 +80,9 @@ typedef struct fnn_stats {
     double  t_scan_s;        /* sum of scan-kernel durations (HIP events), 0 unless timing enabled */
     int64_t scan_launches;   /* number of scan-kernel launches */
     int64_t scan_bytes;      /* algorithmic bytes of those launches (8 * sum E_t) */
-    int64_t reserved[8];
+    int64_t n_rx_certified;  /* events whose 4-candidate choice was certified from tree sums */
+    int64_t n_rx_exact;      /* events that needed the exact sequential ComputeRx sums */
+    int64_t reserved[6];
 } fnn_stats;
 
 typedef struct fnn_handle fnn_handle;

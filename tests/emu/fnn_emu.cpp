@@ -20,6 +20,7 @@
 namespace {
 
 int g_order_mode = 0;  // 0 forward, 1 reverse, 2 shuffled
+int g_update_mode = 0; // interleaving of k_update's bulk threads and special phases
 uint64_t g_shuffle_state = 0x12345678ULL;
 
 std::vector<int32_t> thread_order(int32_t count) {
@@ -117,29 +118,54 @@ struct EmuBackend {
         fnn::pick(d, best);
         if (!st.ev_active) return FNN_OK;
         if (!st.ev_finish) {
-            // k_rx_fill + k_decide
+            // k_rx_fill (+ per-block partial sums) and k_decide4 (certify, else exact chains)
             double rx[4] = {0.0, 0.0, 0.0, 0.0};
+            bool certified = true;
             if (st.need_rx) {
-                for (int32_t s : thread_order(m_bound)) fnn::rx_fill_thread(d, s);
-                int32_t z[4] = {st.sa, st.sap, st.sb, st.sbp};
-                for (int k = 0; k < 4; k++)
-                    if (z[k] >= 0) rx[k] = fnn::chain_sum(d.chain + (int64_t)k * d.cstride, st.m_old);
+                const int32_t nblk = (m_bound + 255) / 256;
+                for (int32_t b = 0; b < nblk; b++) {
+                    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int32_t t : thread_order(256)) {
+                        double term[4];
+                        fnn::rx_fill_thread(d, b * 256 + t, term);
+                        for (int k = 0; k < 4; k++) { acc[k] += term[k]; acc[4 + k] += term[k] < 0 ? -term[k] : term[k]; }
+                    }
+                    for (int k = 0; k < 8; k++) d.rxpart[(size_t)b * 8 + k] = acc[k];
+                }
+                double rxa[4] = {0, 0, 0, 0}, rxs[4] = {0, 0, 0, 0};
+                for (int32_t b : thread_order(nblk))
+                    for (int k = 0; k < 4; k++) { rxa[k] += d.rxpart[(size_t)b * 8 + k]; rxs[k] += d.rxpart[(size_t)b * 8 + 4 + k]; }
+                certified = fnn::rx_certify(d, rxa, rxs);
+                if (certified) { for (int k = 0; k < 4; k++) rx[k] = rxa[k]; st.n_rx_certified++; }
+                else {
+                    int32_t z[4] = {st.sa, st.sap, st.sb, st.sbp};
+                    for (int k = 0; k < 4; k++)
+                        if (z[k] >= 0) rx[k] = fnn::chain_sum(d.chain + (int64_t)k * d.cstride, st.m_old);
+                    st.n_rx_exact++;
+                }
             }
             fnn::decide(d, rx);
-            // k_subtract
-            for (int32_t s : thread_order(m_bound)) fnn::subtract_thread(d, s);
         }
-        // k_op x nops
-        for (int32_t i = 0; i < st.nops; i++) {
-            fnn::Op op = st.ops[i];
-            for (int32_t k : thread_order(m_bound)) fnn::op_thread(d, op, k);
+        // k_update: bulk columns and the special phases run concurrently on the GPU; emulate
+        // different interleavings (g_update_mode) to expose any conflict between them
+        {
+            const int32_t nph = fnn::update_special_phases(st);
+            auto bulk = [&]() { for (int32_t k : thread_order(m_bound)) fnn::update_bulk(d, k); };
+            auto special = [&](int32_t ph) { for (int32_t i : thread_order(fnn::MAX_S)) fnn::update_special(d, ph, i); };
+            if (g_update_mode == 0) { bulk(); for (int32_t ph = 0; ph < nph; ph++) special(ph); }
+            else if (g_update_mode == 1) { for (int32_t ph = 0; ph < nph; ph++) special(ph); bulk(); }
+            else {  // bulk split in two halves around the middle phase
+                std::vector<int32_t> ord = thread_order(m_bound);
+                size_t half = ord.size() / 2;
+                for (int32_t ph = 0; ph < nph; ph++) {
+                    if (ph == nph / 2) for (size_t q = 0; q < half; q++) fnn::update_bulk(d, ord[q]);
+                    special(ph);
+                }
+                for (size_t q = half; q < ord.size(); q++) fnn::update_bulk(d, ord[q]);
+            }
         }
         double usx = 0.0;
-        if (!st.ev_finish) {
-            // k_add + chain
-            for (int32_t s : thread_order(m_bound)) fnn::add_thread(d, s);
-            usx = fnn::chain_sum(d.chain, st.m);
-        }
+        if (!st.ev_finish) usx = fnn::chain_sum(d.chain, st.m);
         fnn::finalize(d, usx);
         return FNN_OK;
     }
@@ -229,7 +255,7 @@ double emu_chain_serial(const double* buf, int32_t m) {
     return s;
 }
 
-void emu_set_order_mode(int32_t mode) { g_order_mode = mode; }
+void emu_set_order_mode(int32_t mode) { g_order_mode = mode % 3; g_update_mode = (mode / 3) % 3; }
 const char* emu_last_error(void) { return fnn::g_last_error.c_str(); }
 
 int32_t emu_create(int32_t n, const fnn_opts* opts, void** out) {

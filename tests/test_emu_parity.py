@@ -9,7 +9,9 @@ from common import check_order, compare_trajectory
 from fastneighbornet_amd._capi import Handle
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+# mode = thread order (0 forward, 1 reverse, 2 shuffled) + 3 * interleaving of k_update's bulk
+# threads with its special phases (0 bulk first, 1 special first, 2 mixed)
+@pytest.mark.parametrize("mode", list(range(9)))
 @pytest.mark.parametrize("dist", ["uniform53", "dec4"])
 def test_small_sizes_deep(emu_api, oracle, dist, mode):
     emu_api.set_order_mode(mode)
@@ -18,7 +20,7 @@ def test_small_sizes_deep(emu_api, oracle, dist, mode):
             compare_trajectory(emu_api, oracle, oracle.synth(n, seed, dist), deep=True)
 
 
-@pytest.mark.parametrize("n,seed,dist,mode", [(257, 1, "uniform53", 2), (300, 2, "dec4", 1),
+@pytest.mark.parametrize("n,seed,dist,mode", [(257, 1, "uniform53", 8), (300, 2, "dec4", 4),
                                               (400, 3, "uniform53", 0)])
 def test_medium_sizes(emu_api, oracle, n, seed, dist, mode):
     emu_api.set_order_mode(mode)
@@ -67,3 +69,12 @@ def test_validate_rejects_bad_matrix(emu_api, oracle):
             h.set_matrix(E)
             with pytest.raises(FnnError):
                 h.run()
+
+
+@pytest.mark.parametrize("dist", ["uniform53", "dec4"])
+def test_exact_rx_path_gives_the_same_trajectory(emu_api, oracle, dist):
+    """The 4-candidate choice is normally certified from tree sums; force_exact_rx makes every
+    event take the exact sequential-sum path instead.  Both must match the oracle."""
+    emu_api.set_order_mode(2)
+    for n in (9, 33, 90):
+        compare_trajectory(emu_api, oracle, oracle.synth(n, 4, dist), deep=True, force_exact_rx=True)

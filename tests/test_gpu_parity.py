@@ -46,6 +46,14 @@ def test_run_matches_oracle(hip_api, oracle, n, seed):
     assert (bits(ev["best"]) == bits(ev_ref["best"])).all()
 
 
+@pytest.mark.parametrize("dist", ["uniform53", "dec4"])
+def test_exact_rx_path(hip_api, oracle, dist):
+    # force the rare path (exact ComputeRx sums) on every event
+    for n in (9, 65, 300):
+        compare_trajectory(hip_api, oracle, oracle.synth(n, 4, dist), deep=True, deep_every=7, force_exact_rx=True)
+    compare_trajectory(hip_api, oracle, oracle.synth(1200, 5, dist), deep=False, force_exact_rx=True)
+
+
 def test_device_synth_is_bit_identical(hip_api, oracle):
     for n, seed, dist in [(100, 1, "uniform53"), (777, 9, "dec4")]:
         D = oracle.synth(n, seed, dist)

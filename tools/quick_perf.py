@@ -17,4 +17,5 @@ for n in sizes:
         print(f"n={n} total={st.t_total_s:.3f}s init={st.t_init_s:.4f} agglom={st.t_agglom_s:.3f} "
               f"scan={st.t_scan_s:.3f}s events={st.n_events} sumE/n^3={st.sum_entries / n**3:.4f} "
               f"scan_GBps={gb / max(st.t_scan_s, 1e-9):.1f} whole_GBps={gb / st.t_total_s:.1f} "
-              f"per_event_overhead_us={(st.t_agglom_s - st.t_scan_s) / max(st.n_events, 1) * 1e6:.1f}", flush=True)
+              f"per_event_overhead_us={(st.t_agglom_s - st.t_scan_s) / max(st.n_events, 1) * 1e6:.1f} "
+              f"rx_certified={st.n_rx_certified} rx_exact={st.n_rx_exact}", flush=True)
