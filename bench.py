@@ -8,10 +8,12 @@ resident in HBM when the step starts.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--n 32768] [--seed 1]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU).  The
-matrix row-sharding over several GPUs is not built yet (DESIGN.md "Multi-GPU"): with
-N > 1 rank 0 computes the single problem instance on its GPU while the other ranks wait
-at the barrier, so the reported time is a true whole-job time ("scaling": "strong").
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU): every rank
+holds the whole matrix and scans 1/N of each event's tiles; one 16-byte candidate per rank is
+all-gathered per event with RCCL on the engine's stream and every rank applies the same
+deterministic update (DESIGN.md "Multi-GPU").  The job is ONE problem instance, so the metric
+is a strong-scaling time.  If the RCCL communicator cannot be created the ranks agree to let
+rank 0 compute alone (reported in config.parallelism).
 
 Prints ONE JSON line on rank 0.
 """
@@ -79,12 +81,18 @@ def main():
 
     import torch
     dist = None
+    same_gpu = os.environ.get("FNN_BENCH_SAME_GPU") == "1"  # rehearsal on a one-GPU box (gloo transport)
+    dev_index = 0 if same_gpu else local_rank
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
 
     import fastneighbornet_amd as fa
+    from fastneighbornet_amd import distributed as fd
     from fastneighbornet_amd._capi import Handle
     api = fa.api()
 
@@ -94,10 +102,34 @@ def main():
         torch.cuda.synchronize()
 
     n = args.n
-    worker = (rank == 0)  # the single problem instance lives on rank 0's GPU (see module docstring)
     h = None
+    parallelism = "single GPU"
+    sharded = False
+    if world > 1:
+        ok, why = 1, ""
+        try:
+            h = Handle(api, n, device=dev_index)
+            if same_gpu:
+                fd.init_gloo(h, dist)
+            else:
+                fd.init_rccl(h, dist, torch.device("cuda", dev_index))
+        except Exception as e:  # all ranks must agree on the fallback
+            ok, why = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if same_gpu else "cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        sharded = int(flag.item()) == 1
+        if sharded:
+            parallelism = (f"scan sharded over {world} ranks (tile index mod {world}), matrix replicated, one 16-byte "
+                           f"all-gather per event ({'gloo host callback' if same_gpu else 'RCCL on stream'})")
+        else:
+            if h is not None:
+                h.close()
+                h = None
+            parallelism = f"rank 0 computes alone (communicator setup failed: {why or 'on another rank'})"
+    worker = sharded or rank == 0
+    if worker and h is None:
+        h = Handle(api, n, device=dev_index)
     if worker:
-        h = Handle(api, n, device=local_rank)
         api.set_scan_timing(h._h, 1)
 
     def one_step():
@@ -116,7 +148,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if same_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -125,7 +157,12 @@ def main():
         sec = elapsed / args.steps
         scan_bytes = float(st.scan_bytes)
         assert sorted(order[1:].tolist()) == list(range(1, n + 1)) and order[0] == 0 and order[1] == 1
-        scan_gbps = scan_bytes / max(st.t_scan_s, 1e-12) / 1e9
+        share = args.gpus if sharded else 1  # this rank's launches cover 1/share of the entries
+        scan_gbps = scan_bytes / share / max(st.t_scan_s, 1e-12) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_scan_summary_n32768.json")
+        if n == 32768 and args.gpus == 1 and os.path.exists(pmc):
+            traffic = round(json.load(open(pmc))["hbm_bytes_per_launch_avg"], 1)
         out = {
             "metric": f"sec to circular order, n={n} taxa (+ achieved HBM GB/s)",
             "value": round(sec, 4),
@@ -141,7 +178,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{n} synthetic taxa (SplitMix64 uniform53, seed {args.seed}), -mode Canonical, "
-                            f"{args.gpus} MI355X" + (" (rank 0 computes; row-sharding not built yet)" if args.gpus > 1 else ""),
+                            f"{args.gpus} MI355X",
+                "parallelism": parallelism,
                 "n_taxa": n,
                 "events": int(st.n_events),
                 "sum_entries": int(st.sum_entries),
@@ -149,6 +187,7 @@ def main():
             },
             "hbm_gbps_whole_run": round(scan_bytes / sec / 1e9, 1),
             "hbm_frac_whole_run": round(scan_bytes / sec / 1e9 / (HBM_PEAK_GBPS * max(args.gpus, 1)), 4),
+            "rx_decisions": {"certified_from_tree_sums": int(st.n_rx_certified), "exact_sequential_sums": int(st.n_rx_exact)},
             "phases_s": {"init": round(st.t_init_s, 4), "agglomerate": round(st.t_agglom_s, 4),
                          "expand": round(st.t_expand_s, 4), "scan_kernel_sum": round(st.t_scan_s, 4)},
             "roofline": {
@@ -158,16 +197,20 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(scan_gbps / HBM_PEAK_GBPS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                 "workload (FETCH_SIZE x2 per the gfx950 correction), profiles/r01/pmc_scan_summary_n32768.json"
+                                 if traffic else None),
                 "launches": int(st.scan_launches),
                 "avg_launch_us": round(st.t_scan_s / max(st.scan_launches, 1) * 1e6, 2),
-                "algorithmic_bytes_per_launch_avg": round(scan_bytes / max(st.scan_launches, 1), 1),
+                "algorithmic_bytes_per_launch_avg": round(scan_bytes / share / max(st.scan_launches, 1), 1),
+                "per_gpu": args.gpus > 1,
             },
         }
         try:
             import ctypes as C
             g = C.c_double(0.0)
-            if api.stream_probe(local_rank, 4 << 30, 5, C.byref(g)) == 0:
+            if api.stream_probe(dev_index, 4 << 30, 5, C.byref(g)) == 0:
                 out["roofline"]["measured_stream_read_gbps"] = round(g.value, 1)
         except Exception:
             pass

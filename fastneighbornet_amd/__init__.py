@@ -19,6 +19,7 @@ from ._capi import FnnError, Handle  # noqa: F401
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
 LIB_PATH = _os.path.join(_HERE, "libfastnn_hip.so")
 _api = None
+TORCH_LOADED_FIRST = False
 
 
 def api() -> _capi.Api:
@@ -29,6 +30,11 @@ def api() -> _capi.Api:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m fastneighbornet_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        import sys as _sys
+        global TORCH_LOADED_FIRST
+        # PyTorch bundles its own HIP runtime; whichever of the two is loaded first serves both
+        # (same soname).  distributed.rccl_path() picks the librccl that matches.
+        TORCH_LOADED_FIRST = "torch" in _sys.modules
         lib = _C.CDLL(LIB_PATH)
         a = _capi.Api(lib, "fnn_")
         a._fn("abi_version", _C.c_int32, [])
@@ -41,6 +47,8 @@ def api() -> _capi.Api:
         a._fn("test_chain_sum", _C.c_int32,
               [_C.c_int32, _C.POINTER(_C.c_double), _C.c_int32, _C.c_int32, _C.c_int32,
                _C.POINTER(_C.c_double), _C.POINTER(_C.c_int32)])
+        a._fn("comm_unique_id", _C.c_int32, [_C.POINTER(_C.c_uint8), _C.c_char_p])
+        a._fn("comm_init_rccl", _C.c_int32, [_C.c_void_p, _C.c_int32, _C.c_int32, _C.POINTER(_C.c_uint8), _C.c_char_p])
         a._fn("stream_probe", _C.c_int32, [_C.c_int32, _C.c_int64, _C.c_int32, _C.POINTER(_C.c_double)])
         _api = a
     return _api

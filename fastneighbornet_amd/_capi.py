@@ -49,6 +49,10 @@ EVENT_DTYPE = np.dtype(
      ("best", "<f8"), ("entries", "<i8")], align=True)
 
 
+# int32_t (*fnn_allgather_fn)(void* ctx, const void* send, void* recv, int32_t bytes_per_rank)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32)
+
+
 class FnnError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"{STATUS_NAMES.get(code, code)}: {msg}")
@@ -77,6 +81,7 @@ class Api:
         f("get_counts", C.c_int32, [C.c_void_p, _ip, _ip, _ip])
         f("get_nodes", C.c_int32, [C.c_void_p, _ip, _ip, _dp])
         f("get_live_matrix", C.c_int32, [C.c_void_p, _dp])
+        f("comm_init_host", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, ALLGATHER_FN, C.c_void_p])
 
     def _fn(self, name, restype, argtypes, optional=False):
         try:
@@ -128,6 +133,26 @@ class Handle:
 
     def __exit__(self, *a):
         self.close()
+
+    # -- several ranks --
+    def comm_init_host(self, world: int, rank: int, allgather):
+        """Test transport: `allgather(send: bytes) -> list[bytes]` (one entry per rank)."""
+        def _cb(ctx, send, recv, nbytes):
+            try:
+                parts = allgather(C.string_at(send, nbytes))
+                C.memmove(recv, b"".join(parts), nbytes * world)
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = ALLGATHER_FN(_cb)  # keep alive
+        self.api.check(self.api.comm_init_host(self._h, world, rank, self._cb, None))
+
+    def comm_init_rccl(self, world: int, rank: int, uid: bytes, rccl_path: str | None = None):
+        p = rccl_path.encode() if rccl_path else None
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self.api.check(self.api.comm_init_rccl(self._h, world, rank, buf, p))
 
     # -- matrix --
     def set_matrix(self, D: np.ndarray, chunk_rows: int = 0):

@@ -116,6 +116,9 @@ struct Dev {
     int64_t cstride; // n rounded up to a whole super-chunk
     Cand* recs;      // per-block scan records
     double* rxpart;  // per-block partial sums of k_rx_fill: [block][8] = 4 sums + 4 sums of |terms|
+    Cand* gsend;     // multi-GPU: this rank's best candidate of the event (1 record)
+    Cand* grecv;     // multi-GPU: all ranks' candidates (world records)
+    int32_t rank, world;  // scan sharding: rank scans the tiles with index = rank (mod world)
     State* st;
     Event* evlog;    // n records (if record_events)
     Agg3Rec* agglog; // n records

@@ -50,6 +50,10 @@ class Engine {
     std::vector<Agg3Rec> agglog;
     int32_t last3[3] = {0, 0, 0};
     int32_t batch = 32;    // events enqueued between host round trips in run()
+    // several GPUs: 0 = single, 1 = RCCL all-gather on the stream, 2 = host callback (tests)
+    int32_t comm_mode = 0, world = 1, rank = 0;
+    fnn_allgather_fn host_fn = nullptr;
+    void* host_ctx = nullptr;
 
     int32_t create(int32_t n_, const fnn_opts* o) {
         if (n_ < 0) return fail(FNN_EINVAL, "fnn_create: n < 0");
@@ -65,6 +69,8 @@ class Engine {
         dev.n = n;
         dev.ld = ld;
         dev.cstride = round_up(n > 0 ? n : 1, CH_SC);
+        dev.rank = 0;
+        dev.world = 1;
         size_t nn = (size_t)(n > 0 ? n : 1);
         if (!(dev.D = (double*)be.alloc(sizeof(double) * (size_t)nrows * (size_t)ld)) ||
             !(dev.Sx = (double*)be.alloc(sizeof(double) * (nn + 8))) ||
@@ -74,6 +80,8 @@ class Engine {
             !(dev.chain = (double*)be.alloc(sizeof(double) * 4 * (size_t)dev.cstride)) ||
             !(dev.recs = (Cand*)be.alloc(sizeof(Cand) * be.max_records(n))) ||
             !(dev.rxpart = (double*)be.alloc(sizeof(double) * 8 * (nn / 256 + 2))) ||
+            !(dev.gsend = (Cand*)be.alloc(sizeof(Cand) * 64)) ||
+            !(dev.grecv = (Cand*)be.alloc(sizeof(Cand) * 64)) ||
             !(dev.st = (State*)be.alloc(sizeof(State))) ||
             !(dev.evlog = (Event*)be.alloc(sizeof(Event) * (nn + 8))) ||
             !(dev.agglog = (Agg3Rec*)be.alloc(sizeof(Agg3Rec) * (nn + 8))))
@@ -86,7 +94,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.recs); be.free(dev.rxpart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.recs); be.free(dev.rxpart); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }
@@ -159,13 +167,46 @@ class Engine {
         return FNN_OK;
     }
 
+    int32_t comm_set(int32_t mode, int32_t world_, int32_t rank_) {
+        if (world_ < 1 || world_ > 64 || rank_ < 0 || rank_ >= world_)
+            return fail(FNN_EINVAL, "fnn_comm_init: need 1 <= world <= 64 and 0 <= rank < world");
+        // world == 1 normally needs no exchange; FNN_COMM_FORCE=1 keeps the exchange path on
+        // (lets a one-GPU box exercise the RCCL plumbing end to end)
+        comm_mode = (world_ > 1 || std::getenv("FNN_COMM_FORCE")) ? mode : 0;
+        world = world_;
+        rank = rank_;
+        dev.world = world_;
+        dev.rank = rank_;
+        return FNN_OK;
+    }
+
+    // one event: scan (+ exchange of the per-rank candidates) + the rest of the sequence
+    int32_t enqueue_event() {
+        if (comm_mode == 0) return be.launch_event(dev, m_bound) == FNN_OK ? FNN_OK : fail(FNN_EHIP, "launch failed (" + be.err() + ")");
+        if (be.launch_event_scan(dev, m_bound) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
+        if (comm_mode == 1) {
+            if (be.allgather_on_stream(dev) != FNN_OK) return fail(FNN_ERCCL, "all-gather failed (" + be.err() + ")");
+        } else {
+            Cand mine, all[64];
+            if (be.sync() != FNN_OK || be.d2h(&mine, dev.gsend, sizeof(Cand)) != FNN_OK)
+                return fail(FNN_EHIP, "candidate download failed (" + be.err() + ")");
+            if (!host_fn || host_fn(host_ctx, &mine, all, (int32_t)sizeof(Cand)) != 0)
+                return fail(FNN_ERCCL, "host all-gather callback failed");
+            if (be.h2d(dev.grecv, all, sizeof(Cand) * (size_t)world) != FNN_OK)
+                return fail(FNN_EHIP, "candidate upload failed (" + be.err() + ")");
+        }
+        if (be.launch_event_rest(dev, m_bound) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
+        return FNN_OK;
+    }
+
     // one event with a host round trip (tests / diagnostics)
     int32_t step(fnn_event* ev) {
         if (!begun) return fail(FNN_ESTATE, "fnn_step: call fnn_begin first");
         if (ended) return 0;
-        if (be.launch_event(dev, m_bound) != FNN_OK || be.sync() != FNN_OK)
-            return fail(FNN_EHIP, "fnn_step: launch failed (" + be.err() + ")");
-        int32_t rc = pull_state();
+        int32_t rc = enqueue_event();
+        if (rc != FNN_OK) return rc;
+        if (be.sync() != FNN_OK) return fail(FNN_EHIP, "fnn_step: sync failed (" + be.err() + ")");
+        rc = pull_state();
         if (rc != FNN_OK) return rc;
         m_bound = hst.m;
         if (std::getenv("FNN_DEBUG")) {
@@ -187,9 +228,10 @@ class Engine {
         if (!begun) return fail(FNN_ESTATE, "agglomerate: call fnn_begin first");
         double t0 = now_s();
         while (!ended) {
-            for (int i = 0; i < batch; i++)
-                if (be.launch_event(dev, m_bound) != FNN_OK)
-                    return fail(FNN_EHIP, "fnn_run: launch failed (" + be.err() + ")");
+            for (int i = 0; i < batch; i++) {
+                int32_t rce = enqueue_event();
+                if (rce != FNN_OK) return rce;
+            }
             if (be.sync() != FNN_OK) return fail(FNN_EHIP, "fnn_run: sync failed (" + be.err() + ")");
             int32_t rc = pull_state();
             if (rc != FNN_OK) return rc;

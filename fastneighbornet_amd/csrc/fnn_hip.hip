@@ -20,6 +20,8 @@
 //   k_finalize  sequential u.Sx sum (:532), event log, loop condition (:339)
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <new>
 
@@ -27,6 +29,8 @@
 #include "fnn_engine.h"
 
 namespace fnn {
+
+struct fnn_nccl_id { char internal[FNN_COMM_ID_BYTES]; };  // == ncclUniqueId (rccl.h:43)
 
 constexpr int SCAN_TW = 512;  // columns per scan tile (256 threads x 2)
 constexpr int SCAN_TH = 32;   // rows per scan tile
@@ -102,7 +106,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(Dev d) {
         const int twoP = 2 * st->P;
         const double cm2 = (double)st->c - 2.0;
         const int ntiles = scan_tile_count(m);
-        for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        // several GPUs: rank r of `world` takes the tiles with index = r (mod world)
+        for (int t = blockIdx.x * d.world + d.rank; t < ntiles; t += gridDim.x * d.world) {
             int rt, ct;
             scan_tile_decode(t, rt, ct);
             const int rbase = rt * SCAN_TH;
@@ -141,19 +146,31 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(Dev d) {
 }
 
 // ------------------------------------------------------------------ k_pick
-__global__ __launch_bounds__(1024) void k_pick(Dev d, int nrecs) {
-    __shared__ Cand sh[16];
+__device__ __forceinline__ Cand reduce_records(const Dev& d, const Cand* src, int nrecs, Cand* sh) {
     Cand best;
     best.q = inf_f64();
     best.key = ~0ULL;
     if (!d.st->done) {
         for (int i = threadIdx.x; i < nrecs; i += 1024) {
-            Cand c = d.recs[i];
+            Cand c = src[i];
             if (cand_better(c, best)) best = c;
         }
     }
-    best = block_reduce<16>(best, sh);
+    return block_reduce<16>(best, sh);
+}
+
+// single GPU: records of the scan -> Cx, Cy.  Several GPUs: the all-gathered per-rank records.
+__global__ __launch_bounds__(1024) void k_pick(Dev d, const Cand* src, int nrecs) {
+    __shared__ Cand sh[16];
+    Cand best = reduce_records(d, src, nrecs, sh);
     if (threadIdx.x == 0) pick(d, best);
+}
+
+// several GPUs: this rank's records -> one candidate for the all-gather
+__global__ __launch_bounds__(1024) void k_reduce_local(Dev d, int nrecs) {
+    __shared__ Cand sh[16];
+    Cand best = reduce_records(d, d.recs, nrecs, sh);
+    if (threadIdx.x == 0) d.gsend[0] = best;
 }
 
 // ------------------------------------------------------------------ k_rx_fill
@@ -542,10 +559,53 @@ struct HipBackend {
     double scan_ms = 0.0;
     int64_t scan_launches = 0;
     int* d_bad = nullptr;
+    // RCCL (dlopen'ed: the process may already hold PyTorch's copy of the library)
+    void* rccl_lib = nullptr;
+    void* rccl_comm = nullptr;
+    int (*p_ncclCommInitRank)(void**, int, fnn_nccl_id, int) = nullptr;
+    int (*p_ncclAllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*p_ncclCommDestroy)(void*) = nullptr;
+    const char* (*p_ncclGetErrorString)(int) = nullptr;
+    std::string comm_err;
     int scan_grid = 8192;   // workgroups of the scan (FNN_SCAN_GRID)
     bool scan_nt = true;    // non-temporal matrix loads in the scan (FNN_SCAN_NT)
 
-    std::string err() const { return std::string(hipGetErrorString(last)); }
+    std::string err() const { return comm_err.empty() ? std::string(hipGetErrorString(last)) : comm_err; }
+
+    static void* open_rccl(const char* path, std::string& why) {
+        const char* cands[4] = {path, std::getenv("FNN_RCCL_PATH"), "librccl.so.1", "librccl.so"};
+        for (const char* c : cands) {
+            if (!c || !*c) continue;
+            if (void* h = dlopen(c, RTLD_NOW | RTLD_LOCAL)) return h;
+            why = dlerror();
+        }
+        return nullptr;
+    }
+    int32_t comm_init_rccl(int world, int rank, const uint8_t* id, const char* path) {
+        comm_err.clear();
+        if (!rccl_lib && !(rccl_lib = open_rccl(path, comm_err))) { comm_err = "cannot load librccl: " + comm_err; return FNN_ERCCL; }
+        p_ncclCommInitRank = (decltype(p_ncclCommInitRank))dlsym(rccl_lib, "ncclCommInitRank");
+        p_ncclAllGather = (decltype(p_ncclAllGather))dlsym(rccl_lib, "ncclAllGather");
+        p_ncclCommDestroy = (decltype(p_ncclCommDestroy))dlsym(rccl_lib, "ncclCommDestroy");
+        p_ncclGetErrorString = (decltype(p_ncclGetErrorString))dlsym(rccl_lib, "ncclGetErrorString");
+        if (!p_ncclCommInitRank || !p_ncclAllGather || !p_ncclCommDestroy) { comm_err = "librccl lacks the expected symbols"; return FNN_ERCCL; }
+        fnn_nccl_id uid;
+        std::memcpy(uid.internal, id, sizeof(uid.internal));
+        (void)hipSetDevice(device);
+        int rc = p_ncclCommInitRank(&rccl_comm, world, uid, rank);
+        if (rc != 0) {
+            comm_err = std::string("ncclCommInitRank: ") + (p_ncclGetErrorString ? p_ncclGetErrorString(rc) : "error");
+            rccl_comm = nullptr;
+            return FNN_ERCCL;
+        }
+        return FNN_OK;
+    }
+    int32_t allgather_on_stream(const Dev& d) {
+        if (!rccl_comm) { comm_err = "RCCL communicator not initialised"; return FNN_ERCCL; }
+        int rc = p_ncclAllGather(d.gsend, d.grecv, sizeof(Cand), /*ncclInt8*/ 0, rccl_comm, stream);
+        if (rc != 0) { comm_err = std::string("ncclAllGather: ") + (p_ncclGetErrorString ? p_ncclGetErrorString(rc) : "error"); return FNN_ERCCL; }
+        return FNN_OK;
+    }
 
     int32_t open(int32_t dev) {
         int cnt = 0;
@@ -564,6 +624,8 @@ struct HipBackend {
     void close() {
         if (!opened) return;
         (void)hipSetDevice(device);
+        if (rccl_comm && p_ncclCommDestroy) (void)p_ncclCommDestroy(rccl_comm);
+        rccl_comm = nullptr;
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
         ev_pool.clear();
         if (d_bad) (void)hipFree(d_bad);
@@ -660,11 +722,11 @@ struct HipBackend {
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
 
-    int32_t launch_event(const Dev& d, int32_t m_bound) {
-        if (m_bound < 1) m_bound = 1;
-        int nt = scan_tile_count(m_bound);
-        dim3 gs((unsigned)(nt < scan_grid ? (nt > 0 ? nt : 1) : scan_grid));
-        dim3 g1 = grid1(m_bound);
+    dim3 scan_dims(const Dev& d, int32_t m_bound) const {
+        int nt = (scan_tile_count(m_bound) + d.world - 1) / d.world;  // tiles of this rank
+        return dim3((unsigned)(nt < scan_grid ? (nt > 0 ? nt : 1) : scan_grid));
+    }
+    void enqueue_scan(const Dev& d, dim3 gs) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timing) { e0 = next_event(); e1 = next_event(); }
         if (e0) (void)hipEventRecord(e0, stream);
@@ -672,11 +734,35 @@ struct HipBackend {
         else hipLaunchKernelGGL(k_scan<false>, gs, dim3(SCAN_THREADS), 0, stream, d);
         if (e1) (void)hipEventRecord(e1, stream);
         scan_launches++;
-        hipLaunchKernelGGL(k_pick, dim3(1), dim3(1024), 0, stream, d, (int)gs.x);
+    }
+    void enqueue_rest(const Dev& d, int32_t m_bound) {
+        dim3 g1 = grid1(m_bound);
         hipLaunchKernelGGL(k_rx_fill, g1, dim3(256), 0, stream, d);
         hipLaunchKernelGGL(k_decide4, dim3(1), dim3(CH_T), 0, stream, d, (int)g1.x);
         hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d);
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d);
+    }
+    // single GPU: the whole event
+    int32_t launch_event(const Dev& d, int32_t m_bound) {
+        if (m_bound < 1) m_bound = 1;
+        dim3 gs = scan_dims(d, m_bound);
+        enqueue_scan(d, gs);
+        hipLaunchKernelGGL(k_pick, dim3(1), dim3(1024), 0, stream, d, (const Cand*)d.recs, (int)gs.x);
+        enqueue_rest(d, m_bound);
+        return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
+    }
+    // several GPUs: scan of this rank's tiles + local reduction ... (all-gather) ... the rest
+    int32_t launch_event_scan(const Dev& d, int32_t m_bound) {
+        if (m_bound < 1) m_bound = 1;
+        dim3 gs = scan_dims(d, m_bound);
+        enqueue_scan(d, gs);
+        hipLaunchKernelGGL(k_reduce_local, dim3(1), dim3(1024), 0, stream, d, (int)gs.x);
+        return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
+    }
+    int32_t launch_event_rest(const Dev& d, int32_t m_bound) {
+        if (m_bound < 1) m_bound = 1;
+        hipLaunchKernelGGL(k_pick, dim3(1), dim3(1024), 0, stream, d, (const Cand*)d.grecv, d.world);
+        enqueue_rest(d, m_bound);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
 };
@@ -809,6 +895,43 @@ int32_t fnn_canonical_order_f64(const double* D, int32_t n, int64_t ld, const fn
     fnn_destroy(h);
     fnn::g_last_error = keep;
     return rc;
+}
+
+int32_t fnn_comm_unique_id(uint8_t* id_out, const char* rccl_path) {
+    if (!id_out) return fnn::fail(FNN_EINVAL, "fnn_comm_unique_id: id_out is NULL");
+    std::string why;
+    void* lib = fnn::HipBackend::open_rccl(rccl_path, why);
+    if (!lib) return fnn::fail(FNN_ERCCL, "cannot load librccl: " + why);
+    auto get = (int (*)(fnn::fnn_nccl_id*))dlsym(lib, "ncclGetUniqueId");
+    if (!get) return fnn::fail(FNN_ERCCL, "librccl lacks ncclGetUniqueId");
+    fnn::fnn_nccl_id uid;
+    int rc = get(&uid);
+    if (rc != 0) return fnn::fail(FNN_ERCCL, "ncclGetUniqueId failed");
+    std::memcpy(id_out, uid.internal, FNN_COMM_ID_BYTES);
+    return FNN_OK;
+}
+int32_t fnn_comm_init_rccl(fnn_handle* h, int32_t world, int32_t rank, const uint8_t* id, const char* rccl_path) {
+    FNN_NEED(h);
+    if (!id) return fnn::fail(FNN_EINVAL, "fnn_comm_init_rccl: id is NULL");
+    FNN_TRY(
+        int32_t rc = h->eng.comm_set(1, world, rank);
+        if (rc != FNN_OK) return rc;
+        if (h->eng.comm_mode == 0) return FNN_OK;
+        rc = h->eng.be.comm_init_rccl(world, rank, id, rccl_path);
+        if (rc != FNN_OK) { h->eng.comm_set(0, 1, 0); return fnn::fail(rc, h->eng.be.err()); }
+        return FNN_OK;
+    )
+}
+int32_t fnn_comm_init_host(fnn_handle* h, int32_t world, int32_t rank, fnn_allgather_fn fn, void* ctx) {
+    FNN_NEED(h);
+    if (world > 1 && !fn) return fnn::fail(FNN_EINVAL, "fnn_comm_init_host: callback is NULL");
+    FNN_TRY(
+        int32_t rc = h->eng.comm_set(2, world, rank);
+        if (rc != FNN_OK) return rc;
+        h->eng.host_fn = fn;
+        h->eng.host_ctx = ctx;
+        return FNN_OK;
+    )
 }
 
 int32_t fnn_test_chain_sum(int32_t device, const double* host_buf, int32_t m, int32_t guard_bits, int32_t ept,

@@ -142,6 +142,26 @@ int32_t fnn_set_scan_timing(fnn_handle* h, int32_t enable);
 int32_t fnn_canonical_order_f64(const double* D, int32_t n, int64_t ld, const fnn_opts* opts,
                                 int32_t* order_out, fnn_stats* stats);
 
+/* ---- several GPUs of one node (one process per GPU) ------------------------------------
+ * Every rank holds the whole matrix (8 GiB at n = 32768, 3 % of an MI355X) and scans 1/world
+ * of the tiles of each event; ONE 16-byte record per rank is all-gathered per event (the
+ * global Q-argmin) and every rank then applies the same deterministic update to its own copy,
+ * so no matrix row ever crosses xGMI.  All ranks must upload the same matrix and make the same
+ * calls; every rank returns the same order.
+ *
+ * fnn_comm_unique_id: rank 0 creates the 128-byte RCCL id and the caller ships it to the other
+ * ranks (bench.py uses torch.distributed for that).  fnn_comm_init_rccl: collective over all
+ * ranks; the all-gather then runs as ncclAllGather on the engine's stream (no host round
+ * trip).  rccl_path may name the librccl.so to dlopen (NULL: default search).
+ * fnn_comm_init_host: test transport - the engine synchronises once per event and calls
+ * `fn(ctx, send, recv, bytes_per_rank)` on the host, which must fill recv with every rank's
+ * `send` in rank order and return 0. */
+#define FNN_COMM_ID_BYTES 128
+typedef int32_t (*fnn_allgather_fn)(void* ctx, const void* send, void* recv, int32_t bytes_per_rank);
+int32_t fnn_comm_unique_id(uint8_t* id_out, const char* rccl_path);
+int32_t fnn_comm_init_rccl(fnn_handle* h, int32_t world, int32_t rank, const uint8_t* id, const char* rccl_path);
+int32_t fnn_comm_init_host(fnn_handle* h, int32_t world, int32_t rank, fnn_allgather_fn fn, void* ctx);
+
 /* Diagnostic: the exact block-parallel evaluation of the sequential fp64 sum
  * (((0 + b[0]) + b[1]) + ...) used for ComputeRx / u.Sx (NetMakerOriginal.java:551-560,
  * :532), run on an arbitrary host buffer.  ept = addends per thread (32, fixed by the

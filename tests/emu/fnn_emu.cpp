@@ -92,9 +92,9 @@ struct EmuBackend {
         return FNN_OK;
     }
 
-    int32_t launch_event(const fnn::Dev& d, int32_t m_bound) {
+    // k_scan over this rank's share of the micro-tiles
+    fnn::Cand scan_local(const fnn::Dev& d) {
         fnn::State& st = *d.st;
-        // k_scan
         fnn::Cand best;
         best.q = fnn::inf_f64();
         best.key = ~0ULL;
@@ -102,8 +102,10 @@ struct EmuBackend {
             int32_t m = st.m, twoP = 2 * st.P;
             double cm2 = (double)st.c - 2.0;
             std::vector<std::pair<int32_t, int32_t>> tiles;
+            int64_t idx = 0;
             for (int32_t r0 = 0; r0 < m; r0 += 2)
-                for (int32_t c0 = 0; c0 <= r0; c0 += 2) tiles.emplace_back(r0, c0);
+                for (int32_t c0 = 0; c0 <= r0; c0 += 2, idx++)
+                    if (idx % d.world == d.rank) tiles.emplace_back(r0, c0);
             for (int32_t t : thread_order((int32_t)tiles.size())) {
                 int32_t r0 = tiles[(size_t)t].first, c0 = tiles[(size_t)t].second;
                 const double* R0 = d.D + (int64_t)r0 * d.ld;
@@ -114,6 +116,22 @@ struct EmuBackend {
                                 d.Sx[c0], c1 ? d.Sx[c0 + 1] : 0.0, d.spos[c0], c1 ? d.spos[c0 + 1] : 0, best);
             }
         }
+        return best;
+    }
+    int32_t launch_event(const fnn::Dev& d, int32_t m_bound) { return event_rest(d, m_bound, scan_local(d)); }
+    int32_t launch_event_scan(const fnn::Dev& d, int32_t) { d.gsend[0] = scan_local(d); return FNN_OK; }
+    int32_t allgather_on_stream(const fnn::Dev&) { return FNN_ERCCL; }  // no RCCL in the emulation
+    int32_t launch_event_rest(const fnn::Dev& d, int32_t m_bound) {
+        fnn::Cand best;
+        best.q = fnn::inf_f64();
+        best.key = ~0ULL;
+        for (int32_t r = 0; r < d.world; r++)
+            if (fnn::cand_better(d.grecv[r], best)) best = d.grecv[r];
+        return event_rest(d, m_bound, best);
+    }
+
+    int32_t event_rest(const fnn::Dev& d, int32_t m_bound, fnn::Cand best) {
+        fnn::State& st = *d.st;
         // k_pick
         fnn::pick(d, best);
         if (!st.ev_active) return FNN_OK;
@@ -286,5 +304,13 @@ int32_t emu_get_counts(void* h, int32_t* m, int32_t* c, int32_t* nn) {
 }
 int32_t emu_get_nodes(void* h, int32_t* id, int32_t* nbr, double* sx) { return ((EmuEngine*)h)->get_nodes(id, nbr, sx); }
 int32_t emu_get_live_matrix(void* h, double* out) { return ((EmuEngine*)h)->get_live_matrix(out); }
+int32_t emu_comm_init_host(void* h, int32_t world, int32_t rank, fnn_allgather_fn fn, void* ctx) {
+    auto* e = (EmuEngine*)h;
+    int32_t rc = e->comm_set(2, world, rank);
+    if (rc != FNN_OK) return rc;
+    e->host_fn = fn;
+    e->host_ctx = ctx;
+    return FNN_OK;
+}
 
 }  // extern "C"

@@ -1,0 +1,92 @@
+"""The N > 1 path: several ranks, scan sharded over the ranks, one all-gathered candidate per
+event.  On CPU (gloo, world_size 2 and 3) through the emulation; on the GPU box with every rank
+on the one GPU (host-callback transport; RCCL itself needs distinct GPUs and is exercised by
+the driver's multi-GPU bench)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_ranks(backend, world, n, seed, dist_name, tmp_path, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
+    procs = []
+    for r in range(world):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), backend, str(n),
+                                       str(seed), dist_name, str(tmp_path)], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    return [json.load(open(os.path.join(str(tmp_path), f"rank{r}.json"))) for r in range(world)]
+
+
+def check(res, oracle, n, seed, dist_name):
+    o_ref, ev_ref, se = oracle.run(oracle.synth(n, seed, dist_name))
+    for r in res:
+        assert r["order"] == o_ref.tolist()
+        assert r["n_events"] == len(ev_ref) and r["sum_entries"] == se
+        assert r["kinds"] == ev_ref["kind"].tolist()
+        assert r["x"] == ev_ref["x_id"].tolist() and r["y"] == ev_ref["y_id"].tolist()
+
+
+@pytest.mark.parametrize("world,n,seed,dist_name", [(2, 70, 1, "uniform53"), (2, 45, 2, "dec4"), (3, 64, 3, "uniform53")])
+def test_emulation_over_gloo(emu_api, oracle, tmp_path, world, n, seed, dist_name):
+    res = run_ranks("emu", world, n, seed, dist_name, tmp_path, 29511 + world + n)
+    check(res, oracle, n, seed, dist_name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,seed,dist_name", [(2, 600, 1, "uniform53"), (3, 300, 2, "dec4")])
+def test_hip_ranks_sharing_one_gpu(hip_api, oracle, tmp_path, world, n, seed, dist_name):
+    res = run_ranks("hip", world, n, seed, dist_name, tmp_path, 29611 + world)
+    check(res, oracle, n, seed, dist_name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("torch_first", [True, False])
+def test_rccl_plumbing_single_rank(oracle, torch_first):
+    """RCCL needs one GPU per rank, so on a one-GPU box only a 1-rank communicator can be made;
+    FNN_COMM_FORCE keeps the exchange path on: dlopen, unique id, ncclCommInitRank, one
+    ncclAllGather per event on the engine's stream, ncclCommDestroy."""
+    code = r'''
+import os, sys
+sys.path.insert(0, os.environ["FNN_ROOT"]); sys.path.insert(0, os.path.join(os.environ["FNN_ROOT"], "tests"))
+import ctypes as C
+if os.environ["FNN_TORCH_FIRST"] == "1":
+    import torch   # bench.py order: torch's HIP runtime serves both
+import fastneighbornet_amd as fa
+fa.api()
+from fastneighbornet_amd import distributed as fd
+from fastneighbornet_amd._capi import Handle
+from oracle import nnet_oracle as O
+a = fa.api()
+n = 500
+D = O.synth(n, 3)
+o_ref, _, _ = O.run(D)
+buf = (C.c_uint8 * 128)()
+path = fd.rccl_path()
+with Handle(a, n) as h:   # HIP is initialised before RCCL is touched, as in bench.py
+    a.check(a.comm_unique_id(buf, path.encode() if path else None))
+    h.comm_init_rccl(1, 0, bytes(buf), path)
+    h.set_matrix(D)
+    order, st = h.run()
+assert (order == o_ref).all()
+print("RCCL_OK")
+'''
+    env = dict(os.environ, FNN_COMM_FORCE="1", FNN_ROOT=ROOT, FNN_TORCH_FIRST="1" if torch_first else "0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout + r.stderr
