@@ -6,7 +6,7 @@ A "step" = one complete circular-order computation (initial row sums, the whole
 agglomeration loop, expansion) on a synthetic random symmetric matrix that is already
 resident in HBM when the step starts.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 32768] [--seed 1]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--taxa 32768] [--seed 1]
 
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU): every rank
 holds the whole matrix and scans 1/N of each event's tiles; one 16-byte candidate per rank is
@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=32768)
+    ap.add_argument("--taxa", "--n", dest="n", type=int, default=32768)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
