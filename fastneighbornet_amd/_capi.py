@@ -20,7 +20,7 @@ KIND_2WAY, KIND_3WAY, KIND_4WAY, KIND_FINISH = 2, 3, 4, 5
 
 class FnnOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("validate", C.c_int32), ("record_events", C.c_int32),
-                ("force_exact_rx", C.c_int32), ("reserved", C.c_int32 * 12)]
+                ("force_exact_rx", C.c_int32), ("disable_screen", C.c_int32), ("reserved", C.c_int32 * 11)]
 
 
 class FnnEvent(C.Structure):
@@ -37,7 +37,8 @@ class FnnStats(C.Structure):
     _fields_ = [("n_events", C.c_int64), ("sum_entries", C.c_int64), ("t_init_s", C.c_double),
                 ("t_agglom_s", C.c_double), ("t_expand_s", C.c_double), ("t_total_s", C.c_double),
                 ("t_scan_s", C.c_double), ("scan_launches", C.c_int64), ("scan_bytes", C.c_int64),
-                ("n_rx_certified", C.c_int64), ("n_rx_exact", C.c_int64), ("reserved", C.c_int64 * 6)]
+                ("n_rx_certified", C.c_int64), ("n_rx_exact", C.c_int64), ("n_screen_events", C.c_int64),
+                ("n_rescan_units", C.c_int64), ("reserved", C.c_int64 * 4)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -105,7 +106,7 @@ class Handle:
     """Thin RAII wrapper over an engine handle of either library."""
 
     def __init__(self, api: Api, n: int, device: int = 0, validate: bool = False,
-                 record_events: bool = False, force_exact_rx: bool = False):
+                 record_events: bool = False, force_exact_rx: bool = False, disable_screen: bool = False):
         self.api = api
         self.n = int(n)
         opts = FnnOpts()
@@ -113,6 +114,7 @@ class Handle:
         opts.validate = 1 if validate else 0
         opts.record_events = 1 if record_events else 0
         opts.force_exact_rx = 1 if force_exact_rx else 0
+        opts.disable_screen = 1 if disable_screen else 0
         h = C.c_void_p()
         api.check(api.create(self.n, C.byref(opts), C.byref(h)))
         self._h = h

@@ -85,6 +85,13 @@ struct State {
     int32_t n, m, c, P, num_nodes, done, n_agg3, record_events;
     int64_t n_events, sum_entries;
     int32_t error;  // non-zero if an "unreachable" branch was taken
+    // ---- fp32 screening (see screen_delta) ----
+    int32_t screen_ok;     // the bound is valid for this matrix (finite, |D| < 1e37)
+    int32_t rescan_all;    // candidate list overflowed: rescan every unit
+    int32_t ncand;         // units in clist
+    int32_t pad_scr;
+    uint64_t dmax_bits;    // bit pattern of max |D| over the input matrix
+    int64_t n_rescan_units, n_screen_events;  // statistics
     // ---- current event ----
     int32_t ev_active, ev_finish, need_rx;
     int32_t sa, sap, sb, sbp;  // slots of Cx, Cx.nbr, Cy, Cy.nbr (-1: none)
@@ -116,6 +123,9 @@ struct Dev {
     int64_t cstride; // n rounded up to a whole super-chunk
     Cand* recs;      // per-block scan records
     double* rxpart;  // per-block partial sums of k_rx_fill: [block][8] = 4 sums + 4 sums of |terms|
+    float* F;        // fp32 screening copy of D (same geometry, F[r][c] == (float)D[r][c])
+    float* srec;     // screening: per-unit minimum of the fp32 Q estimate
+    int32_t* clist;  // screening: units that may hold the true minimum
     Cand* gsend;     // multi-GPU: this rank's best candidate of the event (1 record)
     Cand* grecv;     // multi-GPU: all ranks' candidates (world records)
     int32_t rank, world;  // scan sharding: rank scans the tiles with index = rank (mod world)
@@ -206,6 +216,88 @@ FNN_HD void scan_micro(int32_t r0, int32_t c0, int32_t m, int32_t twoP, double c
             if (r1ok) consider(qval(cm2, e10, sxr1, pr1, sxc0, pc0), pr1, pc0, best);
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// fp32 screening of the scan.  A float copy F of the matrix is streamed
+// (4 B per entry instead of 8) and Q is estimated in fp32:  Qh = (cm2 * mean(F entries) - Sp) - Sq
+// with Sx rounded to float.  Error budget, u = 2^-24, Dmax = max |D| of the INPUT matrix (entries
+// only ever become convex combinations of earlier entries, so it bounds every later entry),
+// |Sx| <= n * Dmax (a sum of <= n cluster distances), M = (c-2) Dmax + 2 n Dmax >= any
+// intermediate magnitude:
+//   entry rounding + <=3 adds of the mean     4 u Dmax, amplified by (c-2)
+//   the product                               u (c-2) Dmax
+//   rounding Sp, Sq to float                  2 u n Dmax
+//   the two subtractions                      2 u M
+//   total  <=  u Dmax (7 (c-2) + 6 n);   the exact fp64 value's own roundings are ~2^-29 of that.
+// screen_delta returns twice this.  If Qh_min is the smallest estimate, the pair with the true
+// minimum has Qh <= Qh_min + 2 delta, and every pair with Qh > Qh_min + 2 delta has a true Q
+// STRICTLY above the true minimum - so rescanning (in fp64, with the exact tie-break) only the
+// units whose estimate-minimum is <= Qh_min + 2 delta gives the same pair as the full scan.
+// ---------------------------------------------------------------------------
+constexpr int SCR_TH = 32;    // rows per screening tile
+constexpr int SCR_TW = 1024;  // columns per screening tile (256 threads x 4)
+constexpr int SCR_UW = 256;   // columns per unit (one wave of a tile)
+constexpr int SCR_CAP = 16384;  // capacity of the candidate-unit list
+
+FNN_HD float screen_delta(const State& st) {
+    const double dmax = __builtin_bit_cast(double, st.dmax_bits);
+    const double u = 5.9604644775390625e-08;  // 2^-24
+    const double dlt = 2.0 * u * dmax * (7.0 * ((double)st.c - 2.0) + 6.0 * (double)st.n);
+    return (float)(dlt * 1.0000002);  // round up when narrowing to float
+}
+
+FNN_HD float fminf_(float a, float b) { return a < b ? a : b; }
+
+// one 2x2 block of the screening pass: same case analysis as scan_micro, fp32, minimum only
+FNN_HD void screen_micro(int32_t r0, int32_t c0, int32_t m, int32_t twoP, float cm2,
+                         float e00, float e01, float e10, float e11,
+                         float sxr0, float sxr1, float sxc0, float sxc1, float& best) {
+    if (r0 >= m || c0 >= m || c0 > r0) return;
+    if (r0 < twoP) {
+        if (r0 == c0) return;
+        const float dpq = (((e00 + e01) + e10) + e11) * 0.25f;
+        best = fminf_(best, (cm2 * dpq - sxr0) - sxc0);
+    } else if (c0 < twoP) {
+        best = fminf_(best, (cm2 * ((e00 + e01) * 0.5f) - sxr0) - sxc0);
+        if (r0 + 1 < m) best = fminf_(best, (cm2 * ((e10 + e11) * 0.5f) - sxr1) - sxc0);
+    } else {
+        const bool c1ok = (c0 + 1 < m), r1ok = (r0 + 1 < m);
+        if (r0 > c0) {
+            best = fminf_(best, (cm2 * e00 - sxr0) - sxc0);
+            if (c1ok) best = fminf_(best, (cm2 * e01 - sxr0) - sxc1);
+            if (r1ok) {
+                best = fminf_(best, (cm2 * e10 - sxr1) - sxc0);
+                if (c1ok) best = fminf_(best, (cm2 * e11 - sxr1) - sxc1);
+            }
+        } else if (r1ok) best = fminf_(best, (cm2 * e10 - sxr1) - sxc0);
+    }
+}
+
+// triangular tile bookkeeping, shared by the exact scan (R = 16) and the screening pass (R = 32):
+// row tiles of TH rows come in bands of R; a row tile of band g owns g + 1 column tiles
+FNN_HD int32_t tri_tile_count(int32_t m, int32_t TH, int32_t R) {
+    const int32_t nrt = (m + TH - 1) / TH;
+    const int32_t G = nrt / R, rr = nrt % R;
+    return (R / 2) * G * (G + 1) + rr * (G + 1);
+}
+FNN_HD void tri_tile_decode(int32_t t, int32_t R, int32_t& rt, int32_t& ct) {
+    // largest g with (R/2) g (g+1) <= t; the float estimate is corrected by the two loops
+    int32_t g = (int32_t)((__builtin_sqrtf(1.0f + (float)t * (8.0f / (float)R)) - 1.0f) * 0.5f);
+    if (g < 0) g = 0;
+    while ((R / 2) * (g + 1) * (g + 2) <= t) g++;
+    while (g > 0 && (R / 2) * g * (g + 1) > t) g--;
+    const int32_t r = t - (R / 2) * g * (g + 1);
+    rt = R * g + r / (g + 1);
+    ct = r % (g + 1);
+}
+// number of screening units for m live slots: 4 per screening tile
+FNN_HD int32_t screen_unit_count(int32_t m) { return 4 * tri_tile_count(m, SCR_TH, SCR_TW / SCR_TH); }
+
+// every store into the matrix keeps the fp32 copy in step
+FNN_HD void store_d(const Dev& d, int64_t idx, double v) {
+    d.D[idx] = v;
+    if (d.F) d.F[idx] = (float)v;
 }
 
 // ---------------------------------------------------------------------------
@@ -561,17 +653,17 @@ FNN_HD void op_thread(const Dev& d, const Op& op, int32_t k) {
             double t = d.Sx[a]; d.Sx[a] = d.Sx[b]; d.Sx[b] = t;
         } else if (k != b) {
             double ta = D[a * ld + k], tb = D[b * ld + k];
-            D[a * ld + k] = tb; D[k * ld + a] = tb;
-            D[b * ld + k] = ta; D[k * ld + b] = ta;
+            store_d(d, a * ld + k, tb); store_d(d, k * ld + a, tb);
+            store_d(d, b * ld + k, ta); store_d(d, k * ld + b, ta);
         }
     } else if (op.kind == OP_MOVE) {
         int32_t src = op.a, dst = op.b;
         if (k == src) {
-            D[dst * ld + dst] = 0.0;
+            store_d(d, dst * ld + dst, 0.0);
             d.Sx[dst] = d.Sx[src];
         } else if (k != dst) {
             double t = D[src * ld + k];
-            D[dst * ld + k] = t; D[k * ld + dst] = t;
+            store_d(d, dst * ld + k, t); store_d(d, k * ld + dst, t);
         }
     } else if (op.kind == OP_AGG3) {
         int32_t X = op.a, Y = op.b, Z = op.c, U = op.d, V = op.e;
@@ -583,14 +675,14 @@ FNN_HD void op_thread(const Dev& d, const Op& op, int32_t k) {
             double uv;
             if (op.flag) uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + dyx / 3.0) + dyz / 3.0;
             else uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + dyz / 3.0) + dyx / 3.0;
-            D[U * ld + U] = 0.0; D[V * ld + V] = 0.0;
-            D[U * ld + V] = uv; D[V * ld + U] = uv;
+            store_d(d, U * ld + U, 0.0); store_d(d, V * ld + V, 0.0);
+            store_d(d, U * ld + V, uv); store_d(d, V * ld + U, uv);
         } else if (k != Y && k != Z) {
             double dx = D[X * ld + k], dy = D[Y * ld + k], dz = D[Z * ld + k];
             double nu = (2.0 / 3.0) * dx + dy / 3.0;
             double nv = (2.0 / 3.0) * dz + dy / 3.0;
-            D[U * ld + k] = nu; D[k * ld + U] = nu;
-            D[V * ld + k] = nv; D[k * ld + V] = nv;
+            store_d(d, U * ld + k, nu); store_d(d, k * ld + U, nu);
+            store_d(d, V * ld + k, nv); store_d(d, k * ld + V, nv);
         }
     }
 }
@@ -675,11 +767,11 @@ FNN_HD void update_bulk(const Dev& d, int32_t k) {
     for (int t = 0; t < MAX_TGT; t++) {
         if (t < st.ntgt) {
             const int32_t dst = st.tgt[t].dst;
-            D[dst * ld + k] = tv[t][0];
-            D[k * ld + dst] = tv[t][0];
+            store_d(d, dst * ld + k, tv[t][0]);
+            store_d(d, k * ld + dst, tv[t][0]);
             if (paired) {
-                D[dst * ld + k + 1] = tv[t][1];
-                D[(k + 1) * ld + dst] = tv[t][1];
+                store_d(d, dst * ld + k + 1, tv[t][1]);
+                store_d(d, (k + 1) * ld + dst, tv[t][1]);
             }
         }
     }
@@ -739,6 +831,11 @@ FNN_HD void init_thread(const Dev& d, int32_t k) {
     d.sid[k] = k + 1;
     d.spos[k] = k;
     d.pslot[k] = k;
+    if (k == 0) {
+        // the screening bound needs a finite, float-representable bound on |D| (prep kernel)
+        const double dmax = __builtin_bit_cast(double, d.st->dmax_bits);
+        d.st->screen_ok = (d.F != nullptr && dmax == dmax && dmax < 1e37) ? 1 : 0;
+    }
 }
 
 // SplitMix64, k-th output for a given seed

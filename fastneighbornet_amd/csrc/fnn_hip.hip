@@ -65,26 +65,14 @@ __device__ __forceinline__ Cand block_reduce(Cand c, Cand* sh) {
 // ------------------------------------------------------------------ k_scan
 // Tiles of SCAN_TH rows x SCAN_TW columns cover the lower triangle of the live m x m block.
 // Row tiles come in bands of R = SCAN_TW / SCAN_TH; every row tile of band g owns g + 1 column
-// tiles, so the tiles in front of band g number R * g * (g + 1) / 2.  A fixed-size grid strides
-// over the linear tile index (no empty workgroups, at most gridDim.x records for k_pick).
+// tiles (fnn_core.h: tri_tile_count / tri_tile_decode).  A fixed-size grid strides over the
+// linear tile index (no empty workgroups, at most gridDim.x records for k_pick).
 constexpr int SCAN_R = SCAN_TW / SCAN_TH;
 
-__host__ __device__ inline int scan_tile_count(int m) {
-    const int nrt = (m + SCAN_TH - 1) / SCAN_TH;
-    const int G = nrt / SCAN_R, rr = nrt % SCAN_R;
-    return (SCAN_R / 2) * G * (G + 1) + rr * (G + 1);
-}
-
-__device__ __forceinline__ void scan_tile_decode(int t, int& rt, int& ct) {
-    int g = (int)((sqrtf(1.0f + (float)t * (8.0f / SCAN_R)) - 1.0f) * 0.5f);
-    while ((SCAN_R / 2) * (g + 1) * (g + 2) <= t) g++;
-    while ((SCAN_R / 2) * g * (g + 1) > t) g--;
-    const int r = t - (SCAN_R / 2) * g * (g + 1);
-    rt = SCAN_R * g + r / (g + 1);
-    ct = r % (g + 1);
-}
+__host__ __device__ inline int scan_tile_count(int m) { return tri_tile_count(m, SCAN_TH, SCAN_R); }
 
 typedef double fnn_v2f64 __attribute__((ext_vector_type(2)));
+typedef float fnn_v4f32 __attribute__((ext_vector_type(4)));
 template <bool NT>
 __device__ __forceinline__ double2 ld16(const double* p) {
     if (NT) {
@@ -92,6 +80,45 @@ __device__ __forceinline__ double2 ld16(const double* p) {
         return make_double2(v.x, v.y);
     }
     return *reinterpret_cast<const double2*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ float4 ld16f(const float* p) {
+    if (NT) {
+        const fnn_v4f32 v = __builtin_nontemporal_load(reinterpret_cast<const fnn_v4f32*>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+
+// exact scan of rows [rbase, rbase + 32) at the two columns c0, c0 + 1 of this thread
+template <bool NT>
+__device__ __forceinline__ void scan_rows_exact(const Dev& d, int rbase, int c0, int m, int twoP, double cm2, Cand& best) {
+    if (!(c0 < m && c0 <= rbase + SCAN_TH - 2)) return;
+    const double2 sxc = *reinterpret_cast<const double2*>(d.Sx + c0);
+    const int2 pc = *reinterpret_cast<const int2*>(d.spos + c0);
+    const double* colbase = d.D + c0;
+#pragma unroll 1
+    for (int half = 0; half < SCAN_TH / 16; half++) {
+        const int rb = rbase + 16 * half;
+        if (rb >= m) break;
+        double2 a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int r0 = rb + 2 * k;  // r0 + 1 < nrows (padded), c0 + 1 < ld: always in bounds
+            a[k] = ld16<NT>(colbase + (int64_t)r0 * d.ld);
+            b[k] = ld16<NT>(colbase + (int64_t)(r0 + 1) * d.ld);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int r0 = rb + 2 * k;
+            if (c0 <= r0) {
+                const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + r0);
+                const int2 pr = *reinterpret_cast<const int2*>(d.spos + r0);
+                scan_micro(r0, c0, m, twoP, cm2, a[k].x, a[k].y, b[k].x, b[k].y,
+                           sxr.x, sxr.y, pr.x, pr.y, sxc.x, sxc.y, pc.x, pc.y, best);
+            }
+        }
+    }
 }
 
 template <bool NT>
@@ -109,40 +136,156 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(Dev d) {
         // several GPUs: rank r of `world` takes the tiles with index = r (mod world)
         for (int t = blockIdx.x * d.world + d.rank; t < ntiles; t += gridDim.x * d.world) {
             int rt, ct;
-            scan_tile_decode(t, rt, ct);
-            const int rbase = rt * SCAN_TH;
-            const int c0 = ct * SCAN_TW + 2 * (int)threadIdx.x;
-            if (c0 < m && c0 <= rbase + SCAN_TH - 2) {
-                const double2 sxc = *reinterpret_cast<const double2*>(d.Sx + c0);
-                const int2 pc = *reinterpret_cast<const int2*>(d.spos + c0);
-                const double* colbase = d.D + c0;
-#pragma unroll 1
-                for (int half = 0; half < SCAN_TH / 16; half++) {
-                    const int rb = rbase + 16 * half;
-                    if (rb >= m) break;
-                    double2 a[8], b[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int r0 = rb + 2 * k;  // r0 + 1 < nrows (padded), c0 + 1 < ld: always in bounds
-                        a[k] = ld16<NT>(colbase + (int64_t)r0 * d.ld);
-                        b[k] = ld16<NT>(colbase + (int64_t)(r0 + 1) * d.ld);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int r0 = rb + 2 * k;
-                        if (c0 <= r0) {
-                            const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + r0);
-                            const int2 pr = *reinterpret_cast<const int2*>(d.spos + r0);
-                            scan_micro(r0, c0, m, twoP, cm2, a[k].x, a[k].y, b[k].x, b[k].y,
-                                       sxr.x, sxr.y, pr.x, pr.y, sxc.x, sxc.y, pc.x, pc.y, best);
-                        }
-                    }
-                }
-            }
+            tri_tile_decode(t, SCAN_R, rt, ct);
+            scan_rows_exact<NT>(d, rt * SCAN_TH, ct * SCAN_TW + 2 * (int)threadIdx.x, m, twoP, cm2, best);
         }
     }
     best = block_reduce<SCAN_THREADS / 64>(best, sh);
     if (threadIdx.x == 0) d.recs[blockIdx.x] = best;
+}
+
+// ------------------------------------------------------------------ fp32 screening (fnn_core.h: screen_delta)
+// k_screen streams the float copy (4 B per entry): tiles of 32 rows x 1024 columns, a thread owns
+// 4 adjacent columns (one 16-byte load per row), a wave owns one 32 x 256 "unit" and records the
+// minimum of the fp32 Q estimate over it.  k_select turns the records into the list of units
+// that can hold the true minimum; k_rescan scans exactly those in fp64 with the exact body.
+constexpr int SCR_R = SCR_TW / SCR_TH;
+
+template <bool NT>
+__global__ __launch_bounds__(256) void k_screen(Dev d) {
+    const State* st = d.st;
+    if (st->done) return;
+    const int m = st->m;
+    const int twoP = 2 * st->P;
+    const float cm2 = (float)((double)st->c - 2.0);
+    const int ntiles = tri_tile_count(m, SCR_TH, SCR_R);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int t = blockIdx.x * d.world + d.rank; t < ntiles; t += gridDim.x * d.world) {
+        int rt, ct;
+        tri_tile_decode(t, SCR_R, rt, ct);
+        const int rbase = rt * SCR_TH;
+        const int c0 = ct * SCR_TW + 4 * (int)threadIdx.x;
+        float best = __builtin_inff();
+        if (c0 < m && c0 <= rbase + SCR_TH - 2) {
+            const double2 sa = *reinterpret_cast<const double2*>(d.Sx + c0);
+            const double2 sb = *reinterpret_cast<const double2*>(d.Sx + c0 + 2);
+            const float sxc0 = (float)sa.x, sxc1 = (float)sa.y, sxc2 = (float)sb.x, sxc3 = (float)sb.y;
+            const float* colbase = d.F + c0;
+#pragma unroll 1
+            for (int half = 0; half < SCR_TH / 16; half++) {
+                const int rb = rbase + 16 * half;
+                if (rb >= m) break;
+                float4 a[8], b[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int r0 = rb + 2 * k;  // rows < nrows (padded), c0 + 3 < ld (ld padded to 1024)
+                    a[k] = ld16f<NT>(colbase + (int64_t)r0 * d.ld);
+                    b[k] = ld16f<NT>(colbase + (int64_t)(r0 + 1) * d.ld);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int r0 = rb + 2 * k;
+                    const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + r0);
+                    const float sxr0 = (float)sxr.x, sxr1 = (float)sxr.y;
+                    screen_micro(r0, c0, m, twoP, cm2, a[k].x, a[k].y, b[k].x, b[k].y, sxr0, sxr1, sxc0, sxc1, best);
+                    screen_micro(r0, c0 + 2, m, twoP, cm2, a[k].z, a[k].w, b[k].z, b[k].w, sxr0, sxr1, sxc2, sxc3, best);
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) best = fminf_(best, __shfl_down(best, off, 64));
+        if (lane == 0) d.srec[4 * t + w] = best;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_select(Dev d) {
+    __shared__ float shmin[16];
+    __shared__ int cnt;
+    State* st = d.st;
+    if (st->done) return;
+    const int m = st->m;
+    const int nunits = screen_unit_count(m);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float mn = __builtin_inff();
+    for (int u = threadIdx.x; u < nunits; u += 1024)
+        if ((u >> 2) % d.world == d.rank) mn = fminf_(mn, d.srec[u]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mn = fminf_(mn, __shfl_down(mn, off, 64));
+    if (lane == 0) shmin[w] = mn;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    float g = shmin[0];
+#pragma unroll
+    for (int k = 1; k < 16; k++) g = fminf_(g, shmin[k]);
+    // this rank's minimum is >= the global one, so its threshold only admits more units
+    const float thr = g + 2.0f * screen_delta(*st);
+    const bool all = !st->screen_ok || !(thr == thr);
+    if (!all) {
+        for (int u = threadIdx.x; u < nunits; u += 1024)
+            if ((u >> 2) % d.world == d.rank && d.srec[u] <= thr) {
+                const int i = atomicAdd(&cnt, 1);
+                if (i < SCR_CAP) d.clist[i] = u;
+            }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int c = cnt;
+        st->rescan_all = (all || c > SCR_CAP) ? 1 : 0;
+        st->ncand = c > SCR_CAP ? 0 : c;
+        st->n_screen_events += 1;
+        st->n_rescan_units += st->rescan_all ? (int64_t)nunits / d.world : (int64_t)c;
+    }
+}
+
+constexpr int RESCAN_THREADS = 128;
+template <bool NT>
+__global__ __launch_bounds__(RESCAN_THREADS) void k_rescan(Dev d) {
+    __shared__ Cand sh[RESCAN_THREADS / 64];
+    const State* st = d.st;
+    Cand best;
+    best.q = inf_f64();
+    best.key = ~0ULL;
+    if (!st->done) {
+        const int m = st->m;
+        const int twoP = 2 * st->P;
+        const double cm2 = (double)st->c - 2.0;
+        const bool all = st->rescan_all != 0;
+        const int count = all ? screen_unit_count(m) : st->ncand;
+        for (int i = blockIdx.x; i < count; i += gridDim.x) {
+            const int u = all ? i : d.clist[i];
+            if (all && (u >> 2) % d.world != d.rank) continue;
+            int rt, ct;
+            tri_tile_decode(u >> 2, SCR_R, rt, ct);
+            scan_rows_exact<NT>(d, rt * SCR_TH, ct * SCR_TW + (u & 3) * SCR_UW + 2 * (int)threadIdx.x, m, twoP, cm2, best);
+        }
+    }
+    best = block_reduce<RESCAN_THREADS / 64>(best, sh);
+    if (threadIdx.x == 0) d.recs[blockIdx.x] = best;
+}
+
+// D -> F for the whole padded matrix, and max |D| over the n x n input
+__global__ __launch_bounds__(256) void k_prep_screen(Dev d, int64_t nrows) {
+    __shared__ unsigned long long shmax[4];
+    const int64_t r = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long b = 0;
+    if (c < d.ld && r < nrows) {
+        const double v = d.D[r * d.ld + c];
+        d.F[r * d.ld + c] = (float)v;
+        if (r < d.n && c < d.n) b = f2u(v) & 0x7FFFFFFFFFFFFFFFULL;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_down(b, off, 64);
+        b = o > b ? o : b;
+    }
+    if ((threadIdx.x & 63) == 0) shmax[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long x = shmax[0];
+        for (int k = 1; k < 4; k++) x = shmax[k] > x ? shmax[k] : x;
+        if (x) atomicMax(reinterpret_cast<unsigned long long*>(&d.st->dmax_bits), x);
+    }
 }
 
 // ------------------------------------------------------------------ k_pick
@@ -547,7 +690,10 @@ __global__ __launch_bounds__(256) void k_stream(const double2* p, int64_t n16, d
 
 struct HipBackend {
     static constexpr int64_t kRowPad = SCAN_TH;
-    static constexpr int64_t kColPad = SCAN_TW;
+    static constexpr int64_t kColPad = SCR_TW;   // whole screening tiles (and scan tiles) stay in bounds
+    // below this many taxa the fp32 copy is not even allocated (FNN_SCREEN_MIN_N, tests)
+    int32_t screen_min_n() const { if (const char* e = std::getenv("FNN_SCREEN_MIN_N")) { int v = std::atoi(e); if (v >= 8) return v; } return 8192; }
+    int screen_min_m = 8192;                     // events with fewer live nodes use the plain scan (FNN_SCREEN_MIN_M)
     hipError_t last = hipSuccess;
     hipStream_t stream = nullptr;
     int device = 0;
@@ -618,6 +764,7 @@ struct HipBackend {
             return fail(FNN_EHIP, "hipStreamCreate failed (" + err() + ")");
         if (const char* e = std::getenv("FNN_SCAN_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) scan_grid = v; }
         if (const char* e = std::getenv("FNN_SCAN_NT")) scan_nt = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FNN_SCREEN_MIN_M")) { int v = std::atoi(e); if (v >= 8) screen_min_m = v; }
         opened = true;
         return FNN_OK;
     }
@@ -716,6 +863,11 @@ struct HipBackend {
         *bad = hb;
         return FNN_OK;
     }
+    int32_t launch_prep_screen(const Dev& d, int64_t nrows) {
+        dim3 g((unsigned)((d.ld + 255) / 256), (unsigned)nrows);
+        hipLaunchKernelGGL(k_prep_screen, g, dim3(256), 0, stream, d, nrows);
+        return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
+    }
     int32_t launch_init(const Dev& d) {
         reset_timing();
         hipLaunchKernelGGL(k_init, grid1(d.n), dim3(256), 0, stream, d);
@@ -726,14 +878,32 @@ struct HipBackend {
         int nt = (scan_tile_count(m_bound) + d.world - 1) / d.world;  // tiles of this rank
         return dim3((unsigned)(nt < scan_grid ? (nt > 0 ? nt : 1) : scan_grid));
     }
-    void enqueue_scan(const Dev& d, dim3 gs) {
+    bool use_screen(const Dev& d, int32_t m_bound) const { return d.F != nullptr && m_bound >= screen_min_m; }
+    // the scan of one event; returns the number of records left in d.recs
+    int enqueue_scan(const Dev& d, int32_t m_bound) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timing) { e0 = next_event(); e1 = next_event(); }
-        if (e0) (void)hipEventRecord(e0, stream);
-        if (scan_nt) hipLaunchKernelGGL(k_scan<true>, gs, dim3(SCAN_THREADS), 0, stream, d);
-        else hipLaunchKernelGGL(k_scan<false>, gs, dim3(SCAN_THREADS), 0, stream, d);
-        if (e1) (void)hipEventRecord(e1, stream);
+        int nrecs;
+        if (use_screen(d, m_bound)) {
+            int nt = (tri_tile_count(m_bound, SCR_TH, SCR_R) + d.world - 1) / d.world;
+            dim3 gs((unsigned)(nt < scan_grid ? (nt > 0 ? nt : 1) : scan_grid));
+            if (e0) (void)hipEventRecord(e0, stream);
+            if (scan_nt) hipLaunchKernelGGL(k_screen<true>, gs, dim3(256), 0, stream, d);
+            else hipLaunchKernelGGL(k_screen<false>, gs, dim3(256), 0, stream, d);
+            if (e1) (void)hipEventRecord(e1, stream);
+            hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, stream, d);
+            nrecs = 2048;
+            hipLaunchKernelGGL(k_rescan<false>, dim3(nrecs), dim3(RESCAN_THREADS), 0, stream, d);
+        } else {
+            dim3 gs = scan_dims(d, m_bound);
+            if (e0) (void)hipEventRecord(e0, stream);
+            if (scan_nt) hipLaunchKernelGGL(k_scan<true>, gs, dim3(SCAN_THREADS), 0, stream, d);
+            else hipLaunchKernelGGL(k_scan<false>, gs, dim3(SCAN_THREADS), 0, stream, d);
+            if (e1) (void)hipEventRecord(e1, stream);
+            nrecs = (int)gs.x;
+        }
         scan_launches++;
+        return nrecs;
     }
     void enqueue_rest(const Dev& d, int32_t m_bound) {
         dim3 g1 = grid1(m_bound);
@@ -745,18 +915,16 @@ struct HipBackend {
     // single GPU: the whole event
     int32_t launch_event(const Dev& d, int32_t m_bound) {
         if (m_bound < 1) m_bound = 1;
-        dim3 gs = scan_dims(d, m_bound);
-        enqueue_scan(d, gs);
-        hipLaunchKernelGGL(k_pick, dim3(1), dim3(1024), 0, stream, d, (const Cand*)d.recs, (int)gs.x);
+        int nrecs = enqueue_scan(d, m_bound);
+        hipLaunchKernelGGL(k_pick, dim3(1), dim3(1024), 0, stream, d, (const Cand*)d.recs, nrecs);
         enqueue_rest(d, m_bound);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
     // several GPUs: scan of this rank's tiles + local reduction ... (all-gather) ... the rest
     int32_t launch_event_scan(const Dev& d, int32_t m_bound) {
         if (m_bound < 1) m_bound = 1;
-        dim3 gs = scan_dims(d, m_bound);
-        enqueue_scan(d, gs);
-        hipLaunchKernelGGL(k_reduce_local, dim3(1), dim3(1024), 0, stream, d, (int)gs.x);
+        int nrecs = enqueue_scan(d, m_bound);
+        hipLaunchKernelGGL(k_reduce_local, dim3(1), dim3(1024), 0, stream, d, nrecs);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
     int32_t launch_event_rest(const Dev& d, int32_t m_bound) {

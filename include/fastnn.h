@@ -53,7 +53,11 @@ typedef struct fnn_opts {
     int32_t force_exact_rx;/* diagnostic: 1 = always evaluate the ComputeRx sums with the exact
                               sequential-sum kernel instead of certifying the 4-candidate choice
                               from tree sums (same result; exercises the rare path) */
-    int32_t reserved[12];
+    int32_t disable_screen;/* 1 = always scan the fp64 matrix in full; default (0): events with many
+                              live nodes first stream an fp32 copy of the matrix (half the bytes) to
+                              find, within a rigorous error bound, the few tile units that can hold
+                              the minimum, and only those are rescanned in fp64 (same result) */
+    int32_t reserved[11];
 } fnn_opts;
 
 /* One agglomeration event == one iteration of the loop of
@@ -82,7 +86,9 @@ typedef struct fnn_stats {
     int64_t scan_bytes;      /* algorithmic bytes of those launches (8 * sum E_t) */
     int64_t n_rx_certified;  /* events whose 4-candidate choice was certified from tree sums */
     int64_t n_rx_exact;      /* events that needed the exact sequential ComputeRx sums */
-    int64_t reserved[6];
+    int64_t n_screen_events; /* events whose scan went through the fp32 screening pass */
+    int64_t n_rescan_units;  /* 32 x 256 units rescanned in fp64 over those events */
+    int64_t reserved[4];
 } fnn_stats;
 
 typedef struct fnn_handle fnn_handle;

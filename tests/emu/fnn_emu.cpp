@@ -21,6 +21,8 @@ namespace {
 
 int g_order_mode = 0;  // 0 forward, 1 reverse, 2 shuffled
 int g_update_mode = 0; // interleaving of k_update's bulk threads and special phases
+int g_force_rescan_all = 0;       // screening: pretend the candidate list overflowed
+int g_cand_cap = fnn::SCR_CAP;    // screening: capacity of the candidate list
 uint64_t g_shuffle_state = 0x12345678ULL;
 
 std::vector<int32_t> thread_order(int32_t count) {
@@ -39,7 +41,9 @@ std::vector<int32_t> thread_order(int32_t count) {
 
 struct EmuBackend {
     static constexpr int64_t kRowPad = 32;
-    static constexpr int64_t kColPad = 512;
+    static constexpr int64_t kColPad = 1024;
+    int32_t screen_min_n() const { return 8; }   // tiny on purpose: the CPU tests exercise screening
+    int32_t screen_min_m = 8;
     std::string err() const { return "emu"; }
     int32_t open(int32_t) { return FNN_OK; }
     void close() {}
@@ -87,14 +91,100 @@ struct EmuBackend {
         return FNN_OK;
     }
 
+    int32_t launch_prep_screen(const fnn::Dev& d, int64_t nrows) {
+        uint64_t mx = 0;
+        for (int64_t r = 0; r < nrows; r++)
+            for (int64_t c = 0; c < d.ld; c++) {
+                double v = d.D[r * d.ld + c];
+                d.F[r * d.ld + c] = (float)v;
+                uint64_t b;
+                std::memcpy(&b, &v, 8);
+                b &= 0x7FFFFFFFFFFFFFFFULL;
+                if (r < d.n && c < d.n && b > mx) mx = b;
+            }
+        d.st->dmax_bits = mx;
+        return FNN_OK;
+    }
+
     int32_t launch_init(const fnn::Dev& d) {
         for (int32_t k : thread_order(d.n)) fnn::init_thread(d, k);
         return FNN_OK;
     }
 
+    // exact scan of one 32 x 256 unit (k_rescan)
+    void rescan_unit(const fnn::Dev& d, int32_t u, fnn::Cand& best) {
+        fnn::State& st = *d.st;
+        const int32_t m = st.m, twoP = 2 * st.P;
+        const double cm2 = (double)st.c - 2.0;
+        int32_t rt, ct;
+        fnn::tri_tile_decode(u / 4, fnn::SCR_TW / fnn::SCR_TH, rt, ct);
+        const int32_t rb = rt * fnn::SCR_TH, cb = ct * fnn::SCR_TW + (u % 4) * fnn::SCR_UW;
+        for (int32_t r0 = rb; r0 < rb + fnn::SCR_TH && r0 < m; r0 += 2)
+            for (int32_t c0 = cb; c0 < cb + fnn::SCR_UW && c0 <= r0; c0 += 2) {
+                const double* R0 = d.D + (int64_t)r0 * d.ld;
+                const double* R1 = d.D + (int64_t)(r0 + 1) * d.ld;
+                bool r1 = r0 + 1 < m, c1 = c0 + 1 < m;
+                fnn::scan_micro(r0, c0, m, twoP, cm2, R0[c0], R0[c0 + 1], R1[c0], R1[c0 + 1],
+                                d.Sx[r0], r1 ? d.Sx[r0 + 1] : 0.0, d.spos[r0], r1 ? d.spos[r0 + 1] : 0,
+                                d.Sx[c0], c1 ? d.Sx[c0 + 1] : 0.0, d.spos[c0], c1 ? d.spos[c0 + 1] : 0, best);
+            }
+    }
+    // k_screen + k_select + k_rescan: fp32 screening, candidate units, exact rescan
+    fnn::Cand scan_screened(const fnn::Dev& d) {
+        fnn::State& st = *d.st;
+        fnn::Cand best;
+        best.q = fnn::inf_f64();
+        best.key = ~0ULL;
+        if (st.done) return best;
+        const int32_t m = st.m, twoP = 2 * st.P;
+        const float cm2 = (float)((double)st.c - 2.0);
+        const int32_t nunits = fnn::screen_unit_count(m);
+        const float finf = (float)fnn::inf_f64();
+        for (int32_t u : thread_order(nunits)) {
+            float umin = finf;
+            if ((u / 4) % d.world == d.rank) {
+                int32_t rt, ct;
+                fnn::tri_tile_decode(u / 4, fnn::SCR_TW / fnn::SCR_TH, rt, ct);
+                const int32_t rb = rt * fnn::SCR_TH, cb = ct * fnn::SCR_TW + (u % 4) * fnn::SCR_UW;
+                for (int32_t r0 = rb; r0 < rb + fnn::SCR_TH && r0 < m; r0 += 2)
+                    for (int32_t c0 = cb; c0 < cb + fnn::SCR_UW && c0 <= r0; c0 += 2) {
+                        const float* R0 = d.F + (int64_t)r0 * d.ld;
+                        const float* R1 = d.F + (int64_t)(r0 + 1) * d.ld;
+                        bool r1 = r0 + 1 < m, c1 = c0 + 1 < m;
+                        fnn::screen_micro(r0, c0, m, twoP, cm2, R0[c0], R0[c0 + 1], R1[c0], R1[c0 + 1],
+                                          (float)d.Sx[r0], r1 ? (float)d.Sx[r0 + 1] : 0.f,
+                                          (float)d.Sx[c0], c1 ? (float)d.Sx[c0 + 1] : 0.f, umin);
+                    }
+            }
+            d.srec[u] = umin;
+        }
+        // k_select
+        float gmin = finf;
+        for (int32_t u = 0; u < nunits; u++) gmin = fnn::fminf_(gmin, d.srec[u]);
+        const float thr = gmin + 2.0f * fnn::screen_delta(st);
+        st.ncand = 0;
+        st.rescan_all = (!st.screen_ok || !(thr == thr) || g_force_rescan_all) ? 1 : 0;
+        if (!st.rescan_all)
+            for (int32_t u : thread_order(nunits))
+                if (d.srec[u] <= thr) {
+                    if (st.ncand >= g_cand_cap) { st.rescan_all = 1; break; }
+                    d.clist[st.ncand++] = u;
+                }
+        st.n_screen_events++;
+        // k_rescan
+        if (st.rescan_all) {
+            for (int32_t u : thread_order(nunits))
+                if ((u / 4) % d.world == d.rank) { rescan_unit(d, u, best); st.n_rescan_units++; }
+        } else {
+            for (int32_t i : thread_order(st.ncand)) { rescan_unit(d, d.clist[i], best); st.n_rescan_units++; }
+        }
+        return best;
+    }
+
     // k_scan over this rank's share of the micro-tiles
     fnn::Cand scan_local(const fnn::Dev& d) {
         fnn::State& st = *d.st;
+        if (d.F && st.m >= screen_min_m) return scan_screened(d);
         fnn::Cand best;
         best.q = fnn::inf_f64();
         best.key = ~0ULL;
@@ -274,6 +364,10 @@ double emu_chain_serial(const double* buf, int32_t m) {
 }
 
 void emu_set_order_mode(int32_t mode) { g_order_mode = mode % 3; g_update_mode = (mode / 3) % 3; }
+void emu_set_screen_debug(int32_t force_rescan_all, int32_t cand_cap) {
+    g_force_rescan_all = force_rescan_all;
+    g_cand_cap = cand_cap > 0 ? cand_cap : fnn::SCR_CAP;
+}
 const char* emu_last_error(void) { return fnn::g_last_error.c_str(); }
 
 int32_t emu_create(int32_t n, const fnn_opts* opts, void** out) {

@@ -78,3 +78,44 @@ def test_exact_rx_path_gives_the_same_trajectory(emu_api, oracle, dist):
     emu_api.set_order_mode(2)
     for n in (9, 33, 90):
         compare_trajectory(emu_api, oracle, oracle.synth(n, 4, dist), deep=True, force_exact_rx=True)
+
+
+def test_fp32_screening_keeps_the_exact_result(emu_api, oracle):
+    """Events first stream the fp32 copy; only units within the error bound of the estimate's
+    minimum are rescanned in fp64.  Trajectories must still match the oracle bit for bit, also
+    when the candidate list overflows (tiny capacity) and for inputs whose fp32 roundings tie
+    (dec4, two-valued) or are negative / large."""
+    import ctypes as C
+    lib = emu_api.lib
+    lib.emu_set_screen_debug.argtypes = [C.c_int32, C.c_int32]
+    try:
+        for cap in (0, 1, 3):
+            lib.emu_set_screen_debug(0, cap)
+            for mode in (0, 5):
+                emu_api.set_order_mode(mode)
+                for n, seed, dist in [(40, 1, "uniform53"), (90, 2, "dec4"), (130, 3, "uniform53")]:
+                    compare_trajectory(emu_api, oracle, oracle.synth(n, seed, dist), deep=True, deep_every=5)
+        lib.emu_set_screen_debug(0, 0)
+        emu_api.set_order_mode(2)
+        rng = np.random.default_rng(3)
+        n = 70
+        A = rng.integers(1, 3, size=(n, n)).astype(np.float64); A = np.triu(A, 1); A = A + A.T
+        compare_trajectory(emu_api, oracle, A, deep=True, deep_every=3)
+        B = oracle.synth(n, 4) * 1e30                      # large magnitudes: bound scales with Dmax
+        compare_trajectory(emu_api, oracle, B, deep=True, deep_every=3)
+        Cm = oracle.synth(n, 5) - 0.5                       # negative "distances"
+        np.fill_diagonal(Cm, 0.0)
+        compare_trajectory(emu_api, oracle, Cm, deep=True, deep_every=3)
+        Dh = oracle.synth(n, 6) * 1e300                     # beyond float range: screening must switch itself off
+        compare_trajectory(emu_api, oracle, Dh, deep=True, deep_every=3)
+        # statistics: screening really ran and rescanned only a fraction of the units
+        with Handle(emu_api, 400) as h:
+            h.set_matrix(oracle.synth(400, 7))
+            order, st = h.run()
+        assert st.n_screen_events > 300 and 0 < st.n_rescan_units
+        with Handle(emu_api, 400, disable_screen=True) as h:
+            h.set_matrix(oracle.synth(400, 7))
+            order2, st2 = h.run()
+        assert st2.n_screen_events == 0 and (order == order2).all()
+    finally:
+        lib.emu_set_screen_debug(0, 0)

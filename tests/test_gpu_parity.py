@@ -140,3 +140,41 @@ def test_full_size_invariants(hip_api):
     e[ev["kind"] == 5] = 0
     assert (ev["entries"] == e).all() and st.sum_entries == e.sum()
     assert n ** 3 / 6 <= st.sum_entries <= n ** 3 / 3
+
+
+def test_fp32_screening_small_sizes(oracle):
+    """Screening forced on for small matrices (separate process: the thresholds are read from
+    the environment when the handle is created)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, os.environ["FNN_ROOT"]); sys.path.insert(0, os.path.join(os.environ["FNN_ROOT"], "tests"))
+import numpy as np
+import fastneighbornet_amd as fa
+from fastneighbornet_amd._capi import Handle
+from oracle import nnet_oracle as O
+from common import compare_trajectory
+a = fa.api()
+for n, seed, dist in [(40, 1, "uniform53"), (300, 2, "dec4"), (1100, 3, "uniform53"), (2100, 4, "uniform53")]:
+    compare_trajectory(a, O, O.synth(n, seed, dist), deep=(n < 1000), deep_every=11)
+rng = np.random.default_rng(3)
+n = 300
+A = rng.integers(1, 3, size=(n, n)).astype(np.float64); A = np.triu(A, 1); A = A + A.T
+compare_trajectory(a, O, A, deep=False)
+compare_trajectory(a, O, O.synth(n, 4) * 1e30, deep=False)
+Cm = O.synth(n, 5) - 0.5; np.fill_diagonal(Cm, 0.0)
+compare_trajectory(a, O, Cm, deep=False)
+compare_trajectory(a, O, O.synth(n, 6) * 1e300, deep=False)
+with Handle(a, 3000) as h:
+    h.synth(7, "uniform53"); order, st = h.run()
+o_ref, _, _ = O.run(O.synth(3000, 7), threads=8)
+assert (order == o_ref).all()
+assert st.n_screen_events > 2000 and st.n_rescan_units > 0
+print("SCREEN_OK", st.n_screen_events, st.n_rescan_units)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FNN_ROOT=root, FNN_SCREEN_MIN_N="8", FNN_SCREEN_MIN_M="8")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SCREEN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

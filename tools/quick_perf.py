@@ -18,4 +18,5 @@ for n in sizes:
               f"scan={st.t_scan_s:.3f}s events={st.n_events} sumE/n^3={st.sum_entries / n**3:.4f} "
               f"scan_GBps={gb / max(st.t_scan_s, 1e-9):.1f} whole_GBps={gb / st.t_total_s:.1f} "
               f"per_event_overhead_us={(st.t_agglom_s - st.t_scan_s) / max(st.n_events, 1) * 1e6:.1f} "
-              f"rx_certified={st.n_rx_certified} rx_exact={st.n_rx_exact}", flush=True)
+              f"rx_certified={st.n_rx_certified} rx_exact={st.n_rx_exact} screen_events={st.n_screen_events} "
+              f"rescan_units_per_event={st.n_rescan_units / max(st.n_screen_events, 1):.1f}", flush=True)
