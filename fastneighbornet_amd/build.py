@@ -44,17 +44,22 @@ def check_isa() -> None:
                              r"s_absdiff|s_wqm|s_quadmask|s_bcnt|s_ff|s_flbit|s_addk)")
         cmp_like = re.compile(r"^\s*(s_cmp|s_bitcmp|s_cmpk|s_and_b64|s_or_b64|s_andn2_b64|s_and_b32|s_or_b32|"
                               r"s_xor_b64|s_orn2_b64)")
-        last, kern, bad = None, None, []
+        # signature of the miscompile: a VALU compare (result in VCC) sits between the last SCC
+        # writer and an SCC consumer, i.e. the select was meant to test that compare.  (An
+        # s_cselect right after s_add_u32 / s_addc_u32 legitimately captures the carry.)
+        last, last_i, vcmp_i, kern, bad = None, 0, -1, None, []
         for i, line in enumerate(open(asm), 1):
             m = re.match(r"^(_Z\w+):", line)
             if m:
-                kern, last = m.group(1), None
+                kern, last, last_i, vcmp_i = m.group(1), None, 0, -1
             t = line.strip()
+            if t.startswith("v_cmp"):
+                vcmp_i = i
             if t.startswith("s_cselect") or t.startswith("s_cbranch_scc"):
-                if last is None or not cmp_like.match(last):
-                    bad.append(f"{kern}:{i}: {t} (SCC from: {last.strip() if last else None})")
+                if (last is None or not cmp_like.match(last)) and vcmp_i > last_i:
+                    bad.append(f"{kern}:{i}: {t} (SCC from: {last.strip() if last else None}; v_cmp at line {vcmp_i})")
             if writers.match(line):
-                last = line
+                last, last_i = line, i
         if bad:
             raise RuntimeError("suspicious SCC use in device ISA (compiler miscompile?):\n" + "\n".join(bad))
 

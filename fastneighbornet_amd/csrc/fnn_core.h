@@ -89,7 +89,7 @@ struct State {
     int32_t screen_ok;     // the bound is valid for this matrix (finite, |D| < 1e37)
     int32_t rescan_all;    // candidate list overflowed: rescan every unit
     int32_t ncand;         // units in clist
-    int32_t pad_scr;
+    int32_t res_ticket;    // arrival counter of k_resolve's workgroups
     uint64_t dmax_bits;    // bit pattern of max |D| over the input matrix
     int64_t n_rescan_units, n_screen_events;  // statistics
     // ---- current event ----

@@ -198,81 +198,128 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
     }
 }
 
-__global__ __launch_bounds__(1024) void k_select(Dev d) {
+// k_resolve: from the per-unit estimates to the exact pair, in one launch.  Every workgroup
+// derives the same candidate list (units whose estimate is within 2 delta of this rank's smallest
+// estimate), the waves of all workgroups share the exact fp64 rescans of those units, and the
+// last workgroup to arrive reduces the per-workgroup results and forms Cx/Cy (single GPU) or this
+// rank's candidate for the all-gather (several GPUs).
+constexpr int RES_BLOCKS = 64;
+constexpr int RES_LIST = 4096;
+
+__global__ __launch_bounds__(1024) void k_resolve(Dev d, int final_pick) {
     __shared__ float shmin[16];
     __shared__ int cnt;
+    __shared__ int list[RES_LIST];
+    __shared__ Cand shc[16];
+    __shared__ int lastflag;
     State* st = d.st;
-    if (st->done) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    Cand best;
+    best.q = inf_f64();
+    best.key = ~0ULL;
+    if (st->done) {  // nothing to scan; keep the control flow of the event alive
+        if (blockIdx.x == 0 && tid == 0) { if (final_pick) pick(d, best); else d.gsend[0] = best; }
+        return;
+    }
     const int m = st->m;
-    const int nunits = screen_unit_count(m);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ntiles = tri_tile_count(m, SCR_TH, SCR_R);
+    const float4* rec4 = reinterpret_cast<const float4*>(d.srec);
+    // 1. this rank's smallest estimate
     float mn = __builtin_inff();
-    for (int u = threadIdx.x; u < nunits; u += 1024)
-        if ((u >> 2) % d.world == d.rank) mn = fminf_(mn, d.srec[u]);
+    for (int t = tid; t < ntiles; t += 1024)
+        if (t % d.world == d.rank) {
+            const float4 v = rec4[t];
+            mn = fminf_(fminf_(mn, fminf_(v.x, v.y)), fminf_(v.z, v.w));
+        }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mn = fminf_(mn, __shfl_down(mn, off, 64));
     if (lane == 0) shmin[w] = mn;
-    if (threadIdx.x == 0) cnt = 0;
+    if (tid == 0) cnt = 0;
     __syncthreads();
     float g = shmin[0];
 #pragma unroll
     for (int k = 1; k < 16; k++) g = fminf_(g, shmin[k]);
-    // this rank's minimum is >= the global one, so its threshold only admits more units
+    // (a rank's minimum is >= the global one, so its threshold only admits more units)
     const float thr = g + 2.0f * screen_delta(*st);
-    const bool all = !st->screen_ok || !(thr == thr);
+    bool all = !st->screen_ok || !(thr == thr);
+    // 2. candidate units
     if (!all) {
-        for (int u = threadIdx.x; u < nunits; u += 1024)
-            if ((u >> 2) % d.world == d.rank && d.srec[u] <= thr) {
-                const int i = atomicAdd(&cnt, 1);
-                if (i < SCR_CAP) d.clist[i] = u;
+        for (int t = tid; t < ntiles; t += 1024)
+            if (t % d.world == d.rank) {
+                const float4 v = rec4[t];
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (e[k] <= thr) {
+                        const int i = atomicAdd(&cnt, 1);
+                        if (i < RES_LIST) list[i] = 4 * t + k;
+                    }
             }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int c = cnt;
-        st->rescan_all = (all || c > SCR_CAP) ? 1 : 0;
-        st->ncand = c > SCR_CAP ? 0 : c;
-        st->n_screen_events += 1;
-        st->n_rescan_units += st->rescan_all ? (int64_t)nunits / d.world : (int64_t)c;
-    }
-}
-
-constexpr int RESCAN_THREADS = 128;
-template <bool NT>
-__global__ __launch_bounds__(RESCAN_THREADS) void k_rescan(Dev d) {
-    __shared__ Cand sh[RESCAN_THREADS / 64];
-    const State* st = d.st;
-    Cand best;
-    best.q = inf_f64();
-    best.key = ~0ULL;
-    if (!st->done) {
-        const int m = st->m;
+    const int count = cnt;
+    if (count > RES_LIST) all = true;
+    // 3. exact rescans, one unit per wave at a time
+    {
         const int twoP = 2 * st->P;
         const double cm2 = (double)st->c - 2.0;
-        const bool all = st->rescan_all != 0;
-        const int count = all ? screen_unit_count(m) : st->ncand;
-        for (int i = blockIdx.x; i < count; i += gridDim.x) {
-            const int u = all ? i : d.clist[i];
+        const int gw = blockIdx.x * 16 + w, nw = gridDim.x * 16;
+        const int total = all ? 4 * ntiles : count;
+        for (int i = gw; i < total; i += nw) {
+            const int u = all ? i : list[i];
             if (all && (u >> 2) % d.world != d.rank) continue;
             int rt, ct;
             tri_tile_decode(u >> 2, SCR_R, rt, ct);
-            scan_rows_exact<NT>(d, rt * SCR_TH, ct * SCR_TW + (u & 3) * SCR_UW + 2 * (int)threadIdx.x, m, twoP, cm2, best);
+            const int cb = ct * SCR_TW + (u & 3) * SCR_UW;
+            scan_rows_exact<false>(d, rt * SCR_TH, cb + 2 * lane, m, twoP, cm2, best);
+            scan_rows_exact<false>(d, rt * SCR_TH, cb + 128 + 2 * lane, m, twoP, cm2, best);
         }
     }
-    best = block_reduce<RESCAN_THREADS / 64>(best, sh);
-    if (threadIdx.x == 0) d.recs[blockIdx.x] = best;
+    best = block_reduce<16>(best, shc);
+    // 4. arrival; the last workgroup finishes the job
+    if (tid == 0) {
+        __hip_atomic_store(&d.recs[blockIdx.x].q, best.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&d.recs[blockIdx.x].key, best.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const int ticket = __hip_atomic_fetch_add(&st->res_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        lastflag = (ticket == (int)gridDim.x - 1) ? 1 : 0;
+        if (lastflag) __threadfence();
+    }
+    __syncthreads();
+    if (!lastflag) return;
+    Cand c;
+    c.q = inf_f64();
+    c.key = ~0ULL;
+    if (tid < (int)gridDim.x) {
+        c.q = __hip_atomic_load(&d.recs[tid].q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.key = __hip_atomic_load(&d.recs[tid].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();  // shc is reused
+    c = block_reduce<16>(c, shc);
+    if (tid == 0) {
+        st->res_ticket = 0;
+        st->rescan_all = all ? 1 : 0;
+        st->ncand = all ? 0 : count;
+        st->n_screen_events += 1;
+        st->n_rescan_units += all ? (int64_t)(4 * ntiles) / d.world : (int64_t)count;
+        if (final_pick) pick(d, c);
+        else d.gsend[0] = c;
+    }
 }
 
 // D -> F for the whole padded matrix, and max |D| over the n x n input
 __global__ __launch_bounds__(256) void k_prep_screen(Dev d, int64_t nrows) {
     __shared__ unsigned long long shmax[4];
-    const int64_t r = blockIdx.y;
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long b = 0;
-    if (c < d.ld && r < nrows) {
-        const double v = d.D[r * d.ld + c];
-        d.F[r * d.ld + c] = (float)v;
-        if (r < d.n && c < d.n) b = f2u(v) & 0x7FFFFFFFFFFFFFFFULL;
+    const int64_t total = nrows * d.ld;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const double v = d.D[i];
+        d.F[i] = (float)v;
+        const int64_t r = i / d.ld, c = i - r * d.ld;
+        if (r < d.n && c < d.n) {
+            const unsigned long long x = f2u(v) & 0x7FFFFFFFFFFFFFFFULL;
+            b = x > b ? x : b;
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -864,8 +911,7 @@ struct HipBackend {
         return FNN_OK;
     }
     int32_t launch_prep_screen(const Dev& d, int64_t nrows) {
-        dim3 g((unsigned)((d.ld + 255) / 256), (unsigned)nrows);
-        hipLaunchKernelGGL(k_prep_screen, g, dim3(256), 0, stream, d, nrows);
+        hipLaunchKernelGGL(k_prep_screen, dim3(8192), dim3(256), 0, stream, d, nrows);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
     int32_t launch_init(const Dev& d) {
@@ -879,8 +925,10 @@ struct HipBackend {
         return dim3((unsigned)(nt < scan_grid ? (nt > 0 ? nt : 1) : scan_grid));
     }
     bool use_screen(const Dev& d, int32_t m_bound) const { return d.F != nullptr && m_bound >= screen_min_m; }
-    // the scan of one event; returns the number of records left in d.recs
-    int enqueue_scan(const Dev& d, int32_t m_bound) {
+    // the scan of one event.  Returns the number of records left in d.recs for k_pick /
+    // k_reduce_local, or 0 when the screening path has already produced Cx/Cy (final_pick) or the
+    // rank's candidate.
+    int enqueue_scan(const Dev& d, int32_t m_bound, int final_pick) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timing) { e0 = next_event(); e1 = next_event(); }
         int nrecs;
@@ -891,9 +939,8 @@ struct HipBackend {
             if (scan_nt) hipLaunchKernelGGL(k_screen<true>, gs, dim3(256), 0, stream, d);
             else hipLaunchKernelGGL(k_screen<false>, gs, dim3(256), 0, stream, d);
             if (e1) (void)hipEventRecord(e1, stream);
-            hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), 0, stream, d);
-            nrecs = 2048;
-            hipLaunchKernelGGL(k_rescan<false>, dim3(nrecs), dim3(RESCAN_THREADS), 0, stream, d);
+            hipLaunchKernelGGL(k_resolve, dim3(RES_BLOCKS), dim3(1024), 0, stream, d, final_pick);
+            nrecs = 0;
         } else {
             dim3 gs = scan_dims(d, m_bound);
             if (e0) (void)hipEventRecord(e0, stream);
@@ -915,16 +962,16 @@ struct HipBackend {
     // single GPU: the whole event
     int32_t launch_event(const Dev& d, int32_t m_bound) {
         if (m_bound < 1) m_bound = 1;
-        int nrecs = enqueue_scan(d, m_bound);
-        hipLaunchKernelGGL(k_pick, dim3(1), dim3(1024), 0, stream, d, (const Cand*)d.recs, nrecs);
+        int nrecs = enqueue_scan(d, m_bound, 1);
+        if (nrecs > 0) hipLaunchKernelGGL(k_pick, dim3(1), dim3(1024), 0, stream, d, (const Cand*)d.recs, nrecs);
         enqueue_rest(d, m_bound);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
     // several GPUs: scan of this rank's tiles + local reduction ... (all-gather) ... the rest
     int32_t launch_event_scan(const Dev& d, int32_t m_bound) {
         if (m_bound < 1) m_bound = 1;
-        int nrecs = enqueue_scan(d, m_bound);
-        hipLaunchKernelGGL(k_reduce_local, dim3(1), dim3(1024), 0, stream, d, nrecs);
+        int nrecs = enqueue_scan(d, m_bound, 0);
+        if (nrecs > 0) hipLaunchKernelGGL(k_reduce_local, dim3(1), dim3(1024), 0, stream, d, nrecs);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
     int32_t launch_event_rest(const Dev& d, int32_t m_bound) {
