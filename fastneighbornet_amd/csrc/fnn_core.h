@@ -124,7 +124,8 @@ struct Dev {
     Cand* recs;      // per-block scan records
     double* rxpart;  // per-block partial sums of k_rx_fill: [block][8] = 4 sums + 4 sums of |terms|
     float* F;        // fp32 screening copy of D (same geometry, F[r][c] == (float)D[r][c])
-    float* srec;     // screening: per-unit minimum of the fp32 Q estimate
+    float* srec;     // screening: per-unit minimum of the fp32 Q estimate ([tile][4])
+    float* stile;    // screening: per-tile minimum (min over the tile's 4 units)
     int32_t* clist;  // screening: units that may hold the true minimum
     Cand* gsend;     // multi-GPU: this rank's best candidate of the event (1 record)
     Cand* grecv;     // multi-GPU: all ranks' candidates (world records)

@@ -81,6 +81,7 @@ class Engine {
             !(dev.recs = (Cand*)be.alloc(sizeof(Cand) * be.max_records(n))) ||
             !(dev.rxpart = (double*)be.alloc(sizeof(double) * 8 * (nn / 256 + 2))) ||
             !(dev.srec = (float*)be.alloc(sizeof(float) * ((size_t)screen_unit_count(n > 0 ? n : 1) + 8))) ||
+            !(dev.stile = (float*)be.alloc(sizeof(float) * ((size_t)screen_unit_count(n > 0 ? n : 1) / 4 + 8))) ||
             !(dev.clist = (int32_t*)be.alloc(sizeof(int32_t) * SCR_CAP)) ||
             !(dev.gsend = (Cand*)be.alloc(sizeof(Cand) * 64)) ||
             !(dev.grecv = (Cand*)be.alloc(sizeof(Cand) * 64)) ||
@@ -101,7 +102,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.recs); be.free(dev.rxpart); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.F); be.free(dev.srec); be.free(dev.clist); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.recs); be.free(dev.rxpart); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.F); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }

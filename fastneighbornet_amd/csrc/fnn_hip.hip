@@ -153,6 +153,7 @@ constexpr int SCR_R = SCR_TW / SCR_TH;
 
 template <bool NT>
 __global__ __launch_bounds__(256) void k_screen(Dev d) {
+    __shared__ float shw[4];
     const State* st = d.st;
     if (st->done) return;
     const int m = st->m;
@@ -194,7 +195,10 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) best = fminf_(best, __shfl_down(best, off, 64));
-        if (lane == 0) d.srec[4 * t + w] = best;
+        if (lane == 0) { d.srec[4 * t + w] = best; shw[w] = best; }
+        __syncthreads();
+        if (threadIdx.x == 0) d.stile[t] = fminf_(fminf_(shw[0], shw[1]), fminf_(shw[2], shw[3]));
+        __syncthreads();
     }
 }
 
@@ -205,6 +209,33 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
 // rank's candidate for the all-gather (several GPUs).
 constexpr int RES_BLOCKS = 64;
 constexpr int RES_LIST = 4096;
+
+// exact scan of one 32 x 256 unit by a whole 1024-thread workgroup: every thread owns one column
+// pair and two of the 16 row pairs, so all loads of the unit are issued at once
+__device__ __forceinline__ void scan_unit_block(const Dev& d, int rbase, int cb, int m, int twoP, double cm2, Cand& best) {
+    const int c0 = cb + 2 * ((int)threadIdx.x & 127);
+    const int rg = (int)threadIdx.x >> 7;  // 0..7
+    if (!(c0 < m && c0 <= rbase + SCR_TH - 2)) return;
+    const double* colbase = d.D + c0;
+    const int ra = rbase + 2 * rg, rb = ra + 16;
+    double2 a0 = make_double2(0.0, 0.0), b0 = a0, a1 = a0, b1 = a0;
+    const bool va = ra < m && c0 <= ra, vb = rb < m && c0 <= rb;
+    if (va) { a0 = *reinterpret_cast<const double2*>(colbase + (int64_t)ra * d.ld); b0 = *reinterpret_cast<const double2*>(colbase + (int64_t)(ra + 1) * d.ld); }
+    if (vb) { a1 = *reinterpret_cast<const double2*>(colbase + (int64_t)rb * d.ld); b1 = *reinterpret_cast<const double2*>(colbase + (int64_t)(rb + 1) * d.ld); }
+    if (!va && !vb) return;
+    const double2 sxc = *reinterpret_cast<const double2*>(d.Sx + c0);
+    const int2 pc = *reinterpret_cast<const int2*>(d.spos + c0);
+    if (va) {
+        const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + ra);
+        const int2 pr = *reinterpret_cast<const int2*>(d.spos + ra);
+        scan_micro(ra, c0, m, twoP, cm2, a0.x, a0.y, b0.x, b0.y, sxr.x, sxr.y, pr.x, pr.y, sxc.x, sxc.y, pc.x, pc.y, best);
+    }
+    if (vb) {
+        const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + rb);
+        const int2 pr = *reinterpret_cast<const int2*>(d.spos + rb);
+        scan_micro(rb, c0, m, twoP, cm2, a1.x, a1.y, b1.x, b1.y, sxr.x, sxr.y, pr.x, pr.y, sxc.x, sxc.y, pc.x, pc.y, best);
+    }
+}
 
 __global__ __launch_bounds__(1024) void k_resolve(Dev d, int final_pick) {
     __shared__ float shmin[16];
@@ -224,13 +255,20 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d, int final_pick) {
     const int m = st->m;
     const int ntiles = tri_tile_count(m, SCR_TH, SCR_R);
     const float4* rec4 = reinterpret_cast<const float4*>(d.srec);
-    // 1. this rank's smallest estimate
-    float mn = __builtin_inff();
-    for (int t = tid; t < ntiles; t += 1024)
-        if (t % d.world == d.rank) {
-            const float4 v = rec4[t];
-            mn = fminf_(fminf_(mn, fminf_(v.x, v.y)), fminf_(v.z, v.w));
-        }
+    const float finf = __builtin_inff();
+    // 1. this rank's smallest estimate, from the per-tile minima (kept in registers for step 2)
+    constexpr int RJ = 20;  // 20 * 1024 tiles cover n <= 35000 in one sweep; larger n re-read
+    float v[RJ];
+    float mn = finf;
+#pragma unroll
+    for (int j = 0; j < RJ; j++) {
+        const int t = tid + 1024 * j;
+        v[j] = (t < ntiles && t % d.world == d.rank) ? d.stile[t] : finf;
+    }
+#pragma unroll
+    for (int j = 0; j < RJ; j++) mn = fminf_(mn, v[j]);
+    for (int t = tid + 1024 * RJ; t < ntiles; t += 1024)
+        if (t % d.world == d.rank) mn = fminf_(mn, d.stile[t]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mn = fminf_(mn, __shfl_down(mn, off, 64));
     if (lane == 0) shmin[w] = mn;
@@ -242,60 +280,64 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d, int final_pick) {
     // (a rank's minimum is >= the global one, so its threshold only admits more units)
     const float thr = g + 2.0f * screen_delta(*st);
     bool all = !st->screen_ok || !(thr == thr);
-    // 2. candidate units
+    // 2. candidate units: the units of the few tiles whose minimum passes
     if (!all) {
-        for (int t = tid; t < ntiles; t += 1024)
-            if (t % d.world == d.rank) {
-                const float4 v = rec4[t];
-                const float e[4] = {v.x, v.y, v.z, v.w};
+        auto take_tile = [&](int t) {
+            const float4 x = rec4[t];
+            if (x.x <= thr) { const int i = atomicAdd(&cnt, 1); if (i < RES_LIST) list[i] = 4 * t; }
+            if (x.y <= thr) { const int i = atomicAdd(&cnt, 1); if (i < RES_LIST) list[i] = 4 * t + 1; }
+            if (x.z <= thr) { const int i = atomicAdd(&cnt, 1); if (i < RES_LIST) list[i] = 4 * t + 2; }
+            if (x.w <= thr) { const int i = atomicAdd(&cnt, 1); if (i < RES_LIST) list[i] = 4 * t + 3; }
+        };
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (e[k] <= thr) {
-                        const int i = atomicAdd(&cnt, 1);
-                        if (i < RES_LIST) list[i] = 4 * t + k;
-                    }
-            }
+        for (int j = 0; j < RJ; j++)
+            if (v[j] <= thr) take_tile(tid + 1024 * j);
+        for (int t = tid + 1024 * RJ; t < ntiles; t += 1024)
+            if (t % d.world == d.rank && d.stile[t] <= thr) take_tile(t);
     }
     __syncthreads();
     const int count = cnt;
     if (count > RES_LIST) all = true;
-    // 3. exact rescans, one unit per wave at a time
+    const int total = all ? 4 * ntiles : count;
+    // few candidates (the usual case): workgroup 0 finishes alone, no cross-workgroup hand-off
+    const bool solo = !all && count <= 16;
+    if (solo && blockIdx.x != 0) return;
+    // 3. exact rescans, one unit per workgroup at a time
     {
         const int twoP = 2 * st->P;
         const double cm2 = (double)st->c - 2.0;
-        const int gw = blockIdx.x * 16 + w, nw = gridDim.x * 16;
-        const int total = all ? 4 * ntiles : count;
-        for (int i = gw; i < total; i += nw) {
+        const int first = solo ? 0 : (int)blockIdx.x, step = solo ? 1 : (int)gridDim.x;
+        for (int i = first; i < total; i += step) {
             const int u = all ? i : list[i];
             if (all && (u >> 2) % d.world != d.rank) continue;
             int rt, ct;
             tri_tile_decode(u >> 2, SCR_R, rt, ct);
-            const int cb = ct * SCR_TW + (u & 3) * SCR_UW;
-            scan_rows_exact<false>(d, rt * SCR_TH, cb + 2 * lane, m, twoP, cm2, best);
-            scan_rows_exact<false>(d, rt * SCR_TH, cb + 128 + 2 * lane, m, twoP, cm2, best);
+            scan_unit_block(d, rt * SCR_TH, ct * SCR_TW + (u & 3) * SCR_UW, m, twoP, cm2, best);
         }
     }
     best = block_reduce<16>(best, shc);
-    // 4. arrival; the last workgroup finishes the job
-    if (tid == 0) {
-        __hip_atomic_store(&d.recs[blockIdx.x].q, best.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&d.recs[blockIdx.x].key, best.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        const int ticket = __hip_atomic_fetch_add(&st->res_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        lastflag = (ticket == (int)gridDim.x - 1) ? 1 : 0;
-        if (lastflag) __threadfence();
+    Cand c = best;  // valid in thread 0
+    if (!solo) {
+        // 4. arrival; the last workgroup reduces the per-workgroup results
+        if (tid == 0) {
+            __hip_atomic_store(&d.recs[blockIdx.x].q, best.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&d.recs[blockIdx.x].key, best.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            const int ticket = __hip_atomic_fetch_add(&st->res_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            lastflag = (ticket == (int)gridDim.x - 1) ? 1 : 0;
+            if (lastflag) __threadfence();
+        }
+        __syncthreads();
+        if (!lastflag) return;
+        c.q = inf_f64();
+        c.key = ~0ULL;
+        if (tid < (int)gridDim.x) {
+            c.q = __hip_atomic_load(&d.recs[tid].q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c.key = __hip_atomic_load(&d.recs[tid].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();  // shc is reused
+        c = block_reduce<16>(c, shc);
     }
-    __syncthreads();
-    if (!lastflag) return;
-    Cand c;
-    c.q = inf_f64();
-    c.key = ~0ULL;
-    if (tid < (int)gridDim.x) {
-        c.q = __hip_atomic_load(&d.recs[tid].q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c.key = __hip_atomic_load(&d.recs[tid].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();  // shc is reused
-    c = block_reduce<16>(c, shc);
     if (tid == 0) {
         st->res_ticket = 0;
         st->rescan_all = all ? 1 : 0;
