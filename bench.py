@@ -155,12 +155,13 @@ def main():
     if rank == 0:
         order, st = last
         sec = elapsed / args.steps
-        scan_bytes = float(st.scan_bytes)
+        scan_bytes = float(st.scan_bytes)            # bytes at the element size actually streamed (4 or 8 B / entry)
+        fp64_equiv = 8.0 * float(st.sum_entries)     # BASELINE.md's 8 * sum E_t, for reference
         assert sorted(order[1:].tolist()) == list(range(1, n + 1)) and order[0] == 0 and order[1] == 1
         share = args.gpus if sharded else 1  # this rank's launches cover 1/share of the entries
         scan_gbps = scan_bytes / share / max(st.t_scan_s, 1e-12) / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_scan_summary_n32768.json")
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_screen_summary_n32768.json")
         if n == 32768 and args.gpus == 1 and os.path.exists(pmc):
             traffic = round(json.load(open(pmc))["hbm_bytes_per_launch_avg"], 1)
         out = {
@@ -184,6 +185,10 @@ def main():
                 "events": int(st.n_events),
                 "sum_entries": int(st.sum_entries),
                 "algorithmic_bytes": int(scan_bytes),
+                "algorithmic_bytes_note": ("E_t entries per event at 4 B when the event's scan is the fp32 screening pass "
+                                           "(m >= 8192) or 8 B for the plain fp64 scan, plus the fp64 rescans of the "
+                                           "candidate units; 8 * sum E_t would be %d" % int(fp64_equiv)),
+                "screening": {"events": int(st.n_screen_events), "rescanned_units_32x256": int(st.n_rescan_units)},
             },
             "hbm_gbps_whole_run": round(scan_bytes / sec / 1e9, 1),
             "hbm_frac_whole_run": round(scan_bytes / sec / 1e9 / (HBM_PEAK_GBPS * max(args.gpus, 1)), 4),
@@ -191,7 +196,7 @@ def main():
             "phases_s": {"init": round(st.t_init_s, 4), "agglomerate": round(st.t_agglom_s, 4),
                          "expand": round(st.t_expand_s, 4), "scan_kernel_sum": round(st.t_scan_s, 4)},
             "roofline": {
-                "kernel": "fnn::k_scan",
+                "kernel": "fnn::k_screen (fp32 pass, 98.9 % of the streamed bytes; fnn::k_scan fp64 for m < 8192)",
                 "bound": "hbm",
                 "achieved": round(scan_gbps, 1),
                 "peak": HBM_PEAK_GBPS,
@@ -199,7 +204,7 @@ def main():
                 "frac": round(scan_gbps / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
                 "traffic_note": ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                 "workload (FETCH_SIZE x2 per the gfx950 correction), profiles/r01/pmc_scan_summary_n32768.json"
+                                 "workload (FETCH_SIZE x2 per the gfx950 correction), profiles/r01/pmc_screen_summary_n32768.json"
                                  if traffic else None),
                 "launches": int(st.scan_launches),
                 "avg_launch_us": round(st.t_scan_s / max(st.scan_launches, 1) * 1e6, 2),

@@ -92,6 +92,8 @@ struct State {
     int32_t res_ticket;    // arrival counter of k_resolve's workgroups
     uint64_t dmax_bits;    // bit pattern of max |D| over the input matrix
     int64_t n_rescan_units, n_screen_events;  // statistics
+    int64_t bytes_streamed;  // matrix bytes the scans had to stream: 4 (fp32 pass) or 8 per entry + rescans
+    int32_t ev_screened, pad_scr2;
     // ---- current event ----
     int32_t ev_active, ev_finish, need_rx;
     int32_t sa, sap, sb, sbp;  // slots of Cx, Cx.nbr, Cy, Cy.nbr (-1: none)
@@ -446,6 +448,9 @@ FNN_HD void pick(const Dev& d, Cand best) {
     if (st.m == 4 && st.c == 2) { finish_plan(d); return; }
     cur.entries = (int64_t)st.m * (st.m - 1) / 2 - (st.m - st.c);
     cur.best = best.q;
+    st.bytes_streamed += (st.ev_screened ? 4 : 8) * cur.entries +
+                         (st.ev_screened ? (int64_t)(st.rescan_all ? 0 : st.ncand) * SCR_TH * SCR_UW * 8 : 0);
+    st.ev_screened = 0;
     int32_t i = (int32_t)(best.key >> 32), j = (int32_t)(best.key & 0xFFFFFFFFu);
     int32_t a = d.pslot[i], b = d.pslot[j];  // Cx = p, Cy = q
     if (d.sid[a] > d.sid[b]) { int32_t t = a; a = b; b = t; }

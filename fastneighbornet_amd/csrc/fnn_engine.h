@@ -286,7 +286,7 @@ class Engine {
         stats.t_expand_s = now_s() - t0;
         stats.n_events = hst.n_events;
         stats.sum_entries = hst.sum_entries;
-        stats.scan_bytes = 8 * hst.sum_entries;
+        stats.scan_bytes = hst.bytes_streamed;
         stats.n_rx_certified = hst.n_rx_certified;
         stats.n_rx_exact = hst.n_rx_exact;
         stats.n_screen_events = hst.n_screen_events;

@@ -344,6 +344,7 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d, int final_pick) {
         st->ncand = all ? 0 : count;
         st->n_screen_events += 1;
         st->n_rescan_units += all ? (int64_t)(4 * ntiles) / d.world : (int64_t)count;
+        st->ev_screened = 1;
         if (final_pick) pick(d, c);
         else d.gsend[0] = c;
     }

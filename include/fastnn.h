@@ -83,7 +83,8 @@ typedef struct fnn_stats {
     double  t_total_s;       /* matrix resident on device -> order on host */
     double  t_scan_s;        /* sum of scan-kernel durations (HIP events), 0 unless timing enabled */
     int64_t scan_launches;   /* number of scan-kernel launches */
-    int64_t scan_bytes;      /* algorithmic bytes of those launches (8 * sum E_t) */
+    int64_t scan_bytes;      /* matrix bytes those launches had to stream: per event E_t entries at 4 B
+                                (fp32 screening pass) or 8 B (plain fp64 scan), plus the fp64 rescans */
     int64_t n_rx_certified;  /* events whose 4-candidate choice was certified from tree sums */
     int64_t n_rx_exact;      /* events that needed the exact sequential ComputeRx sums */
     int64_t n_screen_events; /* events whose scan went through the fp32 screening pass */

@@ -171,6 +171,7 @@ struct EmuBackend {
                     d.clist[st.ncand++] = u;
                 }
         st.n_screen_events++;
+        st.ev_screened = 1;
         // k_rescan
         if (st.rescan_all) {
             for (int32_t u : thread_order(nunits))

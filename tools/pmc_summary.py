@@ -14,7 +14,7 @@ def load(path, name):
     vals = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            if r["Counter_Name"] == name and "k_scan" in r["Kernel_Name"]:
+            if r["Counter_Name"] == name and ("k_scan" in r["Kernel_Name"] or "k_screen" in r["Kernel_Name"]):
                 vals.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     vals.sort()
     return [v for _, v in vals]
@@ -28,7 +28,7 @@ def main():
     fetch_b = sum(fetch) * 1024.0 * 2.0
     write_b = sum(write) * 1024.0
     res = {
-        "kernel": "fnn::k_scan<true>",
+        "kernel": "fnn::k_screen<true> (+ fnn::k_scan<true> for m < 8192)",
         "launches": n,
         "FETCH_SIZE_KiB_sum_raw": sum(fetch),
         "WRITE_SIZE_KiB_sum_raw": sum(write),
