@@ -92,7 +92,7 @@ struct State {
     int32_t res_ticket;    // arrival counter of k_resolve's workgroups
     uint64_t dmax_bits;    // bit pattern of max |D| over the input matrix
     int64_t n_rescan_units, n_screen_events;  // statistics
-    int64_t bytes_streamed;  // matrix bytes the scans had to stream: 4 (fp32 pass) or 8 per entry + rescans
+    int64_t bytes_streamed;  // matrix bytes the scans had to stream: 2 (bf16 pass) or 8 per entry + rescans
     int32_t ev_screened, pad_scr2;
     // ---- current event ----
     int32_t ev_active, ev_finish, need_rx;
@@ -125,9 +125,9 @@ struct Dev {
     int64_t cstride; // n rounded up to a whole super-chunk
     Cand* recs;      // per-block scan records
     double* rxpart;  // per-block partial sums of k_rx_fill: [block][8] = 4 sums + 4 sums of |terms|
-    float* F;        // fp32 screening copy of D (same geometry, F[r][c] == (float)D[r][c])
-    float* srec;     // screening: per-unit minimum of the fp32 Q estimate ([tile][4])
-    float* stile;    // screening: per-tile minimum (min over the tile's 4 units)
+    uint16_t* H;     // bf16 screening copy of D (same geometry, H[r][c] == bf16(D[r][c]))
+    float* srec;     // screening: per unit [tile][4] lower bounds, then [tile][4] upper bounds
+    float* stile;    // screening: per tile lower bound, then per tile upper bound
     int32_t* clist;  // screening: units that may hold the true minimum
     Cand* gsend;     // multi-GPU: this rank's best candidate of the event (1 record)
     Cand* grecv;     // multi-GPU: all ranks' candidates (world records)
@@ -222,58 +222,86 @@ FNN_HD void scan_micro(int32_t r0, int32_t c0, int32_t m, int32_t twoP, double c
 }
 
 // ---------------------------------------------------------------------------
-// fp32 screening of the scan.  A float copy F of the matrix is streamed
-// (4 B per entry instead of 8) and Q is estimated in fp32:  Qh = (cm2 * mean(F entries) - Sp) - Sq
-// with Sx rounded to float.  Error budget, u = 2^-24, Dmax = max |D| of the INPUT matrix (entries
-// only ever become convex combinations of earlier entries, so it bounds every later entry),
-// |Sx| <= n * Dmax (a sum of <= n cluster distances), M = (c-2) Dmax + 2 n Dmax >= any
-// intermediate magnitude:
-//   entry rounding + <=3 adds of the mean     4 u Dmax, amplified by (c-2)
-//   the product                               u (c-2) Dmax
-//   rounding Sp, Sq to float                  2 u n Dmax
-//   the two subtractions                      2 u M
-//   total  <=  u Dmax (7 (c-2) + 6 n);   the exact fp64 value's own roundings are ~2^-29 of that.
-// screen_delta returns twice this.  If Qh_min is the smallest estimate, the pair with the true
-// minimum has Qh <= Qh_min + 2 delta, and every pair with Qh > Qh_min + 2 delta has a true Q
-// STRICTLY above the true minimum - so rescanning (in fp64, with the exact tie-break) only the
-// units whose estimate-minimum is <= Qh_min + 2 delta gives the same pair as the full scan.
+// Screening of the scan with a 2-byte copy (the fp64 master decides, a narrow copy
+// may screen).  H holds every matrix entry rounded to bf16 (8 significant bits); the screening
+// pass streams H (2 B per entry instead of 8) and brackets every cluster pair's Q:
+//     Qh = fma(cm2, mean(h), -Sp~) - Sq~          (fp32; Sx rounded to float)
+//     e  = cm2k * mean(|h|)                       (cm2k >= (c-2) * kappa)
+//     LB = Qh - e - dlt <= Q <= Qh + e + dlt = UB
+// kappa bounds the RELATIVE entry error |d - h| <= kappa |h| of double -> float -> bf16 (round to
+// nearest twice: (2^-8 + 1.01 * 2^-24) / (1 - 2^-8 - 1.01 * 2^-24) < 0.003945), so pairs with small
+// distances - the ones that can win - get tight brackets.  dlt (screen_delta) is the global slack
+// for everything done in fp32: with u = 2^-24, Dmax = max |D| of the INPUT matrix (later entries
+// are convex combinations of earlier ones), |Sx| <= n Dmax, M = (c-2) Dmax + 2 n Dmax:
+//   <=3 adds of the mean, amplified by (c-2)    3 u (c-2) Dmax
+//   the product / fma                            u (c-2) Dmax
+//   rounding Sp, Sq to float                     2 u n Dmax
+//   the subtractions                             2 u M
+//   the same again for e, plus subnormal slack   (generously) the same
+//   total <= u Dmax (7 (c-2) + 6 n), doubled by screen_delta.
+// Per unit the pass records min LB and min UB.  Let UBg be the smallest UB (of this rank).  The
+// pair with the true minimum has LB <= Q* <= UBg, and every pair with LB > UBg has a true Q
+// STRICTLY above the true minimum, so rescanning (fp64, exact tie-break) only the units whose
+// min LB <= UBg finds the same pair as the full scan.
 // ---------------------------------------------------------------------------
 constexpr int SCR_TH = 32;    // rows per screening tile
-constexpr int SCR_TW = 1024;  // columns per screening tile (256 threads x 4)
-constexpr int SCR_UW = 256;   // columns per unit (one wave of a tile)
-constexpr int SCR_CAP = 16384;  // capacity of the candidate-unit list
+constexpr int SCR_TW = 2048;  // columns per screening tile (256 threads x 8)
+constexpr int SCR_UW = 512;   // columns per unit (one wave of a tile)
+constexpr int SCR_CAP = 16384;  // capacity of the candidate-unit list (emulation)
+constexpr float SCR_KAPPA = 0.003945f;
+
+FNN_HD uint16_t bf16_from_double(double v) {
+    const float f = (float)v;
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)((u >> 16) | ((u & 0xFFFFu) ? 0x40u : 0u));  // inf / NaN
+    u += 0x7FFFu + ((u >> 16) & 1u);  // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+FNN_HD float bf16_to_float(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
 
 FNN_HD float screen_delta(const State& st) {
     const double dmax = __builtin_bit_cast(double, st.dmax_bits);
     const double u = 5.9604644775390625e-08;  // 2^-24
-    const double dlt = 2.0 * u * dmax * (7.0 * ((double)st.c - 2.0) + 6.0 * (double)st.n);
+    const double dlt = 2.0 * u * dmax * (7.0 * ((double)st.c - 2.0) + 6.0 * (double)st.n) + 1e-30;
     return (float)(dlt * 1.0000002);  // round up when narrowing to float
 }
+// (c - 2) * kappa, rounded up
+FNN_HD float screen_cm2k(const State& st) { return (float)(((double)st.c - 2.0) * (double)SCR_KAPPA * 1.000001); }
 
 FNN_HD float fminf_(float a, float b) { return a < b ? a : b; }
+FNN_HD float fabsf_(float a) { return a < 0.0f ? -a : a; }
 
-// one 2x2 block of the screening pass: same case analysis as scan_micro, fp32, minimum only
-FNN_HD void screen_micro(int32_t r0, int32_t c0, int32_t m, int32_t twoP, float cm2,
+struct Brk { float lb, ub; };  // running minima of the lower / upper bounds
+
+FNN_HD void brk_take(float dmean, float amean, float cm2, float cm2k, float sp, float sq, Brk& b) {
+    const float q = __builtin_fmaf(cm2, dmean, -sp) - sq;
+    const float e = cm2k * amean;
+    b.lb = fminf_(b.lb, q - e);
+    b.ub = fminf_(b.ub, q + e);
+}
+
+// one 2x2 block of the screening pass: same case analysis as scan_micro, on bf16-decoded floats
+FNN_HD void screen_micro(int32_t r0, int32_t c0, int32_t m, int32_t twoP, float cm2, float cm2k,
                          float e00, float e01, float e10, float e11,
-                         float sxr0, float sxr1, float sxc0, float sxc1, float& best) {
+                         float sxr0, float sxr1, float sxc0, float sxc1, Brk& b) {
     if (r0 >= m || c0 >= m || c0 > r0) return;
     if (r0 < twoP) {
         if (r0 == c0) return;
-        const float dpq = (((e00 + e01) + e10) + e11) * 0.25f;
-        best = fminf_(best, (cm2 * dpq - sxr0) - sxc0);
+        brk_take((((e00 + e01) + e10) + e11) * 0.25f,
+                 (((fabsf_(e00) + fabsf_(e01)) + fabsf_(e10)) + fabsf_(e11)) * 0.25f, cm2, cm2k, sxr0, sxc0, b);
     } else if (c0 < twoP) {
-        best = fminf_(best, (cm2 * ((e00 + e01) * 0.5f) - sxr0) - sxc0);
-        if (r0 + 1 < m) best = fminf_(best, (cm2 * ((e10 + e11) * 0.5f) - sxr1) - sxc0);
+        brk_take((e00 + e01) * 0.5f, (fabsf_(e00) + fabsf_(e01)) * 0.5f, cm2, cm2k, sxr0, sxc0, b);
+        if (r0 + 1 < m) brk_take((e10 + e11) * 0.5f, (fabsf_(e10) + fabsf_(e11)) * 0.5f, cm2, cm2k, sxr1, sxc0, b);
     } else {
         const bool c1ok = (c0 + 1 < m), r1ok = (r0 + 1 < m);
         if (r0 > c0) {
-            best = fminf_(best, (cm2 * e00 - sxr0) - sxc0);
-            if (c1ok) best = fminf_(best, (cm2 * e01 - sxr0) - sxc1);
+            brk_take(e00, fabsf_(e00), cm2, cm2k, sxr0, sxc0, b);
+            if (c1ok) brk_take(e01, fabsf_(e01), cm2, cm2k, sxr0, sxc1, b);
             if (r1ok) {
-                best = fminf_(best, (cm2 * e10 - sxr1) - sxc0);
-                if (c1ok) best = fminf_(best, (cm2 * e11 - sxr1) - sxc1);
+                brk_take(e10, fabsf_(e10), cm2, cm2k, sxr1, sxc0, b);
+                if (c1ok) brk_take(e11, fabsf_(e11), cm2, cm2k, sxr1, sxc1, b);
             }
-        } else if (r1ok) best = fminf_(best, (cm2 * e10 - sxr1) - sxc0);
+        } else if (r1ok) brk_take(e10, fabsf_(e10), cm2, cm2k, sxr1, sxc0, b);
     }
 }
 
@@ -297,10 +325,10 @@ FNN_HD void tri_tile_decode(int32_t t, int32_t R, int32_t& rt, int32_t& ct) {
 // number of screening units for m live slots: 4 per screening tile
 FNN_HD int32_t screen_unit_count(int32_t m) { return 4 * tri_tile_count(m, SCR_TH, SCR_TW / SCR_TH); }
 
-// every store into the matrix keeps the fp32 copy in step
+// every store into the matrix keeps the bf16 copy in step
 FNN_HD void store_d(const Dev& d, int64_t idx, double v) {
     d.D[idx] = v;
-    if (d.F) d.F[idx] = (float)v;
+    if (d.H) d.H[idx] = bf16_from_double(v);
 }
 
 // ---------------------------------------------------------------------------
@@ -448,7 +476,7 @@ FNN_HD void pick(const Dev& d, Cand best) {
     if (st.m == 4 && st.c == 2) { finish_plan(d); return; }
     cur.entries = (int64_t)st.m * (st.m - 1) / 2 - (st.m - st.c);
     cur.best = best.q;
-    st.bytes_streamed += (st.ev_screened ? 4 : 8) * cur.entries +
+    st.bytes_streamed += (st.ev_screened ? 2 : 8) * cur.entries +
                          (st.ev_screened ? (int64_t)(st.rescan_all ? 0 : st.ncand) * SCR_TH * SCR_UW * 8 : 0);
     st.ev_screened = 0;
     int32_t i = (int32_t)(best.key >> 32), j = (int32_t)(best.key & 0xFFFFFFFFu);
@@ -840,7 +868,7 @@ FNN_HD void init_thread(const Dev& d, int32_t k) {
     if (k == 0) {
         // the screening bound needs a finite, float-representable bound on |D| (prep kernel)
         const double dmax = __builtin_bit_cast(double, d.st->dmax_bits);
-        d.st->screen_ok = (d.F != nullptr && dmax == dmax && dmax < 1e37) ? 1 : 0;
+        d.st->screen_ok = (d.H != nullptr && dmax == dmax && dmax < 1e37) ? 1 : 0;
     }
 }
 

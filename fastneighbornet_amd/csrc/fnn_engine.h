@@ -80,8 +80,8 @@ class Engine {
             !(dev.chain = (double*)be.alloc(sizeof(double) * 4 * (size_t)dev.cstride)) ||
             !(dev.recs = (Cand*)be.alloc(sizeof(Cand) * be.max_records(n))) ||
             !(dev.rxpart = (double*)be.alloc(sizeof(double) * 8 * (nn / 256 + 2))) ||
-            !(dev.srec = (float*)be.alloc(sizeof(float) * ((size_t)screen_unit_count(n > 0 ? n : 1) + 8))) ||
-            !(dev.stile = (float*)be.alloc(sizeof(float) * ((size_t)screen_unit_count(n > 0 ? n : 1) / 4 + 8))) ||
+            !(dev.srec = (float*)be.alloc(sizeof(float) * (2 * (size_t)screen_unit_count(n > 0 ? n : 1) + 16))) ||
+            !(dev.stile = (float*)be.alloc(sizeof(float) * (2 * (size_t)screen_unit_count(n > 0 ? n : 1) / 4 + 16))) ||
             !(dev.clist = (int32_t*)be.alloc(sizeof(int32_t) * SCR_CAP)) ||
             !(dev.gsend = (Cand*)be.alloc(sizeof(Cand) * 64)) ||
             !(dev.grecv = (Cand*)be.alloc(sizeof(Cand) * 64)) ||
@@ -89,10 +89,10 @@ class Engine {
             !(dev.evlog = (Event*)be.alloc(sizeof(Event) * (nn + 8))) ||
             !(dev.agglog = (Agg3Rec*)be.alloc(sizeof(Agg3Rec) * (nn + 8))))
             return fail(FNN_ENOMEM, "fnn_create: device allocation failed (" + be.err() + ")");
-        dev.F = nullptr;
+        dev.H = nullptr;
         if (!opts.disable_screen && n >= be.screen_min_n()) {
-            if (!(dev.F = (float*)be.alloc(sizeof(float) * (size_t)nrows * (size_t)ld)))
-                return fail(FNN_ENOMEM, "fnn_create: device allocation of the fp32 copy failed (" + be.err() + ")");
+            if (!(dev.H = (uint16_t*)be.alloc(sizeof(uint16_t) * (size_t)nrows * (size_t)ld)))
+                return fail(FNN_ENOMEM, "fnn_create: device allocation of the bf16 copy failed (" + be.err() + ")");
         }
         // zero the padding once so that stray loads never see signalling patterns
         if (be.memset(dev.D, 0, sizeof(double) * (size_t)nrows * (size_t)ld) != FNN_OK)
@@ -102,7 +102,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.recs); be.free(dev.rxpart); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.F); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.recs); be.free(dev.rxpart); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }
@@ -164,8 +164,8 @@ class Engine {
         if (be.h2d(dev.st, &hst, sizeof(State)) != FNN_OK)
             return fail(FNN_EHIP, "fnn_begin: state upload failed (" + be.err() + ")");
         if (n > 3) {
-            if (dev.F && be.launch_prep_screen(dev, nrows) != FNN_OK)
-                return fail(FNN_EHIP, "fnn_begin: fp32 copy failed (" + be.err() + ")");
+            if (dev.H && be.launch_prep_screen(dev, nrows) != FNN_OK)
+                return fail(FNN_EHIP, "fnn_begin: bf16 copy failed (" + be.err() + ")");
             if (be.launch_init(dev) != FNN_OK || be.sync() != FNN_OK)
                 return fail(FNN_EHIP, "fnn_begin: init failed (" + be.err() + ")");
         }

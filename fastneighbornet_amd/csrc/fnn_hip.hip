@@ -144,74 +144,108 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(Dev d) {
     if (threadIdx.x == 0) d.recs[blockIdx.x] = best;
 }
 
-// ------------------------------------------------------------------ fp32 screening (fnn_core.h: screen_delta)
-// k_screen streams the float copy (4 B per entry): tiles of 32 rows x 1024 columns, a thread owns
-// 4 adjacent columns (one 16-byte load per row), a wave owns one 32 x 256 "unit" and records the
-// minimum of the fp32 Q estimate over it.  k_select turns the records into the list of units
-// that can hold the true minimum; k_rescan scans exactly those in fp64 with the exact body.
+// ------------------------------------------------------------------ bf16 screening (fnn_core.h: screen_micro)
+// k_screen streams the bf16 copy (2 B per entry): tiles of 32 rows x 2048 columns, a thread owns
+// 8 adjacent columns (one 16-byte load per row), a wave owns one 32 x 512 "unit" and records the
+// minima of the lower and upper bounds of Q over it.  k_resolve turns the records into the list
+// of units that can hold the true minimum and rescans exactly those in fp64 with the exact body.
 constexpr int SCR_R = SCR_TW / SCR_TH;
+
+typedef unsigned int fnn_v4u32 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 ld16h(const uint16_t* p) {
+    if (NT) {
+        const fnn_v4u32 v = __builtin_nontemporal_load(reinterpret_cast<const fnn_v4u32*>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const uint4*>(p);
+}
+__device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
 
 template <bool NT>
 __global__ __launch_bounds__(256) void k_screen(Dev d) {
-    __shared__ float shw[4];
+    __shared__ float shl[4], shu[4];
     const State* st = d.st;
     if (st->done) return;
     const int m = st->m;
     const int twoP = 2 * st->P;
     const float cm2 = (float)((double)st->c - 2.0);
+    const float cm2k = screen_cm2k(*st);
     const int ntiles = tri_tile_count(m, SCR_TH, SCR_R);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* lbrec = d.srec;
+    float* ubrec = d.srec + 4 * (size_t)ntiles;
+    float* lbt = d.stile;
+    float* ubt = d.stile + ntiles;
     for (int t = blockIdx.x * d.world + d.rank; t < ntiles; t += gridDim.x * d.world) {
         int rt, ct;
         tri_tile_decode(t, SCR_R, rt, ct);
         const int rbase = rt * SCR_TH;
-        const int c0 = ct * SCR_TW + 4 * (int)threadIdx.x;
-        float best = __builtin_inff();
+        const int c0 = ct * SCR_TW + 8 * (int)threadIdx.x;
+        Brk bk;
+        bk.lb = __builtin_inff();
+        bk.ub = __builtin_inff();
         if (c0 < m && c0 <= rbase + SCR_TH - 2) {
-            const double2 sa = *reinterpret_cast<const double2*>(d.Sx + c0);
-            const double2 sb = *reinterpret_cast<const double2*>(d.Sx + c0 + 2);
-            const float sxc0 = (float)sa.x, sxc1 = (float)sa.y, sxc2 = (float)sb.x, sxc3 = (float)sb.y;
-            const float* colbase = d.F + c0;
+            float sxc[8];
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                const double2 sv = *reinterpret_cast<const double2*>(d.Sx + c0 + k);
+                sxc[k] = (float)sv.x;
+                sxc[k + 1] = (float)sv.y;
+            }
+            const uint16_t* colbase = d.H + c0;
 #pragma unroll 1
             for (int half = 0; half < SCR_TH / 16; half++) {
                 const int rb = rbase + 16 * half;
                 if (rb >= m) break;
-                float4 a[8], b[8];
+                uint4 a[8], b[8];
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    const int r0 = rb + 2 * k;  // rows < nrows (padded), c0 + 3 < ld (ld padded to 1024)
-                    a[k] = ld16f<NT>(colbase + (int64_t)r0 * d.ld);
-                    b[k] = ld16f<NT>(colbase + (int64_t)(r0 + 1) * d.ld);
+                    const int r0 = rb + 2 * k;  // rows < nrows (padded), c0 + 7 < ld (ld padded to 2048)
+                    a[k] = ld16h<NT>(colbase + (int64_t)r0 * d.ld);
+                    b[k] = ld16h<NT>(colbase + (int64_t)(r0 + 1) * d.ld);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const int r0 = rb + 2 * k;
                     const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + r0);
                     const float sxr0 = (float)sxr.x, sxr1 = (float)sxr.y;
-                    screen_micro(r0, c0, m, twoP, cm2, a[k].x, a[k].y, b[k].x, b[k].y, sxr0, sxr1, sxc0, sxc1, best);
-                    screen_micro(r0, c0 + 2, m, twoP, cm2, a[k].z, a[k].w, b[k].z, b[k].w, sxr0, sxr1, sxc2, sxc3, best);
+                    const unsigned aw[4] = {a[k].x, a[k].y, a[k].z, a[k].w};
+                    const unsigned bw[4] = {b[k].x, b[k].y, b[k].z, b[k].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        screen_micro(r0, c0 + 2 * j, m, twoP, cm2, cm2k, bf_lo(aw[j]), bf_hi(aw[j]), bf_lo(bw[j]), bf_hi(bw[j]),
+                                     sxr0, sxr1, sxc[2 * j], sxc[2 * j + 1], bk);
                 }
             }
         }
+        float lb = bk.lb, ub = bk.ub;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) best = fminf_(best, __shfl_down(best, off, 64));
-        if (lane == 0) { d.srec[4 * t + w] = best; shw[w] = best; }
+        for (int off = 32; off >= 1; off >>= 1) {
+            lb = fminf_(lb, __shfl_down(lb, off, 64));
+            ub = fminf_(ub, __shfl_down(ub, off, 64));
+        }
+        if (lane == 0) { lbrec[4 * t + w] = lb; ubrec[4 * t + w] = ub; shl[w] = lb; shu[w] = ub; }
         __syncthreads();
-        if (threadIdx.x == 0) d.stile[t] = fminf_(fminf_(shw[0], shw[1]), fminf_(shw[2], shw[3]));
+        if (threadIdx.x == 0) {
+            lbt[t] = fminf_(fminf_(shl[0], shl[1]), fminf_(shl[2], shl[3]));
+            ubt[t] = fminf_(fminf_(shu[0], shu[1]), fminf_(shu[2], shu[3]));
+        }
         __syncthreads();
     }
 }
 
-// k_resolve: from the per-unit estimates to the exact pair, in one launch.  Every workgroup
-// derives the same candidate list (units whose estimate is within 2 delta of this rank's smallest
-// estimate), the waves of all workgroups share the exact fp64 rescans of those units, and the
-// last workgroup to arrive reduces the per-workgroup results and forms Cx/Cy (single GPU) or this
-// rank's candidate for the all-gather (several GPUs).
+// k_resolve: from the per-unit brackets to the exact pair, in one launch.  Every workgroup derives
+// the same candidate list (units whose lower bound does not exceed this rank's smallest upper
+// bound).  Few candidates (the usual case): workgroup 0 rescans them exactly and forms Cx/Cy
+// (single GPU) or this rank's candidate for the all-gather (several GPUs).  Many: all workgroups
+// share the rescans and the last one to arrive finishes.
 constexpr int RES_BLOCKS = 64;
 constexpr int RES_LIST = 4096;
 
-// exact scan of one 32 x 256 unit by a whole 1024-thread workgroup: every thread owns one column
-// pair and two of the 16 row pairs, so all loads of the unit are issued at once
+// exact scan of a 32 x 256 half-unit by a whole 1024-thread workgroup: every thread owns one
+// column pair and two of the 16 row pairs, so all loads are issued at once
 __device__ __forceinline__ void scan_unit_block(const Dev& d, int rbase, int cb, int m, int twoP, double cm2, Cand& best) {
     const int c0 = cb + 2 * ((int)threadIdx.x & 127);
     const int rg = (int)threadIdx.x >> 7;  // 0..7
@@ -254,21 +288,14 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d, int final_pick) {
     }
     const int m = st->m;
     const int ntiles = tri_tile_count(m, SCR_TH, SCR_R);
-    const float4* rec4 = reinterpret_cast<const float4*>(d.srec);
     const float finf = __builtin_inff();
-    // 1. this rank's smallest estimate, from the per-tile minima (kept in registers for step 2)
-    constexpr int RJ = 20;  // 20 * 1024 tiles cover n <= 35000 in one sweep; larger n re-read
-    float v[RJ];
+    // 1. this rank's smallest upper bound, from the per-tile records
+    const float* lbrec = d.srec;
+    const float* lbt = d.stile;
+    const float* ubt = d.stile + ntiles;
     float mn = finf;
-#pragma unroll
-    for (int j = 0; j < RJ; j++) {
-        const int t = tid + 1024 * j;
-        v[j] = (t < ntiles && t % d.world == d.rank) ? d.stile[t] : finf;
-    }
-#pragma unroll
-    for (int j = 0; j < RJ; j++) mn = fminf_(mn, v[j]);
-    for (int t = tid + 1024 * RJ; t < ntiles; t += 1024)
-        if (t % d.world == d.rank) mn = fminf_(mn, d.stile[t]);
+    for (int t = tid; t < ntiles; t += 1024)
+        if (t % d.world == d.rank) mn = fminf_(mn, ubt[t]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mn = fminf_(mn, __shfl_down(mn, off, 64));
     if (lane == 0) shmin[w] = mn;
@@ -277,23 +304,19 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d, int final_pick) {
     float g = shmin[0];
 #pragma unroll
     for (int k = 1; k < 16; k++) g = fminf_(g, shmin[k]);
-    // (a rank's minimum is >= the global one, so its threshold only admits more units)
+    // (a rank's smallest upper bound is >= the global one, so it only admits more units)
     const float thr = g + 2.0f * screen_delta(*st);
     bool all = !st->screen_ok || !(thr == thr);
-    // 2. candidate units: the units of the few tiles whose minimum passes
+    // 2. candidate units: the units, within the few tiles that pass, whose lower bound passes
     if (!all) {
-        auto take_tile = [&](int t) {
-            const float4 x = rec4[t];
-            if (x.x <= thr) { const int i = atomicAdd(&cnt, 1); if (i < RES_LIST) list[i] = 4 * t; }
-            if (x.y <= thr) { const int i = atomicAdd(&cnt, 1); if (i < RES_LIST) list[i] = 4 * t + 1; }
-            if (x.z <= thr) { const int i = atomicAdd(&cnt, 1); if (i < RES_LIST) list[i] = 4 * t + 2; }
-            if (x.w <= thr) { const int i = atomicAdd(&cnt, 1); if (i < RES_LIST) list[i] = 4 * t + 3; }
-        };
-#pragma unroll
-        for (int j = 0; j < RJ; j++)
-            if (v[j] <= thr) take_tile(tid + 1024 * j);
-        for (int t = tid + 1024 * RJ; t < ntiles; t += 1024)
-            if (t % d.world == d.rank && d.stile[t] <= thr) take_tile(t);
+        for (int t = tid; t < ntiles; t += 1024)
+            if (t % d.world == d.rank && lbt[t] <= thr) {
+                const float4 x = *reinterpret_cast<const float4*>(lbrec + 4 * (size_t)t);
+                if (x.x <= thr) { const int i = atomicAdd(&cnt, 1); if (i < RES_LIST) list[i] = 4 * t; }
+                if (x.y <= thr) { const int i = atomicAdd(&cnt, 1); if (i < RES_LIST) list[i] = 4 * t + 1; }
+                if (x.z <= thr) { const int i = atomicAdd(&cnt, 1); if (i < RES_LIST) list[i] = 4 * t + 2; }
+                if (x.w <= thr) { const int i = atomicAdd(&cnt, 1); if (i < RES_LIST) list[i] = 4 * t + 3; }
+            }
     }
     __syncthreads();
     const int count = cnt;
@@ -313,6 +336,7 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d, int final_pick) {
             int rt, ct;
             tri_tile_decode(u >> 2, SCR_R, rt, ct);
             scan_unit_block(d, rt * SCR_TH, ct * SCR_TW + (u & 3) * SCR_UW, m, twoP, cm2, best);
+            scan_unit_block(d, rt * SCR_TH, ct * SCR_TW + (u & 3) * SCR_UW + 256, m, twoP, cm2, best);
         }
     }
     best = block_reduce<16>(best, shc);
@@ -350,14 +374,14 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d, int final_pick) {
     }
 }
 
-// D -> F for the whole padded matrix, and max |D| over the n x n input
+// D -> H (bf16) for the whole padded matrix, and max |D| over the n x n input
 __global__ __launch_bounds__(256) void k_prep_screen(Dev d, int64_t nrows) {
     __shared__ unsigned long long shmax[4];
     unsigned long long b = 0;
     const int64_t total = nrows * d.ld;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const double v = d.D[i];
-        d.F[i] = (float)v;
+        d.H[i] = bf16_from_double(v);
         const int64_t r = i / d.ld, c = i - r * d.ld;
         if (r < d.n && c < d.n) {
             const unsigned long long x = f2u(v) & 0x7FFFFFFFFFFFFFFFULL;
@@ -967,7 +991,7 @@ struct HipBackend {
         int nt = (scan_tile_count(m_bound) + d.world - 1) / d.world;  // tiles of this rank
         return dim3((unsigned)(nt < scan_grid ? (nt > 0 ? nt : 1) : scan_grid));
     }
-    bool use_screen(const Dev& d, int32_t m_bound) const { return d.F != nullptr && m_bound >= screen_min_m; }
+    bool use_screen(const Dev& d, int32_t m_bound) const { return d.H != nullptr && m_bound >= screen_min_m; }
     // the scan of one event.  Returns the number of records left in d.recs for k_pick /
     // k_reduce_local, or 0 when the screening path has already produced Cx/Cy (final_pick) or the
     // rank's candidate.

@@ -41,7 +41,7 @@ std::vector<int32_t> thread_order(int32_t count) {
 
 struct EmuBackend {
     static constexpr int64_t kRowPad = 32;
-    static constexpr int64_t kColPad = 1024;
+    static constexpr int64_t kColPad = 2048;
     int32_t screen_min_n() const { return 8; }   // tiny on purpose: the CPU tests exercise screening
     int32_t screen_min_m = 8;
     std::string err() const { return "emu"; }
@@ -96,7 +96,7 @@ struct EmuBackend {
         for (int64_t r = 0; r < nrows; r++)
             for (int64_t c = 0; c < d.ld; c++) {
                 double v = d.D[r * d.ld + c];
-                d.F[r * d.ld + c] = (float)v;
+                d.H[r * d.ld + c] = fnn::bf16_from_double(v);
                 uint64_t b;
                 std::memcpy(&b, &v, 8);
                 b &= 0x7FFFFFFFFFFFFFFFULL;
@@ -129,7 +129,7 @@ struct EmuBackend {
                                 d.Sx[c0], c1 ? d.Sx[c0 + 1] : 0.0, d.spos[c0], c1 ? d.spos[c0 + 1] : 0, best);
             }
     }
-    // k_screen + k_select + k_rescan: fp32 screening, candidate units, exact rescan
+    // k_screen + k_resolve: bf16 screening with per-pair brackets, candidate units, exact rescan
     fnn::Cand scan_screened(const fnn::Dev& d) {
         fnn::State& st = *d.st;
         fnn::Cand best;
@@ -137,42 +137,45 @@ struct EmuBackend {
         best.key = ~0ULL;
         if (st.done) return best;
         const int32_t m = st.m, twoP = 2 * st.P;
-        const float cm2 = (float)((double)st.c - 2.0);
+        const float cm2 = (float)((double)st.c - 2.0), cm2k = fnn::screen_cm2k(st);
         const int32_t nunits = fnn::screen_unit_count(m);
         const float finf = (float)fnn::inf_f64();
+        float* lbrec = d.srec;
+        float* ubrec = d.srec + nunits;
         for (int32_t u : thread_order(nunits)) {
-            float umin = finf;
+            fnn::Brk b{finf, finf};
             if ((u / 4) % d.world == d.rank) {
                 int32_t rt, ct;
                 fnn::tri_tile_decode(u / 4, fnn::SCR_TW / fnn::SCR_TH, rt, ct);
                 const int32_t rb = rt * fnn::SCR_TH, cb = ct * fnn::SCR_TW + (u % 4) * fnn::SCR_UW;
                 for (int32_t r0 = rb; r0 < rb + fnn::SCR_TH && r0 < m; r0 += 2)
                     for (int32_t c0 = cb; c0 < cb + fnn::SCR_UW && c0 <= r0; c0 += 2) {
-                        const float* R0 = d.F + (int64_t)r0 * d.ld;
-                        const float* R1 = d.F + (int64_t)(r0 + 1) * d.ld;
+                        const uint16_t* R0 = d.H + (int64_t)r0 * d.ld;
+                        const uint16_t* R1 = d.H + (int64_t)(r0 + 1) * d.ld;
                         bool r1 = r0 + 1 < m, c1 = c0 + 1 < m;
-                        fnn::screen_micro(r0, c0, m, twoP, cm2, R0[c0], R0[c0 + 1], R1[c0], R1[c0 + 1],
+                        fnn::screen_micro(r0, c0, m, twoP, cm2, cm2k, fnn::bf16_to_float(R0[c0]), fnn::bf16_to_float(R0[c0 + 1]),
+                                          fnn::bf16_to_float(R1[c0]), fnn::bf16_to_float(R1[c0 + 1]),
                                           (float)d.Sx[r0], r1 ? (float)d.Sx[r0 + 1] : 0.f,
-                                          (float)d.Sx[c0], c1 ? (float)d.Sx[c0 + 1] : 0.f, umin);
+                                          (float)d.Sx[c0], c1 ? (float)d.Sx[c0 + 1] : 0.f, b);
                     }
             }
-            d.srec[u] = umin;
+            lbrec[u] = b.lb;
+            ubrec[u] = b.ub;
         }
-        // k_select
-        float gmin = finf;
-        for (int32_t u = 0; u < nunits; u++) gmin = fnn::fminf_(gmin, d.srec[u]);
-        const float thr = gmin + 2.0f * fnn::screen_delta(st);
+        // k_resolve: smallest upper bound, then the units whose lower bound does not exceed it
+        float ubg = finf;
+        for (int32_t u = 0; u < nunits; u++) ubg = fnn::fminf_(ubg, ubrec[u]);
+        const float thr = ubg + 2.0f * fnn::screen_delta(st);
         st.ncand = 0;
         st.rescan_all = (!st.screen_ok || !(thr == thr) || g_force_rescan_all) ? 1 : 0;
         if (!st.rescan_all)
             for (int32_t u : thread_order(nunits))
-                if (d.srec[u] <= thr) {
+                if (lbrec[u] <= thr) {
                     if (st.ncand >= g_cand_cap) { st.rescan_all = 1; break; }
                     d.clist[st.ncand++] = u;
                 }
         st.n_screen_events++;
         st.ev_screened = 1;
-        // k_rescan
         if (st.rescan_all) {
             for (int32_t u : thread_order(nunits))
                 if ((u / 4) % d.world == d.rank) { rescan_unit(d, u, best); st.n_rescan_units++; }
@@ -185,7 +188,7 @@ struct EmuBackend {
     // k_scan over this rank's share of the micro-tiles
     fnn::Cand scan_local(const fnn::Dev& d) {
         fnn::State& st = *d.st;
-        if (d.F && st.m >= screen_min_m) return scan_screened(d);
+        if (d.H && st.m >= screen_min_m) return scan_screened(d);
         fnn::Cand best;
         best.q = fnn::inf_f64();
         best.key = ~0ULL;
