@@ -268,8 +268,8 @@ FNN_HD float screen_delta(const State& st) {
 // (c - 2) * kappa, rounded up
 FNN_HD float screen_cm2k(const State& st) { return (float)(((double)st.c - 2.0) * (double)SCR_KAPPA * 1.000001); }
 
-FNN_HD float fminf_(float a, float b) { return a < b ? a : b; }
-FNN_HD float fabsf_(float a) { return a < 0.0f ? -a : a; }
+FNN_HD float fminf_(float a, float b) { return __builtin_fminf(a, b); }  // v_min_f32 (no NaN arises when screen_ok)
+FNN_HD float fabsf_(float a) { return __builtin_fabsf(a); }             // a source modifier on the GPU
 
 struct Brk { float lb, ub; };  // running minima of the lower / upper bounds
 

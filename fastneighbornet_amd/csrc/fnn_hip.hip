@@ -163,6 +163,64 @@ __device__ __forceinline__ uint4 ld16h(const uint16_t* p) {
 __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
 
+// bracket of one cluster pair from the mean dm of its entries and the mean am of their magnitudes
+__device__ __forceinline__ void brk_fast(float dm, float am, float cm2, float cm2k, float sp, float sq, float& lb, float& ub) {
+    const float q = __builtin_fmaf(cm2, dm, -sp) - sq;
+    const float e = cm2k * am;
+    lb = __builtin_fminf(lb, q - e);
+    ub = __builtin_fminf(ub, q + e);
+}
+
+// Tile classes with a branch-free body: strictly below the diagonal, entirely inside the live
+// block, and with all rows / all columns of one kind (two-node clusters or singletons).
+enum { SCR_GENERIC = 0, SCR_PP = 1, SCR_SP = 2, SCR_SS = 3 };
+
+template <bool NT, int CLS>
+__device__ __forceinline__ void screen_tile_fast(const Dev& d, int rbase, int c0, float cm2, float cm2k, float (&lb)[4], float (&ub)[4]) {
+    float sxc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        const double2 sv = *reinterpret_cast<const double2*>(d.Sx + c0 + k);
+        sxc[k] = (float)sv.x;
+        sxc[k + 1] = (float)sv.y;
+    }
+    const uint16_t* colbase = d.H + c0;
+#pragma unroll 1
+    for (int half = 0; half < SCR_TH / 16; half++) {
+        const int rb = rbase + 16 * half;
+        uint4 a[8], b[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            a[k] = ld16h<NT>(colbase + (int64_t)(rb + 2 * k) * d.ld);
+            b[k] = ld16h<NT>(colbase + (int64_t)(rb + 2 * k + 1) * d.ld);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + rb + 2 * k);
+            const float s0 = (float)sxr.x, s1 = (float)sxr.y;
+            const unsigned aw[4] = {a[k].x, a[k].y, a[k].z, a[k].w};
+            const unsigned bw[4] = {b[k].x, b[k].y, b[k].z, b[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float e00 = bf_lo(aw[j]), e01 = bf_hi(aw[j]), e10 = bf_lo(bw[j]), e11 = bf_hi(bw[j]);
+                if (CLS == SCR_PP) {
+                    brk_fast((((e00 + e01) + e10) + e11) * 0.25f,
+                             (((__builtin_fabsf(e00) + __builtin_fabsf(e01)) + __builtin_fabsf(e10)) + __builtin_fabsf(e11)) * 0.25f,
+                             cm2, cm2k, s0, sxc[2 * j], lb[j], ub[j]);
+                } else if (CLS == SCR_SP) {
+                    brk_fast((e00 + e01) * 0.5f, (__builtin_fabsf(e00) + __builtin_fabsf(e01)) * 0.5f, cm2, cm2k, s0, sxc[2 * j], lb[j], ub[j]);
+                    brk_fast((e10 + e11) * 0.5f, (__builtin_fabsf(e10) + __builtin_fabsf(e11)) * 0.5f, cm2, cm2k, s1, sxc[2 * j], lb[j], ub[j]);
+                } else {
+                    brk_fast(e00, __builtin_fabsf(e00), cm2, cm2k, s0, sxc[2 * j], lb[j], ub[j]);
+                    brk_fast(e01, __builtin_fabsf(e01), cm2, cm2k, s0, sxc[2 * j + 1], lb[j], ub[j]);
+                    brk_fast(e10, __builtin_fabsf(e10), cm2, cm2k, s1, sxc[2 * j], lb[j], ub[j]);
+                    brk_fast(e11, __builtin_fabsf(e11), cm2, cm2k, s1, sxc[2 * j + 1], lb[j], ub[j]);
+                }
+            }
+        }
+    }
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void k_screen(Dev d) {
     __shared__ float shl[4], shu[4];
@@ -181,12 +239,24 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
     for (int t = blockIdx.x * d.world + d.rank; t < ntiles; t += gridDim.x * d.world) {
         int rt, ct;
         tri_tile_decode(t, SCR_R, rt, ct);
-        const int rbase = rt * SCR_TH;
-        const int c0 = ct * SCR_TW + 8 * (int)threadIdx.x;
-        Brk bk;
-        bk.lb = __builtin_inff();
-        bk.ub = __builtin_inff();
-        if (c0 < m && c0 <= rbase + SCR_TH - 2) {
+        const int rbase = rt * SCR_TH, cbase = ct * SCR_TW;
+        const int c0 = cbase + 8 * (int)threadIdx.x;
+        float lbv[4], ubv[4];  // independent running minima per column pair
+#pragma unroll
+        for (int j = 0; j < 4; j++) { lbv[j] = __builtin_inff(); ubv[j] = __builtin_inff(); }
+        int cls = SCR_GENERIC;
+        if (cbase + SCR_TW <= rbase && rbase + SCR_TH <= m) {  // below the diagonal, inside the live block
+            if (rbase + SCR_TH <= twoP) cls = SCR_PP;
+            else if (cbase >= twoP) cls = SCR_SS;
+            else if (rbase >= twoP && cbase + SCR_TW <= twoP) cls = SCR_SP;
+        }
+        if (cls == SCR_PP) screen_tile_fast<NT, SCR_PP>(d, rbase, c0, cm2, cm2k, lbv, ubv);
+        else if (cls == SCR_SS) screen_tile_fast<NT, SCR_SS>(d, rbase, c0, cm2, cm2k, lbv, ubv);
+        else if (cls == SCR_SP) screen_tile_fast<NT, SCR_SP>(d, rbase, c0, cm2, cm2k, lbv, ubv);
+        else if (c0 < m && c0 <= rbase + SCR_TH - 2) {
+            Brk bk[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { bk[j].lb = __builtin_inff(); bk[j].ub = __builtin_inff(); }
             float sxc[8];
 #pragma unroll
             for (int k = 0; k < 8; k += 2) {
@@ -216,21 +286,24 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         screen_micro(r0, c0 + 2 * j, m, twoP, cm2, cm2k, bf_lo(aw[j]), bf_hi(aw[j]), bf_lo(bw[j]), bf_hi(bw[j]),
-                                     sxr0, sxr1, sxc[2 * j], sxc[2 * j + 1], bk);
+                                     sxr0, sxr1, sxc[2 * j], sxc[2 * j + 1], bk[j]);
                 }
             }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { lbv[j] = bk[j].lb; ubv[j] = bk[j].ub; }
         }
-        float lb = bk.lb, ub = bk.ub;
+        float lb = __builtin_fminf(__builtin_fminf(lbv[0], lbv[1]), __builtin_fminf(lbv[2], lbv[3]));
+        float ub = __builtin_fminf(__builtin_fminf(ubv[0], ubv[1]), __builtin_fminf(ubv[2], ubv[3]));
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
-            lb = fminf_(lb, __shfl_down(lb, off, 64));
-            ub = fminf_(ub, __shfl_down(ub, off, 64));
+            lb = __builtin_fminf(lb, __shfl_down(lb, off, 64));
+            ub = __builtin_fminf(ub, __shfl_down(ub, off, 64));
         }
         if (lane == 0) { lbrec[4 * t + w] = lb; ubrec[4 * t + w] = ub; shl[w] = lb; shu[w] = ub; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            lbt[t] = fminf_(fminf_(shl[0], shl[1]), fminf_(shl[2], shl[3]));
-            ubt[t] = fminf_(fminf_(shu[0], shu[1]), fminf_(shu[2], shu[3]));
+            lbt[t] = __builtin_fminf(__builtin_fminf(shl[0], shl[1]), __builtin_fminf(shl[2], shl[3]));
+            ubt[t] = __builtin_fminf(__builtin_fminf(shu[0], shu[1]), __builtin_fminf(shu[2], shu[3]));
         }
         __syncthreads();
     }
