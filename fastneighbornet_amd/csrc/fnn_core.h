@@ -459,6 +459,23 @@ FNN_HD void finish_plan(const Dev& d) {
     build_targets(d);
 }
 
+// The slots of Cx, Cx.nbr, Cy, Cy.nbr from the best candidate, without touching the control
+// block (every workgroup of k_rx_fill derives them for itself; workgroup 0 also runs pick()).
+// Returns false when the event needs no ComputeRx terms (loop ended, special finish, both single).
+FNN_HD bool pick_slots(const Dev& d, Cand best, int32_t z[4]) {
+    const State& st = *d.st;
+    z[0] = z[1] = z[2] = z[3] = -1;
+    if (st.done || st.m <= 3 || (st.m == 4 && st.c == 2)) return false;
+    const int32_t i = (int32_t)(best.key >> 32), j = (int32_t)(best.key & 0xFFFFFFFFu);
+    int32_t a = d.pslot[i], b = d.pslot[j];
+    if (d.sid[a] > d.sid[b]) { int32_t t = a; a = b; b = t; }
+    const int32_t twoP = 2 * st.P;
+    z[0] = a; z[2] = b;
+    z[1] = a < twoP ? (a ^ 1) : -1;
+    z[3] = b < twoP ? (b ^ 1) : -1;
+    return z[1] >= 0 || z[3] >= 0;
+}
+
 // After the scan: turn the best candidate into Cx, Cy (NetMakerOriginal.java:376-380)
 FNN_HD void pick(const Dev& d, Cand best) {
     State& st = *d.st;
@@ -494,14 +511,11 @@ FNN_HD void pick(const Dev& d, Cand best) {
 // ComputeRx term for slot s (NetMakerOriginal.java:555-558), written to the chain
 // buffer at the node's reference position; the terms are also returned (0 where absent)
 // so that the kernel can form tree-ordered partial sums for the certified decision.
-FNN_HD void rx_fill_thread(const Dev& d, int32_t s, double term[4]) {
-    const State& st = *d.st;
+FNN_HD void rx_fill_thread(const Dev& d, int32_t s, int32_t m, int32_t twoP, const int32_t z[4], double term[4]) {
     term[0] = term[1] = term[2] = term[3] = 0.0;
-    if (s >= st.m_old) return;
-    int32_t twoP = 2 * st.P_old;
-    bool full = (s == st.sa || s == st.sap || s == st.sb || s == st.sbp || s >= twoP);
+    if (s >= m) return;
+    bool full = (s == z[0] || s == z[1] || s == z[2] || s == z[3] || s >= twoP);
     int32_t pos = d.spos[s];
-    int32_t z[4] = {st.sa, st.sap, st.sb, st.sbp};
     for (int k = 0; k < 4; k++) {
         if (z[k] < 0) continue;
         double v = d.D[(int64_t)z[k] * d.ld + s];

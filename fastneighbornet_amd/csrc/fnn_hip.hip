@@ -10,8 +10,10 @@
 //   k_scan      all-pairs Q-criterion argmin over the lower triangle of the live
 //               m x m block (NeighborNetCanonical.java:151-178).  HBM-bound: reads
 //               each live matrix entry once, 16 B per lane, 1 KiB per wave-load.
-//   k_pick      reduce the per-block records, form Cx/Cy (NetMakerOriginal.java:376-380)
-//   k_rx_fill   ComputeRx terms in reference position order (:549-561) + tree partial sums
+//   k_screen    fp/bf16 screening pass of the scan for events with many live nodes, k_resolve: exact
+//               fp64 rescan of the few units that can hold the minimum
+//   k_rx_fill   reduce the per-block records, form Cx/Cy (NetMakerOriginal.java:376-380); ComputeRx
+//               terms in reference position order (:549-561) + tree partial sums
 //   k_decide4   candidate choice (:413-452) certified from the partial sums, else from the <=4
 //               exact sequential Rx sums; merge plan (:462-488)
 //   k_update    fused: subtractClusterDistance x2 per node (:455-461, 681-696), the net effect of
@@ -317,46 +319,48 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
 constexpr int RES_BLOCKS = 64;
 constexpr int RES_LIST = 4096;
 
-// exact scan of a 32 x 256 half-unit by a whole 1024-thread workgroup: every thread owns one
-// column pair and two of the 16 row pairs, so all loads are issued at once
+// exact scan of one 32 x 512 unit by a whole 1024-thread workgroup: every thread owns one column
+// pair and four of the 16 row pairs x 2 column halves, and issues all its loads before computing
 __device__ __forceinline__ void scan_unit_block(const Dev& d, int rbase, int cb, int m, int twoP, double cm2, Cand& best) {
-    const int c0 = cb + 2 * ((int)threadIdx.x & 127);
-    const int rg = (int)threadIdx.x >> 7;  // 0..7
-    if (!(c0 < m && c0 <= rbase + SCR_TH - 2)) return;
-    const double* colbase = d.D + c0;
-    const int ra = rbase + 2 * rg, rb = ra + 16;
-    double2 a0 = make_double2(0.0, 0.0), b0 = a0, a1 = a0, b1 = a0;
-    const bool va = ra < m && c0 <= ra, vb = rb < m && c0 <= rb;
-    if (va) { a0 = *reinterpret_cast<const double2*>(colbase + (int64_t)ra * d.ld); b0 = *reinterpret_cast<const double2*>(colbase + (int64_t)(ra + 1) * d.ld); }
-    if (vb) { a1 = *reinterpret_cast<const double2*>(colbase + (int64_t)rb * d.ld); b1 = *reinterpret_cast<const double2*>(colbase + (int64_t)(rb + 1) * d.ld); }
-    if (!va && !vb) return;
-    const double2 sxc = *reinterpret_cast<const double2*>(d.Sx + c0);
-    const int2 pc = *reinterpret_cast<const int2*>(d.spos + c0);
-    if (va) {
-        const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + ra);
-        const int2 pr = *reinterpret_cast<const int2*>(d.spos + ra);
-        scan_micro(ra, c0, m, twoP, cm2, a0.x, a0.y, b0.x, b0.y, sxr.x, sxr.y, pr.x, pr.y, sxc.x, sxc.y, pc.x, pc.y, best);
+    const int cp = (int)threadIdx.x & 127, rg = (int)threadIdx.x >> 7;  // rg in 0..7
+    double2 a[4], b[4];
+    int rr[4], cc[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        cc[q] = cb + (q >> 1) * 256 + 2 * cp;
+        rr[q] = rbase + 2 * rg + (q & 1) * 16;
+        ok[q] = cc[q] < m && rr[q] < m && cc[q] <= rr[q];
+        a[q] = make_double2(0.0, 0.0);
+        b[q] = a[q];
+        if (ok[q]) {
+            a[q] = *reinterpret_cast<const double2*>(d.D + (int64_t)rr[q] * d.ld + cc[q]);
+            b[q] = *reinterpret_cast<const double2*>(d.D + (int64_t)(rr[q] + 1) * d.ld + cc[q]);
+        }
     }
-    if (vb) {
-        const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + rb);
-        const int2 pr = *reinterpret_cast<const int2*>(d.spos + rb);
-        scan_micro(rb, c0, m, twoP, cm2, a1.x, a1.y, b1.x, b1.y, sxr.x, sxr.y, pr.x, pr.y, sxc.x, sxc.y, pc.x, pc.y, best);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (!ok[q]) continue;
+        const double2 sxc = *reinterpret_cast<const double2*>(d.Sx + cc[q]);
+        const int2 pc = *reinterpret_cast<const int2*>(d.spos + cc[q]);
+        const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + rr[q]);
+        const int2 pr = *reinterpret_cast<const int2*>(d.spos + rr[q]);
+        scan_micro(rr[q], cc[q], m, twoP, cm2, a[q].x, a[q].y, b[q].x, b[q].y, sxr.x, sxr.y, pr.x, pr.y, sxc.x, sxc.y, pc.x, pc.y, best);
     }
 }
 
-__global__ __launch_bounds__(1024) void k_resolve(Dev d, int final_pick) {
+__global__ __launch_bounds__(1024) void k_resolve(Dev d) {
     __shared__ float shmin[16];
     __shared__ int cnt;
     __shared__ int list[RES_LIST];
     __shared__ Cand shc[16];
-    __shared__ int lastflag;
     State* st = d.st;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     Cand best;
     best.q = inf_f64();
     best.key = ~0ULL;
-    if (st->done) {  // nothing to scan; keep the control flow of the event alive
-        if (blockIdx.x == 0 && tid == 0) { if (final_pick) pick(d, best); else d.gsend[0] = best; }
+    if (st->done) {  // nothing to scan: leave "no candidate" records
+        if (tid == 0) d.recs[blockIdx.x] = best;
         return;
     }
     const int m = st->m;
@@ -395,55 +399,31 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d, int final_pick) {
     const int count = cnt;
     if (count > RES_LIST) all = true;
     const int total = all ? 4 * ntiles : count;
-    // few candidates (the usual case): workgroup 0 finishes alone, no cross-workgroup hand-off
-    const bool solo = !all && count <= 16;
-    if (solo && blockIdx.x != 0) return;
-    // 3. exact rescans, one unit per workgroup at a time
+    // 3. exact rescans shared by all workgroups (k_rx_fill reduces the per-workgroup results)
     {
         const int twoP = 2 * st->P;
         const double cm2 = (double)st->c - 2.0;
-        const int first = solo ? 0 : (int)blockIdx.x, step = solo ? 1 : (int)gridDim.x;
-        for (int i = first; i < total; i += step) {
+        // every workgroup holds the same SET of candidates, but in its own (atomic) order, so the
+        // work is split by unit id, not by list position
+        for (int i = 0; i < total; i++) {
             const int u = all ? i : list[i];
+            if (u % (int)gridDim.x != (int)blockIdx.x) continue;
             if (all && (u >> 2) % d.world != d.rank) continue;
             int rt, ct;
             tri_tile_decode(u >> 2, SCR_R, rt, ct);
             scan_unit_block(d, rt * SCR_TH, ct * SCR_TW + (u & 3) * SCR_UW, m, twoP, cm2, best);
-            scan_unit_block(d, rt * SCR_TH, ct * SCR_TW + (u & 3) * SCR_UW + 256, m, twoP, cm2, best);
         }
     }
     best = block_reduce<16>(best, shc);
-    Cand c = best;  // valid in thread 0
-    if (!solo) {
-        // 4. arrival; the last workgroup reduces the per-workgroup results
-        if (tid == 0) {
-            __hip_atomic_store(&d.recs[blockIdx.x].q, best.q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&d.recs[blockIdx.x].key, best.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence();
-            const int ticket = __hip_atomic_fetch_add(&st->res_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            lastflag = (ticket == (int)gridDim.x - 1) ? 1 : 0;
-            if (lastflag) __threadfence();
-        }
-        __syncthreads();
-        if (!lastflag) return;
-        c.q = inf_f64();
-        c.key = ~0ULL;
-        if (tid < (int)gridDim.x) {
-            c.q = __hip_atomic_load(&d.recs[tid].q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            c.key = __hip_atomic_load(&d.recs[tid].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();  // shc is reused
-        c = block_reduce<16>(c, shc);
-    }
     if (tid == 0) {
-        st->res_ticket = 0;
-        st->rescan_all = all ? 1 : 0;
-        st->ncand = all ? 0 : count;
-        st->n_screen_events += 1;
-        st->n_rescan_units += all ? (int64_t)(4 * ntiles) / d.world : (int64_t)count;
-        st->ev_screened = 1;
-        if (final_pick) pick(d, c);
-        else d.gsend[0] = c;
+        d.recs[blockIdx.x] = best;
+        if (blockIdx.x == 0) {
+            st->rescan_all = all ? 1 : 0;
+            st->ncand = all ? 0 : count;
+            st->n_screen_events += 1;
+            st->n_rescan_units += all ? (int64_t)(4 * ntiles) / d.world : (int64_t)count;
+            st->ev_screened = 1;
+        }
     }
 }
 
@@ -489,13 +469,6 @@ __device__ __forceinline__ Cand reduce_records(const Dev& d, const Cand* src, in
     return block_reduce<16>(best, sh);
 }
 
-// single GPU: records of the scan -> Cx, Cy.  Several GPUs: the all-gathered per-rank records.
-__global__ __launch_bounds__(1024) void k_pick(Dev d, const Cand* src, int nrecs) {
-    __shared__ Cand sh[16];
-    Cand best = reduce_records(d, src, nrecs, sh);
-    if (threadIdx.x == 0) pick(d, best);
-}
-
 // several GPUs: this rank's records -> one candidate for the all-gather
 __global__ __launch_bounds__(1024) void k_reduce_local(Dev d, int nrecs) {
     __shared__ Cand sh[16];
@@ -506,12 +479,36 @@ __global__ __launch_bounds__(1024) void k_reduce_local(Dev d, int nrecs) {
 // ------------------------------------------------------------------ k_rx_fill
 // ComputeRx terms into the chain buffers + per-workgroup partial sums (tree order) of the terms
 // and of their magnitudes for the certified 4-candidate decision (fnn_core.h: rx_certify)
-__global__ __launch_bounds__(256) void k_rx_fill(Dev d) {
+__global__ __launch_bounds__(256) void k_rx_fill(Dev d, const Cand* src, int nrecs) {
     __shared__ double sh[4][8];
+    __shared__ Cand shc[4];
+    __shared__ int zsh[5];
     const State* st = d.st;
-    if (!st->ev_active || st->ev_finish || !st->need_rx) return;
+    // the event's best candidate: every workgroup reduces the records for itself (no cross-
+    // workgroup hand-off); workgroup 0 also turns it into the event's control state
+    Cand best;
+    best.q = inf_f64();
+    best.key = ~0ULL;
+    if (!st->done)
+        for (int i = threadIdx.x; i < nrecs; i += 256) {
+            const Cand c = src[i];
+            if (cand_better(c, best)) best = c;
+        }
+    best = block_reduce<4>(best, shc);
+    if (threadIdx.x == 0) {
+        int32_t z[4];
+        const bool need = pick_slots(d, best, z);
+        zsh[0] = z[0]; zsh[1] = z[1]; zsh[2] = z[2]; zsh[3] = z[3]; zsh[4] = need ? 1 : 0;
+    }
+    __syncthreads();
+    const int32_t z[4] = {zsh[0], zsh[1], zsh[2], zsh[3]};
+    const bool need = zsh[4] != 0;
+    const int32_t m = st->m, twoP = 2 * st->P;  // (pick() does not change m, P)
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) pick(d, best);
+    if (!need) return;
     double term[4];
-    rx_fill_thread(d, blockIdx.x * 256 + threadIdx.x, term);
+    rx_fill_thread(d, blockIdx.x * 256 + threadIdx.x, m, twoP, z, term);
     double v[8];
 #pragma unroll
     for (int k = 0; k < 4; k++) { v[k] = term[k]; v[4 + k] = term[k] < 0.0 ? -term[k] : term[k]; }
@@ -1065,10 +1062,8 @@ struct HipBackend {
         return dim3((unsigned)(nt < scan_grid ? (nt > 0 ? nt : 1) : scan_grid));
     }
     bool use_screen(const Dev& d, int32_t m_bound) const { return d.H != nullptr && m_bound >= screen_min_m; }
-    // the scan of one event.  Returns the number of records left in d.recs for k_pick /
-    // k_reduce_local, or 0 when the screening path has already produced Cx/Cy (final_pick) or the
-    // rank's candidate.
-    int enqueue_scan(const Dev& d, int32_t m_bound, int final_pick) {
+    // the scan of one event; returns the number of per-workgroup records it leaves in d.recs
+    int enqueue_scan(const Dev& d, int32_t m_bound) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (timing) { e0 = next_event(); e1 = next_event(); }
         int nrecs;
@@ -1079,8 +1074,8 @@ struct HipBackend {
             if (scan_nt) hipLaunchKernelGGL(k_screen<true>, gs, dim3(256), 0, stream, d);
             else hipLaunchKernelGGL(k_screen<false>, gs, dim3(256), 0, stream, d);
             if (e1) (void)hipEventRecord(e1, stream);
-            hipLaunchKernelGGL(k_resolve, dim3(RES_BLOCKS), dim3(1024), 0, stream, d, final_pick);
-            nrecs = 0;
+            hipLaunchKernelGGL(k_resolve, dim3(RES_BLOCKS), dim3(1024), 0, stream, d);
+            nrecs = RES_BLOCKS;
         } else {
             dim3 gs = scan_dims(d, m_bound);
             if (e0) (void)hipEventRecord(e0, stream);
@@ -1092,9 +1087,10 @@ struct HipBackend {
         scan_launches++;
         return nrecs;
     }
-    void enqueue_rest(const Dev& d, int32_t m_bound) {
+    // everything after the scan; `src` holds the nrecs candidate records to reduce
+    void enqueue_rest(const Dev& d, int32_t m_bound, const Cand* src, int nrecs) {
         dim3 g1 = grid1(m_bound);
-        hipLaunchKernelGGL(k_rx_fill, g1, dim3(256), 0, stream, d);
+        hipLaunchKernelGGL(k_rx_fill, g1, dim3(256), 0, stream, d, src, nrecs);
         hipLaunchKernelGGL(k_decide4, dim3(1), dim3(CH_T), 0, stream, d, (int)g1.x);
         hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d);
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d);
@@ -1102,22 +1098,20 @@ struct HipBackend {
     // single GPU: the whole event
     int32_t launch_event(const Dev& d, int32_t m_bound) {
         if (m_bound < 1) m_bound = 1;
-        int nrecs = enqueue_scan(d, m_bound, 1);
-        if (nrecs > 0) hipLaunchKernelGGL(k_pick, dim3(1), dim3(1024), 0, stream, d, (const Cand*)d.recs, nrecs);
-        enqueue_rest(d, m_bound);
+        int nrecs = enqueue_scan(d, m_bound);
+        enqueue_rest(d, m_bound, (const Cand*)d.recs, nrecs);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
     // several GPUs: scan of this rank's tiles + local reduction ... (all-gather) ... the rest
     int32_t launch_event_scan(const Dev& d, int32_t m_bound) {
         if (m_bound < 1) m_bound = 1;
-        int nrecs = enqueue_scan(d, m_bound, 0);
-        if (nrecs > 0) hipLaunchKernelGGL(k_reduce_local, dim3(1), dim3(1024), 0, stream, d, nrecs);
+        int nrecs = enqueue_scan(d, m_bound);
+        hipLaunchKernelGGL(k_reduce_local, dim3(1), dim3(1024), 0, stream, d, nrecs);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
     int32_t launch_event_rest(const Dev& d, int32_t m_bound) {
         if (m_bound < 1) m_bound = 1;
-        hipLaunchKernelGGL(k_pick, dim3(1), dim3(1024), 0, stream, d, (const Cand*)d.grecv, d.world);
-        enqueue_rest(d, m_bound);
+        enqueue_rest(d, m_bound, (const Cand*)d.grecv, d.world);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
 };

@@ -227,8 +227,13 @@ struct EmuBackend {
     int32_t event_rest(const fnn::Dev& d, int32_t m_bound, fnn::Cand best) {
         fnn::State& st = *d.st;
         // k_pick
+        int32_t zs[4];
+        const bool zneed = fnn::pick_slots(d, best, zs);  // what the other workgroups of k_rx_fill derive
         fnn::pick(d, best);
         if (!st.ev_active) return FNN_OK;
+        if (!st.ev_finish && (zneed != (st.need_rx != 0) ||
+                              (zneed && (zs[0] != st.sa || zs[1] != st.sap || zs[2] != st.sb || zs[3] != st.sbp))))
+            st.error = 8;
         if (!st.ev_finish) {
             // k_rx_fill (+ per-block partial sums) and k_decide4 (certify, else exact chains)
             double rx[4] = {0.0, 0.0, 0.0, 0.0};
@@ -237,9 +242,10 @@ struct EmuBackend {
                 const int32_t nblk = (m_bound + 255) / 256;
                 for (int32_t b = 0; b < nblk; b++) {
                     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    const int32_t zz[4] = {st.sa, st.sap, st.sb, st.sbp};
                     for (int32_t t : thread_order(256)) {
                         double term[4];
-                        fnn::rx_fill_thread(d, b * 256 + t, term);
+                        fnn::rx_fill_thread(d, b * 256 + t, st.m_old, 2 * st.P_old, zz, term);
                         for (int k = 0; k < 4; k++) { acc[k] += term[k]; acc[4 + k] += term[k] < 0 ? -term[k] : term[k]; }
                     }
                     for (int k = 0; k < 8; k++) d.rxpart[(size_t)b * 8 + k] = acc[k];

@@ -127,6 +127,16 @@ def test_full_size_invariants(hip_api):
         order, st = h.run()
         ev = h.events()
     check_order(order, n)
+    # the screening pass + exact rescans must reproduce the plain fp64 scan event by event
+    with Handle(hip_api, n, record_events=True, disable_screen=True) as h:
+        h.synth(1, "uniform53")
+        order_plain, st_plain = h.run()
+        ev_plain = h.events()
+    assert st.n_screen_events > 20000 and st_plain.n_screen_events == 0
+    assert (order == order_plain).all()
+    for f in ("m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id"):
+        assert (ev[f] == ev_plain[f]).all(), f
+    assert (bits(ev["best"]) == bits(ev_plain["best"])).all()
     assert st.n_events == len(ev)
     # clusters drop by exactly one per event; c <= m <= 2c; counters follow the event kinds
     assert (np.diff(ev["c_before"]) == -1).all()
@@ -178,3 +188,21 @@ print("SCREEN_OK", st.n_screen_events, st.n_rescan_units)
     env = dict(os.environ, FNN_ROOT=root, FNN_SCREEN_MIN_N="8", FNN_SCREEN_MIN_M="8")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SCREEN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_screened_run_equals_plain_fp64_run(hip_api):
+    """Above 8192 live nodes the scan goes through the screening pass + exact rescans.  The
+    whole trajectory must be identical to a run that scans the fp64 matrix in full."""
+    n = 10240
+    runs = []
+    for disable in (True, False):
+        with Handle(hip_api, n, record_events=True, disable_screen=disable) as h:
+            h.synth(3, "uniform53")
+            order, st = h.run()
+            runs.append((order, h.events(), st))
+    (o0, e0, s0), (o1, e1, s1) = runs
+    assert s0.n_screen_events == 0 and s1.n_screen_events > 1000
+    assert (o0 == o1).all()
+    for f in ("m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id", "entries"):
+        assert (e0[f] == e1[f]).all(), f
+    assert (bits(e0["best"]) == bits(e1["best"])).all()
