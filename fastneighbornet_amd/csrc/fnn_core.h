@@ -125,7 +125,6 @@ struct Dev {
     int64_t cstride; // n rounded up to a whole super-chunk
     Cand* recs;      // per-block scan records
     double* rxpart;  // per-block partial sums of k_rx_fill: [block][8] = 4 sums + 4 sums of |terms|
-    double* upart;   // per-block partial sums of k_update: sum of the new cluster distances Dpu
     uint16_t* H;     // bf16 screening copy of D (same geometry, H[r][c] == bf16(D[r][c]))
     float* srec;     // screening: per unit [tile][4] lower bounds, then [tile][4] upper bounds
     float* stile;    // screening: per tile lower bound, then per tile upper bound
@@ -263,10 +262,7 @@ FNN_HD float bf16_to_float(uint16_t h) { return __builtin_bit_cast(float, (uint3
 FNN_HD float screen_delta(const State& st) {
     const double dmax = __builtin_bit_cast(double, st.dmax_bits);
     const double u = 5.9604644775390625e-08;  // 2^-24
-    // (+ the provisional Sx of the newest cluster: any summation order is within
-    //  gamma_n * sum|terms| <= 1.2e-16 n * (n Dmax) of the exact sum, twice for seq. vs tree order)
-    const double dlt = 2.0 * u * dmax * (7.0 * ((double)st.c - 2.0) + 6.0 * (double)st.n) +
-                       4.0 * 1.2e-16 * (double)st.n * (double)st.n * dmax + 1e-30;
+    const double dlt = 2.0 * u * dmax * (7.0 * ((double)st.c - 2.0) + 6.0 * (double)st.n) + 1e-30;
     return (float)(dlt * 1.0000002);  // round up when narrowing to float
 }
 // (c - 2) * kappa, rounded up
@@ -740,9 +736,9 @@ FNN_HD void op_thread(const Dev& d, const Op& op, int32_t k) {
 }
 
 // updateClusterDistances(u), per-node part (NetMakerOriginal.java:520-533). New layout.
-FNN_HD double add_thread(const Dev& d, int32_t s) {
+FNN_HD void add_thread(const Dev& d, int32_t s) {
     const State& st = *d.st;
-    if (s >= st.m) return 0.0;
+    if (s >= st.m) return;
     int32_t twoP = 2 * st.P;
     int32_t U = st.U, V = st.U + 1;
     const double* D = d.D; const int64_t ld = d.ld;
@@ -758,7 +754,6 @@ FNN_HD double add_thread(const Dev& d, int32_t s) {
         val = dpu;
     }
     d.chain[chain_addr(d.spos[s])] = val;  // adding +0.0 to a running sum that starts at +0.0 changes no bit
-    return val;
 }
 
 FNN_HD double tgt_value(const Tgt& t, const double* D, int64_t ld, int32_t c) {
@@ -777,13 +772,13 @@ FNN_HD double tgt_value(const Tgt& t, const double* D, int64_t ld, int32_t c) {
 // Reads only rows of involved slots at its own column(s) and writes only entries with
 // exactly one index equal to its own column(s), so it cannot conflict with any other thread;
 // the involved slots themselves are handled by update_special_*.
-FNN_HD double update_bulk(const Dev& d, int32_t k) {
+FNN_HD void update_bulk(const Dev& d, int32_t k) {
     const State& st = *d.st;
-    if (k >= st.m_old) return 0.0;
+    if (k >= st.m_old) return;
     const int32_t twoP = 2 * st.P_old;
     const bool paired = k < twoP;
-    if (paired && (k & 1)) return 0.0;  // the even thread of a two-node cluster does both columns
-    for (int i = 0; i < st.nS; i++) if (st.S[i] == k) return 0.0;
+    if (paired && (k & 1)) return;  // the even thread of a two-node cluster does both columns
+    for (int i = 0; i < st.nS; i++) if (st.S[i] == k) return;
     double* D = d.D; const int64_t ld = d.ld;
     double sx0 = 0.0, sx1 = 0.0;
     if (!st.ev_finish) {
@@ -839,34 +834,28 @@ FNN_HD double update_bulk(const Dev& d, int32_t k) {
             d.Sx[k + 1] = sx1 + dpu;
             d.chain[chain_addr(d.spos[k + 1])] = 0.0;
         }
-        return dpu;
     }
-    return 0.0;
 }
 
 // The involved slots (<= MAX_S columns) go through the per-column bodies above in phases:
 // phase 0 subtract, phases 1..nops one micro-op each, last phase add.  Within a phase the
 // columns are independent; phases are separated by a workgroup barrier on the GPU.
 FNN_HD int32_t update_special_phases(const State& st) { return st.nops + 2; }
-FNN_HD double update_special(const Dev& d, int32_t phase, int32_t i) {
+FNN_HD void update_special(const Dev& d, int32_t phase, int32_t i) {
     const State& st = *d.st;
-    if (i >= st.nS) return 0.0;
+    if (i >= st.nS) return;
     const int32_t k = st.S[i];
     if (phase == 0) { if (!st.ev_finish) subtract_thread(d, k); }
     else if (phase <= st.nops) { Op op = st.ops[phase - 1]; op_thread(d, op, k); }
-    else { if (!st.ev_finish) return add_thread(d, k); }
-    return 0.0;
+    else { if (!st.ev_finish) add_thread(d, k); }
 }
 
-// Close the event (log, counters, loop condition :339) and give u.Sx / u.nbr.Sx a PROVISIONAL
-// value: the tree-ordered sum of the new cluster distances.  The exact sequential sum (:532)
-// overwrites it (set_usx) before anything exact reads it; only the screening pass of the next
-// event may see the provisional value, and its error bound accounts for that (screen_delta).
-FNN_HD void finalize_event(const Dev& d, double usx_approx) {
+// u.Sx = sequential sum; u.nbr.Sx = u.Sx (:518-519, 532, 535); close the event
+FNN_HD void finalize(const Dev& d, double usx) {
     State& st = *d.st;
     if (!st.ev_finish) {
-        d.Sx[st.U] = usx_approx;
-        d.Sx[st.U + 1] = usx_approx;
+        d.Sx[st.U] = usx;
+        d.Sx[st.U + 1] = usx;
     } else {  // special finish: u, v are fresh nodes whose Sx keeps its default (NetNode.java:15)
         d.Sx[st.U] = 0.0;
         d.Sx[st.U + 1] = 0.0;
@@ -875,14 +864,6 @@ FNN_HD void finalize_event(const Dev& d, double usx_approx) {
     st.n_events += 1;
     st.sum_entries += st.cur.entries;
     if (st.ev_finish || st.m <= 3) st.done = 1;
-}
-
-// u.Sx = sequential sum; u.nbr.Sx = u.Sx (:518-519, 532, 535)
-FNN_HD void set_usx(const Dev& d, double usx) {
-    const State& st = *d.st;
-    if (st.ev_finish) return;
-    d.Sx[st.U] = usx;
-    d.Sx[st.U + 1] = usx;
 }
 
 // NetMakerOriginal.initialize (:164-191) for the all-singleton start: node k receives

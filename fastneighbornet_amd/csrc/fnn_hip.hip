@@ -19,9 +19,7 @@
 //   k_update    fused: subtractClusterDistance x2 per node (:455-461, 681-696), the net effect of
 //               the plan's micro-ops (agg3way row/column rewrite :653-656, slot swaps / moves)
 //               and updateClusterDistances' per-node part (:520-531)
-//   k_sx_approx / k_finalize_exact   event log, loop condition (:339); provisional (tree-ordered),
-//               then exact sequential u.Sx sum (:532), the latter overlapped with the next
-//               event's screening pass on a second stream
+//   k_finalize  sequential u.Sx sum (:532), event log, loop condition (:339)
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -790,50 +788,27 @@ __global__ __launch_bounds__(CH_T) void k_decide4(Dev d, int nparts) {
 // subtract + every micro-op + add of one event in ONE launch (fnn_core.h: update_bulk /
 // update_special).  The last workgroup handles the <= 8 involved slots in phases.
 __global__ __launch_bounds__(256) void k_update(Dev d) {
-    __shared__ double shp[4];
     const State* st = d.st;
     if (!st->ev_active) return;
-    double dpu = 0.0;
     if (blockIdx.x == gridDim.x - 1) {
         const int nph = update_special_phases(*st);
         for (int ph = 0; ph < nph; ph++) {
-            dpu += update_special(d, ph, (int)threadIdx.x);
+            update_special(d, ph, (int)threadIdx.x);
             __syncthreads();  // a phase's stores are visible to the next phase (same CU, same L1)
         }
-    } else {
-        dpu = update_bulk(d, blockIdx.x * 256 + threadIdx.x);
+        return;
     }
-    // tree-ordered partial sum of the new cluster distances (provisional u.Sx, k_sx_approx)
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) dpu += __shfl_down(dpu, off, 64);
-    if ((threadIdx.x & 63) == 0) shp[threadIdx.x >> 6] = dpu;
-    __syncthreads();
-    if (threadIdx.x == 0) d.upart[blockIdx.x] = ((shp[0] + shp[1]) + shp[2]) + shp[3];
+    update_bulk(d, blockIdx.x * 256 + threadIdx.x);
 }
 
-// ------------------------------------------------------------------ k_sx_approx / k_finalize_exact
-// k_sx_approx closes the event on the main stream with the provisional u.Sx (sum of k_update's
-// partials); k_finalize_exact evaluates the exact sequential sum (NetMakerOriginal.java:532) -
-// on a second stream, concurrently with the next event's screening pass, when that pays.
-__global__ __launch_bounds__(256) void k_sx_approx(Dev d, int nparts) {
-    __shared__ double shp[4];
-    const State* st = d.st;
-    if (!st->ev_active) return;
-    double v = 0.0;
-    for (int b = threadIdx.x; b < nparts; b += 256) v += d.upart[b];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0) shp[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) finalize_event(d, ((shp[0] + shp[1]) + shp[2]) + shp[3]);
-}
-
-__global__ __launch_bounds__(CH_T) void k_finalize_exact(Dev d) {
+// ------------------------------------------------------------------ k_finalize
+__global__ __launch_bounds__(CH_T) void k_finalize(Dev d) {
     __shared__ ChainLds<CH_EPT> L;
-    const State* st = d.st;
-    if (!st->ev_active || st->ev_finish) return;
-    const double usx = block_chain_sum<CH_EPT>(d.chain, st->m, CH_GUARD_BITS, L, nullptr);
-    if (threadIdx.x == 0) set_usx(d, usx);
+    State* st = d.st;
+    if (!st->ev_active) return;
+    double usx = 0.0;
+    if (!st->ev_finish) usx = block_chain_sum<CH_EPT>(d.chain, st->m, CH_GUARD_BITS, L, nullptr);
+    if (threadIdx.x == 0) finalize(d, usx);
 }
 
 // diagnostic entry: the block chain sum on an arbitrary buffer (tests)
@@ -905,10 +880,6 @@ struct HipBackend {
     int screen_min_m = 8192;                     // events with fewer live nodes use the plain scan (FNN_SCREEN_MIN_M)
     hipError_t last = hipSuccess;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // exact u.Sx sums, overlapped with the next screening pass
-    std::vector<hipEvent_t> xev;    // cross-stream events (ring, recycled at every host sync)
-    size_t xev_used = 0;
-    hipEvent_t pending_exact = nullptr;  // the exact sum the main stream still has to wait for
     int device = 0;
     bool opened = false;
     // scan timing
@@ -926,7 +897,6 @@ struct HipBackend {
     int (*p_ncclCommDestroy)(void*) = nullptr;
     const char* (*p_ncclGetErrorString)(int) = nullptr;
     std::string comm_err;
-    bool overlap_exact = true;  // FNN_OVERLAP=0: keep the exact u.Sx sum on the main stream
     int scan_grid = 8192;   // workgroups of the scan (FNN_SCAN_GRID)
     bool scan_nt = true;    // non-temporal matrix loads in the scan (FNN_SCAN_NT)
 
@@ -974,13 +944,7 @@ struct HipBackend {
         if (dev < 0 || dev >= cnt) return fail(FNN_EINVAL, "device ordinal out of range");
         device = dev;
         if (!HIPOK(hipSetDevice(device))) return fail(FNN_EHIP, "hipSetDevice failed (" + err() + ")");
-        // second stream: the exact u.Sx sum of event t runs beside the screening pass of event t+1.
-        // (Measured: +0.15 s at n = 32768.  The 1024-thread workgroup only gets a CU when the
-        // streaming kernel lets go of one; a raised stream priority or CU masks that reserve two
-        // CUs for it did not do better - profiles/r01/README.md.)
-        if (const char* e = std::getenv("FNN_OVERLAP")) overlap_exact = std::atoi(e) != 0;
-        if (!HIPOK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) ||
-            !HIPOK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking)))
+        if (!HIPOK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)))
             return fail(FNN_EHIP, "hipStreamCreate failed (" + err() + ")");
         if (const char* e = std::getenv("FNN_SCAN_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) scan_grid = v; }
         if (const char* e = std::getenv("FNN_SCAN_NT")) scan_nt = std::atoi(e) != 0;
@@ -997,10 +961,6 @@ struct HipBackend {
         ev_pool.clear();
         if (d_bad) (void)hipFree(d_bad);
         d_bad = nullptr;
-        for (hipEvent_t e : xev) (void)hipEventDestroy(e);
-        xev.clear();
-        if (stream2) (void)hipStreamDestroy(stream2);
-        stream2 = nullptr;
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
         opened = false;
@@ -1048,24 +1008,9 @@ struct HipBackend {
         ev_used = 0;
     }
     int32_t sync() {
-        if (!HIPOK(hipStreamSynchronize(stream)) || !HIPOK(hipStreamSynchronize(stream2))) return FNN_EHIP;
-        pending_exact = nullptr;
-        xev_used = 0;
+        if (!HIPOK(hipStreamSynchronize(stream))) return FNN_EHIP;
         if (timing) drain_timing();
         return FNN_OK;
-    }
-    hipEvent_t next_xev() {
-        if (xev_used == xev.size()) {
-            hipEvent_t e;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-            xev.push_back(e);
-        }
-        return xev[xev_used++];
-    }
-    // the main stream must not run anything that reads the exact u.Sx before it has landed
-    void wait_exact() {
-        if (pending_exact) (void)hipStreamWaitEvent(stream, pending_exact, 0);
-        pending_exact = nullptr;
     }
     void collect_timing(fnn_stats& s) {
         s.t_scan_s = scan_ms * 1e-3;
@@ -1126,15 +1071,12 @@ struct HipBackend {
             int nt = (tri_tile_count(m_bound, SCR_TH, SCR_R) + d.world - 1) / d.world;
             dim3 gs((unsigned)(nt < scan_grid ? (nt > 0 ? nt : 1) : scan_grid));
             if (e0) (void)hipEventRecord(e0, stream);
-            // the screening pass tolerates the provisional u.Sx of the previous event ...
             if (scan_nt) hipLaunchKernelGGL(k_screen<true>, gs, dim3(256), 0, stream, d);
             else hipLaunchKernelGGL(k_screen<false>, gs, dim3(256), 0, stream, d);
             if (e1) (void)hipEventRecord(e1, stream);
-            wait_exact();  // ... the exact rescans do not
             hipLaunchKernelGGL(k_resolve, dim3(RES_BLOCKS), dim3(1024), 0, stream, d);
             nrecs = RES_BLOCKS;
         } else {
-            wait_exact();
             dim3 gs = scan_dims(d, m_bound);
             if (e0) (void)hipEventRecord(e0, stream);
             if (scan_nt) hipLaunchKernelGGL(k_scan<true>, gs, dim3(SCAN_THREADS), 0, stream, d);
@@ -1151,21 +1093,7 @@ struct HipBackend {
         hipLaunchKernelGGL(k_rx_fill, g1, dim3(256), 0, stream, d, src, nrecs);
         hipLaunchKernelGGL(k_decide4, dim3(1), dim3(CH_T), 0, stream, d, (int)g1.x);
         hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d);
-        // If the next event will be screened, its screening pass can run while the exact
-        // sequential u.Sx sum is evaluated on the second stream.
-        hipEvent_t ea = nullptr, eb = nullptr;
-        if (overlap_exact && use_screen(d, m_bound)) { ea = next_xev(); eb = next_xev(); }
-        if (ea && eb) {
-            hipLaunchKernelGGL(k_sx_approx, dim3(1), dim3(256), 0, stream, d, (int)g1.x + 1);
-            (void)hipEventRecord(ea, stream);  // after k_sx_approx: the exact value must be the LAST write of u.Sx
-            (void)hipStreamWaitEvent(stream2, ea, 0);
-            hipLaunchKernelGGL(k_finalize_exact, dim3(1), dim3(CH_T), 0, stream2, d);
-            (void)hipEventRecord(eb, stream2);
-            pending_exact = eb;
-        } else {
-            hipLaunchKernelGGL(k_sx_approx, dim3(1), dim3(256), 0, stream, d, (int)g1.x + 1);
-            hipLaunchKernelGGL(k_finalize_exact, dim3(1), dim3(CH_T), 0, stream, d);
-        }
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d);
     }
     // single GPU: the whole event
     int32_t launch_event(const Dev& d, int32_t m_bound) {

@@ -44,13 +44,6 @@ struct EmuBackend {
     static constexpr int64_t kColPad = 2048;
     int32_t screen_min_n() const { return 8; }   // tiny on purpose: the CPU tests exercise screening
     int32_t screen_min_m = 8;
-    bool pending = false;
-    int32_t pending_u = 0;
-    double pending_val = 0.0;
-    void flush_pending(const fnn::Dev& d) {
-        if (pending) { d.Sx[pending_u] = pending_val; d.Sx[pending_u + 1] = pending_val; }
-        pending = false;
-    }
     std::string err() const { return "emu"; }
     int32_t open(int32_t) { return FNN_OK; }
     void close() {}
@@ -70,8 +63,7 @@ struct EmuBackend {
     int32_t d2h_2d(double* d, int64_t ldd, const double* s, int64_t lds, int64_t w, int64_t h) {
         return h2d_2d(d, ldd, s, lds, w, h);
     }
-    const fnn::Dev* last_dev = nullptr;
-    int32_t sync() { if (last_dev) flush_pending(*last_dev); return FNN_OK; }
+    int32_t sync() { return FNN_OK; }
     void collect_timing(fnn_stats&) {}
 
     int32_t launch_synth(const fnn::Dev& d, uint64_t seed, int32_t dist) {
@@ -143,7 +135,7 @@ struct EmuBackend {
         fnn::Cand best;
         best.q = fnn::inf_f64();
         best.key = ~0ULL;
-        if (st.done) { flush_pending(d); return best; }
+        if (st.done) return best;
         const int32_t m = st.m, twoP = 2 * st.P;
         const float cm2 = (float)((double)st.c - 2.0), cm2k = fnn::screen_cm2k(st);
         const int32_t nunits = fnn::screen_unit_count(m);
@@ -170,7 +162,6 @@ struct EmuBackend {
             lbrec[u] = b.lb;
             ubrec[u] = b.ub;
         }
-        flush_pending(d);  // stream A waits for the exact sum before k_resolve
         // k_resolve: smallest upper bound, then the units whose lower bound does not exceed it
         float ubg = finf;
         for (int32_t u = 0; u < nunits; u++) ubg = fnn::fminf_(ubg, ubrec[u]);
@@ -198,7 +189,6 @@ struct EmuBackend {
     fnn::Cand scan_local(const fnn::Dev& d) {
         fnn::State& st = *d.st;
         if (d.H && st.m >= screen_min_m) return scan_screened(d);
-        flush_pending(d);
         fnn::Cand best;
         best.q = fnn::inf_f64();
         best.key = ~0ULL;
@@ -222,8 +212,8 @@ struct EmuBackend {
         }
         return best;
     }
-    int32_t launch_event(const fnn::Dev& d, int32_t m_bound) { last_dev = &d; return event_rest(d, m_bound, scan_local(d)); }
-    int32_t launch_event_scan(const fnn::Dev& d, int32_t) { last_dev = &d; d.gsend[0] = scan_local(d); return FNN_OK; }
+    int32_t launch_event(const fnn::Dev& d, int32_t m_bound) { return event_rest(d, m_bound, scan_local(d)); }
+    int32_t launch_event_scan(const fnn::Dev& d, int32_t) { d.gsend[0] = scan_local(d); return FNN_OK; }
     int32_t allgather_on_stream(const fnn::Dev&) { return FNN_ERCCL; }  // no RCCL in the emulation
     int32_t launch_event_rest(const fnn::Dev& d, int32_t m_bound) {
         fnn::Cand best;
@@ -278,34 +268,23 @@ struct EmuBackend {
         // different interleavings (g_update_mode) to expose any conflict between them
         {
             const int32_t nph = fnn::update_special_phases(st);
-            double tree = 0.0;  // tree-ordered (here: thread-order) sum of the new cluster distances
-            auto bulk = [&]() { for (int32_t k : thread_order(m_bound)) tree += fnn::update_bulk(d, k); };
-            auto special = [&](int32_t ph) { for (int32_t i : thread_order(fnn::MAX_S)) tree += fnn::update_special(d, ph, i); };
+            auto bulk = [&]() { for (int32_t k : thread_order(m_bound)) fnn::update_bulk(d, k); };
+            auto special = [&](int32_t ph) { for (int32_t i : thread_order(fnn::MAX_S)) fnn::update_special(d, ph, i); };
             if (g_update_mode == 0) { bulk(); for (int32_t ph = 0; ph < nph; ph++) special(ph); }
             else if (g_update_mode == 1) { for (int32_t ph = 0; ph < nph; ph++) special(ph); bulk(); }
             else {  // bulk split in two halves around the middle phase
                 std::vector<int32_t> ord = thread_order(m_bound);
                 size_t half = ord.size() / 2;
                 for (int32_t ph = 0; ph < nph; ph++) {
-                    if (ph == nph / 2) for (size_t q = 0; q < half; q++) tree += fnn::update_bulk(d, ord[q]);
+                    if (ph == nph / 2) for (size_t q = 0; q < half; q++) fnn::update_bulk(d, ord[q]);
                     special(ph);
                 }
-                for (size_t q = half; q < ord.size(); q++) tree += fnn::update_bulk(d, ord[q]);
+                for (size_t q = half; q < ord.size(); q++) fnn::update_bulk(d, ord[q]);
             }
-            d.upart[0] = tree;
         }
-        // k_sx_approx closes the event with the provisional u.Sx; the exact sequential sum
-        // (k_finalize_exact) runs on a second stream and lands before anything exact reads it.
-        // Emulated by keeping it pending until the next event's screening pass has run.
-        const int32_t U = st.U;
-        const bool fin = st.ev_finish != 0;
         double usx = 0.0;
-        if (!fin) usx = fnn::chain_sum(d.chain, st.m);
-        fnn::finalize_event(d, d.upart[0]);
-        pending = !fin;
-        pending_u = U;
-        pending_val = usx;
-        if (st.done) flush_pending(d);  // the host only reads the state after both streams are idle
+        if (!st.ev_finish) usx = fnn::chain_sum(d.chain, st.m);
+        fnn::finalize(d, usx);
         return FNN_OK;
     }
 };
