@@ -185,10 +185,10 @@ def main():
                 "events": int(st.n_events),
                 "sum_entries": int(st.sum_entries),
                 "algorithmic_bytes": int(scan_bytes),
-                "algorithmic_bytes_note": ("E_t entries per event at 4 B when the event's scan is the fp32 screening pass "
+                "algorithmic_bytes_note": ("E_t entries per event at 2 B when the event's scan is the bf16 screening pass "
                                            "(m >= 8192) or 8 B for the plain fp64 scan, plus the fp64 rescans of the "
                                            "candidate units; 8 * sum E_t would be %d" % int(fp64_equiv)),
-                "screening": {"events": int(st.n_screen_events), "rescanned_units_32x256": int(st.n_rescan_units)},
+                "screening": {"events": int(st.n_screen_events), "rescanned_units_32x512": int(st.n_rescan_units)},
             },
             "hbm_gbps_whole_run": round(scan_bytes / sec / 1e9, 1),
             "hbm_frac_whole_run": round(scan_bytes / sec / 1e9 / (HBM_PEAK_GBPS * max(args.gpus, 1)), 4),
@@ -196,7 +196,7 @@ def main():
             "phases_s": {"init": round(st.t_init_s, 4), "agglomerate": round(st.t_agglom_s, 4),
                          "expand": round(st.t_expand_s, 4), "scan_kernel_sum": round(st.t_scan_s, 4)},
             "roofline": {
-                "kernel": "fnn::k_screen (fp32 pass, 98.9 % of the streamed bytes; fnn::k_scan fp64 for m < 8192)",
+                "kernel": "fnn::k_screen (bf16 pass, 95.8 % of the streamed bytes; fnn::k_scan fp64 for m < 8192)",
                 "bound": "hbm",
                 "achieved": round(scan_gbps, 1),
                 "peak": HBM_PEAK_GBPS,
