@@ -43,6 +43,7 @@ constexpr int OP_AGG3 = 3;  // agg3way: rows X=a, Y=b, Z=c -> new rows U=d, V=e
 constexpr int MAX_OPS = 6;
 
 constexpr int KIND_2WAY = 2, KIND_3WAY = 3, KIND_4WAY = 4, KIND_FINISH = 5;
+constexpr int GATHER_RECS = 64;  // multi-GPU: candidate records a rank may contribute per event
 
 // The net effect of an event's micro-ops on one matrix row, as a recipe over the rows of the
 // matrix BEFORE the event ("o[r]" = old row r), used by the fused update kernel for the
@@ -129,9 +130,10 @@ struct Dev {
     float* srec;     // screening: per unit [tile][4] lower bounds, then [tile][4] upper bounds
     float* stile;    // screening: per tile lower bound, then per tile upper bound
     int32_t* clist;  // screening: units that may hold the true minimum
-    Cand* gsend;     // multi-GPU: this rank's best candidate of the event (1 record)
-    Cand* grecv;     // multi-GPU: all ranks' candidates (world records)
+    Cand* gsend;     // multi-GPU: this rank's candidate record(s) of the event (<= GATHER_RECS)
+    Cand* grecv;     // multi-GPU: all ranks' candidate records
     int32_t rank, world;  // scan sharding: rank scans the tiles with index = rank (mod world)
+    int32_t gather;       // non-zero: candidate records are exchanged between ranks (go to gsend)
     State* st;
     Event* evlog;    // n records (if record_events)
     Agg3Rec* agglog; // n records

@@ -71,6 +71,7 @@ class Engine {
         dev.cstride = round_up(n > 0 ? n : 1, CH_SC);
         dev.rank = 0;
         dev.world = 1;
+        dev.gather = 0;
         size_t nn = (size_t)(n > 0 ? n : 1);
         if (!(dev.D = (double*)be.alloc(sizeof(double) * (size_t)nrows * (size_t)ld)) ||
             !(dev.Sx = (double*)be.alloc(sizeof(double) * (nn + 8))) ||
@@ -83,8 +84,8 @@ class Engine {
             !(dev.srec = (float*)be.alloc(sizeof(float) * (2 * (size_t)screen_unit_count(n > 0 ? n : 1) + 16))) ||
             !(dev.stile = (float*)be.alloc(sizeof(float) * (2 * (size_t)screen_unit_count(n > 0 ? n : 1) / 4 + 16))) ||
             !(dev.clist = (int32_t*)be.alloc(sizeof(int32_t) * SCR_CAP)) ||
-            !(dev.gsend = (Cand*)be.alloc(sizeof(Cand) * 64)) ||
-            !(dev.grecv = (Cand*)be.alloc(sizeof(Cand) * 64)) ||
+            !(dev.gsend = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS)) ||
+            !(dev.grecv = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS * 64)) ||
             !(dev.st = (State*)be.alloc(sizeof(State))) ||
             !(dev.evlog = (Event*)be.alloc(sizeof(Event) * (nn + 8))) ||
             !(dev.agglog = (Agg3Rec*)be.alloc(sizeof(Agg3Rec) * (nn + 8))))
@@ -187,25 +188,29 @@ class Engine {
         rank = rank_;
         dev.world = world_;
         dev.rank = rank_;
+        dev.gather = comm_mode != 0 ? 1 : 0;
         return FNN_OK;
     }
 
-    // one event: scan (+ exchange of the per-rank candidates) + the rest of the sequence
+    // one event: scan (+ exchange of the per-rank candidates) + the rest of the sequence.
+    // A rank contributes nper candidate records (1 after a local reduction, or the scan's
+    // GATHER_RECS per-workgroup records as they are).
     int32_t enqueue_event() {
         if (comm_mode == 0) return be.launch_event(dev, m_bound) == FNN_OK ? FNN_OK : fail(FNN_EHIP, "launch failed (" + be.err() + ")");
-        if (be.launch_event_scan(dev, m_bound) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
+        int32_t nper = 1;
+        if (be.launch_event_scan(dev, m_bound, &nper) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
         if (comm_mode == 1) {
-            if (be.allgather_on_stream(dev) != FNN_OK) return fail(FNN_ERCCL, "all-gather failed (" + be.err() + ")");
+            if (be.allgather_on_stream(dev, nper) != FNN_OK) return fail(FNN_ERCCL, "all-gather failed (" + be.err() + ")");
         } else {
-            Cand mine, all[64];
-            if (be.sync() != FNN_OK || be.d2h(&mine, dev.gsend, sizeof(Cand)) != FNN_OK)
+            std::vector<Cand> mine((size_t)nper), all((size_t)nper * (size_t)world);
+            if (be.sync() != FNN_OK || be.d2h(mine.data(), dev.gsend, sizeof(Cand) * (size_t)nper) != FNN_OK)
                 return fail(FNN_EHIP, "candidate download failed (" + be.err() + ")");
-            if (!host_fn || host_fn(host_ctx, &mine, all, (int32_t)sizeof(Cand)) != 0)
+            if (!host_fn || host_fn(host_ctx, mine.data(), all.data(), (int32_t)(sizeof(Cand) * (size_t)nper)) != 0)
                 return fail(FNN_ERCCL, "host all-gather callback failed");
-            if (be.h2d(dev.grecv, all, sizeof(Cand) * (size_t)world) != FNN_OK)
+            if (be.h2d(dev.grecv, all.data(), sizeof(Cand) * all.size()) != FNN_OK)
                 return fail(FNN_EHIP, "candidate upload failed (" + be.err() + ")");
         }
-        if (be.launch_event_rest(dev, m_bound) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
+        if (be.launch_event_rest(dev, m_bound, nper * world) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
         return FNN_OK;
     }
 

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
 // bound).  Few candidates (the usual case): workgroup 0 rescans them exactly and forms Cx/Cy
 // (single GPU) or this rank's candidate for the all-gather (several GPUs).  Many: all workgroups
 // share the rescans and the last one to arrive finishes.
-constexpr int RES_BLOCKS = 64;
+constexpr int RES_BLOCKS = GATHER_RECS;  // its per-workgroup records go straight into the all-gather
 constexpr int RES_LIST = 4096;
 
 // exact scan of one 32 x 512 unit by a whole 1024-thread workgroup: every thread owns one column
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d) {
     best.q = inf_f64();
     best.key = ~0ULL;
     if (st->done) {  // nothing to scan: leave "no candidate" records
-        if (tid == 0) d.recs[blockIdx.x] = best;
+        if (tid == 0) (d.gather ? d.gsend : d.recs)[blockIdx.x] = best;
         return;
     }
     const int m = st->m;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d) {
     }
     best = block_reduce<16>(best, shc);
     if (tid == 0) {
-        d.recs[blockIdx.x] = best;
+        (d.gather ? d.gsend : d.recs)[blockIdx.x] = best;  // several GPUs: these records are all-gathered
         if (blockIdx.x == 0) {
             st->rescan_all = all ? 1 : 0;
             st->ncand = all ? 0 : count;
@@ -930,9 +930,9 @@ struct HipBackend {
         }
         return FNN_OK;
     }
-    int32_t allgather_on_stream(const Dev& d) {
+    int32_t allgather_on_stream(const Dev& d, int nper) {
         if (!rccl_comm) { comm_err = "RCCL communicator not initialised"; return FNN_ERCCL; }
-        int rc = p_ncclAllGather(d.gsend, d.grecv, sizeof(Cand), /*ncclInt8*/ 0, rccl_comm, stream);
+        int rc = p_ncclAllGather(d.gsend, d.grecv, sizeof(Cand) * (size_t)nper, /*ncclInt8*/ 0, rccl_comm, stream);
         if (rc != 0) { comm_err = std::string("ncclAllGather: ") + (p_ncclGetErrorString ? p_ncclGetErrorString(rc) : "error"); return FNN_ERCCL; }
         return FNN_OK;
     }
@@ -1102,16 +1102,21 @@ struct HipBackend {
         enqueue_rest(d, m_bound, (const Cand*)d.recs, nrecs);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
-    // several GPUs: scan of this rank's tiles + local reduction ... (all-gather) ... the rest
-    int32_t launch_event_scan(const Dev& d, int32_t m_bound) {
+    // several GPUs: scan of this rank's tiles ... (all-gather of the candidate records) ... the rest
+    int32_t launch_event_scan(const Dev& d, int32_t m_bound, int32_t* nper) {
         if (m_bound < 1) m_bound = 1;
         int nrecs = enqueue_scan(d, m_bound);
-        hipLaunchKernelGGL(k_reduce_local, dim3(1), dim3(1024), 0, stream, d, nrecs);
+        if (nrecs == RES_BLOCKS && use_screen(d, m_bound)) {
+            *nper = nrecs;  // k_resolve has written its per-workgroup records straight into d.gsend
+        } else {
+            hipLaunchKernelGGL(k_reduce_local, dim3(1), dim3(1024), 0, stream, d, nrecs);
+            *nper = 1;
+        }
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
-    int32_t launch_event_rest(const Dev& d, int32_t m_bound) {
+    int32_t launch_event_rest(const Dev& d, int32_t m_bound, int32_t ntotal) {
         if (m_bound < 1) m_bound = 1;
-        enqueue_rest(d, m_bound, (const Cand*)d.grecv, d.world);
+        enqueue_rest(d, m_bound, (const Cand*)d.grecv, ntotal);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
 };

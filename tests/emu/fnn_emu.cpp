@@ -213,13 +213,21 @@ struct EmuBackend {
         return best;
     }
     int32_t launch_event(const fnn::Dev& d, int32_t m_bound) { return event_rest(d, m_bound, scan_local(d)); }
-    int32_t launch_event_scan(const fnn::Dev& d, int32_t) { d.gsend[0] = scan_local(d); return FNN_OK; }
-    int32_t allgather_on_stream(const fnn::Dev&) { return FNN_ERCCL; }  // no RCCL in the emulation
-    int32_t launch_event_rest(const fnn::Dev& d, int32_t m_bound) {
+    int32_t launch_event_scan(const fnn::Dev& d, int32_t, int32_t* nper) {
+        // contribute 3 records (the real one plus two "none") to exercise the multi-record exchange
+        fnn::Cand none;
+        none.q = fnn::inf_f64();
+        none.key = ~0ULL;
+        d.gsend[0] = none; d.gsend[1] = scan_local(d); d.gsend[2] = none;
+        *nper = 3;
+        return FNN_OK;
+    }
+    int32_t allgather_on_stream(const fnn::Dev&, int32_t) { return FNN_ERCCL; }  // no RCCL in the emulation
+    int32_t launch_event_rest(const fnn::Dev& d, int32_t m_bound, int32_t ntotal) {
         fnn::Cand best;
         best.q = fnn::inf_f64();
         best.key = ~0ULL;
-        for (int32_t r = 0; r < d.world; r++)
+        for (int32_t r = 0; r < ntotal; r++)
             if (fnn::cand_better(d.grecv[r], best)) best = d.grecv[r];
         return event_rest(d, m_bound, best);
     }

@@ -12,8 +12,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_ranks(backend, world, n, seed, dist_name, tmp_path, port):
+def run_ranks(backend, world, n, seed, dist_name, tmp_path, port, extra_env=None):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
+    env.update(extra_env or {})
     procs = []
     for r in range(world):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
@@ -50,9 +51,13 @@ def test_emulation_over_gloo(emu_api, oracle, tmp_path, world, n, seed, dist_nam
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,n,seed,dist_name", [(2, 600, 1, "uniform53"), (3, 300, 2, "dec4")])
-def test_hip_ranks_sharing_one_gpu(hip_api, oracle, tmp_path, world, n, seed, dist_name):
-    res = run_ranks("hip", world, n, seed, dist_name, tmp_path, 29611 + world)
+@pytest.mark.parametrize("world,n,seed,dist_name,screen", [(2, 600, 1, "uniform53", False), (3, 300, 2, "dec4", False),
+                                                        (2, 1500, 3, "uniform53", True), (3, 700, 4, "dec4", True)])
+def test_hip_ranks_sharing_one_gpu(hip_api, oracle, tmp_path, world, n, seed, dist_name, screen):
+    # screen=True: the bf16 screening pass + k_resolve forced on at small n, so that every rank
+    # contributes its 64 per-workgroup records to the exchange
+    extra = {"FNN_SCREEN_MIN_N": "8", "FNN_SCREEN_MIN_M": "64"} if screen else None
+    res = run_ranks("hip", world, n, seed, dist_name, tmp_path, 29611 + world + (7 if screen else 0), extra)
     check(res, oracle, n, seed, dist_name)
 
 
