@@ -206,3 +206,21 @@ def test_screened_run_equals_plain_fp64_run(hip_api):
     for f in ("m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id", "entries"):
         assert (e0[f] == e1[f]).all(), f
     assert (bits(e0["best"]) == bits(e1["best"])).all()
+
+
+def test_screened_run_against_the_oracle(hip_api, oracle):
+    """n just above the screening threshold: the first ~45 % of the events go through the bf16
+    screening pass + exact rescans; the whole trajectory must equal the oracle's."""
+    n = 8704
+    D = oracle.synth(n, 12)
+    o_ref, ev_ref, se = oracle.run(D, threads=16)
+    with Handle(hip_api, n, validate=True, record_events=True) as h:
+        h.set_matrix(D, chunk_rows=1024)
+        order, st = h.run()
+        ev = h.events()
+    assert st.n_screen_events > 2000
+    assert (order == o_ref).all()
+    assert st.sum_entries == se and st.n_events == len(ev_ref)
+    for f in ("m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id", "entries"):
+        assert (ev[f] == ev_ref[f]).all(), f
+    assert (bits(ev["best"]) == bits(ev_ref["best"])).all()
