@@ -90,7 +90,7 @@ struct State {
     int32_t screen_ok;     // the bound is valid for this matrix (finite, |D| < 1e37)
     int32_t rescan_all;    // candidate list overflowed: rescan every unit
     int32_t ncand;         // units in clist
-    int32_t res_ticket;    // arrival counter of k_resolve's workgroups
+    int32_t pad_scr;
     uint64_t dmax_bits;    // bit pattern of max |D| over the input matrix
     int64_t n_rescan_units, n_screen_events;  // statistics
     int64_t bytes_streamed;  // matrix bytes the scans had to stream: 2 (bf16 pass) or 8 per entry + rescans
@@ -105,7 +105,7 @@ struct State {
     Op ops[MAX_OPS];
     Event cur;
     double rx[4];  // exact ComputeRx results for Cx, Cx.nbr, Cy, Cy.nbr (only when not certified)
-    int32_t rx_ticket;          // arrival counter of the exact-chain workgroups
+    int32_t pad_rx;
     int32_t force_exact_rx;     // diagnostic: never certify (tests the exact path)
     int64_t n_rx_certified, n_rx_exact;  // statistics
     // fused update (k_update): slots involved in the event, and the recipes of the rows that change

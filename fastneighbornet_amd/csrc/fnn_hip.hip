@@ -10,8 +10,9 @@
 //   k_scan      all-pairs Q-criterion argmin over the lower triangle of the live
 //               m x m block (NeighborNetCanonical.java:151-178).  HBM-bound: reads
 //               each live matrix entry once, 16 B per lane, 1 KiB per wave-load.
-//   k_screen    fp/bf16 screening pass of the scan for events with many live nodes, k_resolve: exact
-//               fp64 rescan of the few units that can hold the minimum
+//   k_screen    events with >= 8192 live nodes: the same scan as a bracketing pass over the bf16
+//               copy of the matrix (2 B per entry); k_resolve: exact fp64 rescan of the few
+//               32 x 512 units that can hold the minimum
 //   k_rx_fill   reduce the per-block records, form Cx/Cy (NetMakerOriginal.java:376-380); ComputeRx
 //               terms in reference position order (:549-561) + tree partial sums
 //   k_decide4   candidate choice (:413-452) certified from the partial sums, else from the <=4
@@ -19,7 +20,9 @@
 //   k_update    fused: subtractClusterDistance x2 per node (:455-461, 681-696), the net effect of
 //               the plan's micro-ops (agg3way row/column rewrite :653-656, slot swaps / moves)
 //               and updateClusterDistances' per-node part (:520-531)
-//   k_finalize  sequential u.Sx sum (:532), event log, loop condition (:339)
+//   k_finalize  exact sequential u.Sx sum (:532), event log, loop condition (:339)
+// Several GPUs: every rank scans 1/world of the tiles; the candidate records are all-gathered
+// (k_reduce_local + ncclAllGather) between the scan and k_rx_fill.
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -68,7 +71,7 @@ __device__ __forceinline__ Cand block_reduce(Cand c, Cand* sh) {
 // Tiles of SCAN_TH rows x SCAN_TW columns cover the lower triangle of the live m x m block.
 // Row tiles come in bands of R = SCAN_TW / SCAN_TH; every row tile of band g owns g + 1 column
 // tiles (fnn_core.h: tri_tile_count / tri_tile_decode).  A fixed-size grid strides over the
-// linear tile index (no empty workgroups, at most gridDim.x records for k_pick).
+// linear tile index (no empty workgroups, at most gridDim.x records for k_rx_fill).
 constexpr int SCAN_R = SCAN_TW / SCAN_TH;
 
 __host__ __device__ inline int scan_tile_count(int m) { return tri_tile_count(m, SCAN_TH, SCAN_R); }
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(256) void k_prep_screen(Dev d, int64_t nrows) {
     }
 }
 
-// ------------------------------------------------------------------ k_pick
+// ------------------------------------------------------------------ record reduction
 __device__ __forceinline__ Cand reduce_records(const Dev& d, const Cand* src, int nrecs, Cand* sh) {
     Cand best;
     best.q = inf_f64();

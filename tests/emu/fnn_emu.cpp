@@ -111,7 +111,7 @@ struct EmuBackend {
         return FNN_OK;
     }
 
-    // exact scan of one 32 x 256 unit (k_rescan)
+    // exact scan of one 32 x 512 unit (k_resolve)
     void rescan_unit(const fnn::Dev& d, int32_t u, fnn::Cand& best) {
         fnn::State& st = *d.st;
         const int32_t m = st.m, twoP = 2 * st.P;
@@ -234,7 +234,7 @@ struct EmuBackend {
 
     int32_t event_rest(const fnn::Dev& d, int32_t m_bound, fnn::Cand best) {
         fnn::State& st = *d.st;
-        // k_pick
+        // pick (done by workgroup 0 of k_rx_fill on the GPU)
         int32_t zs[4];
         const bool zneed = fnn::pick_slots(d, best, zs);  // what the other workgroups of k_rx_fill derive
         fnn::pick(d, best);
