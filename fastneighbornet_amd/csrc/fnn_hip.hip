@@ -180,6 +180,8 @@ __device__ __forceinline__ void brk_fast(float dm, float am, float cm2, float cm
 // block, and with all rows / all columns of one kind (two-node clusters or singletons).
 enum { SCR_GENERIC = 0, SCR_PP = 1, SCR_SP = 2, SCR_SS = 3 };
 
+constexpr int SCR_BATCH = 4;  // row pairs (2 x 16-byte loads each) a thread keeps in flight
+
 template <bool NT, int CLS>
 __device__ __forceinline__ void screen_tile_fast(const Dev& d, int rbase, int c0, float cm2, float cm2k, float (&lb)[4], float (&ub)[4]) {
     float sxc[8];
@@ -191,16 +193,16 @@ __device__ __forceinline__ void screen_tile_fast(const Dev& d, int rbase, int c0
     }
     const uint16_t* colbase = d.H + c0;
 #pragma unroll 1
-    for (int half = 0; half < SCR_TH / 16; half++) {
-        const int rb = rbase + 16 * half;
-        uint4 a[8], b[8];
+    for (int part = 0; part < SCR_TH / (2 * SCR_BATCH); part++) {
+        const int rb = rbase + 2 * SCR_BATCH * part;
+        uint4 a[SCR_BATCH], b[SCR_BATCH];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < SCR_BATCH; k++) {
             a[k] = ld16h<NT>(colbase + (int64_t)(rb + 2 * k) * d.ld);
             b[k] = ld16h<NT>(colbase + (int64_t)(rb + 2 * k + 1) * d.ld);
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < SCR_BATCH; k++) {
             const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + rb + 2 * k);
             const float s0 = (float)sxr.x, s1 = (float)sxr.y;
             const unsigned aw[4] = {a[k].x, a[k].y, a[k].z, a[k].w};
@@ -271,18 +273,18 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
             }
             const uint16_t* colbase = d.H + c0;
 #pragma unroll 1
-            for (int half = 0; half < SCR_TH / 16; half++) {
-                const int rb = rbase + 16 * half;
+            for (int part = 0; part < SCR_TH / (2 * SCR_BATCH); part++) {
+                const int rb = rbase + 2 * SCR_BATCH * part;
                 if (rb >= m) break;
-                uint4 a[8], b[8];
+                uint4 a[SCR_BATCH], b[SCR_BATCH];
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < SCR_BATCH; k++) {
                     const int r0 = rb + 2 * k;  // rows < nrows (padded), c0 + 7 < ld (ld padded to 2048)
                     a[k] = ld16h<NT>(colbase + (int64_t)r0 * d.ld);
                     b[k] = ld16h<NT>(colbase + (int64_t)(r0 + 1) * d.ld);
                 }
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < SCR_BATCH; k++) {
                     const int r0 = rb + 2 * k;
                     const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + r0);
                     const float sxr0 = (float)sxr.x, sxr1 = (float)sxr.y;
