@@ -119,7 +119,7 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         sharded = int(flag.item()) == 1
         if sharded:
-            parallelism = (f"scan sharded over {world} ranks (tile index mod {world}), matrix replicated, one 16-byte "
+            parallelism = (f"scan sharded over {world} ranks (tile index mod {world}), matrix replicated, one <=1 KiB "
                            f"all-gather per event ({'gloo host callback' if same_gpu else 'RCCL on stream'})")
         else:
             if h is not None:
@@ -228,6 +228,8 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
+    if h is not None:
+        h.close()  # every rank releases its engine (and its RCCL communicator) before the group goes away
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

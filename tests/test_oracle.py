@@ -108,3 +108,22 @@ def test_synth_generator_properties(oracle):
     # SplitMix64 reference values (seed 0: first outputs of the published algorithm)
     import ctypes
     assert (D != oracle.synth(50, 2)).any()
+
+
+def test_frozen_oracle_vectors(oracle):
+    """tests/golden/oracle_orders.json freezes the oracle's own outputs (generator script next
+    to it); a change of the restatement, of the generator or of the build flags shows up here."""
+    import hashlib
+    g = json.load(open(os.path.join(HERE, "golden", "oracle_orders.json")))
+    assert len(g["cases"]) >= 20
+    for c in g["cases"]:
+        D = oracle.synth(c["n"], c["seed"], c["dist"])
+        assert hashlib.sha256(D.tobytes()).hexdigest() == c["matrix_sha256"]
+        order, ev, se = oracle.run(D)
+        if c["order"] is not None:
+            assert order.tolist() == c["order"]
+        assert hashlib.sha256(order.tobytes()).hexdigest() == c["order_sha256"]
+        traj = ev[["m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id"]].tobytes()
+        assert hashlib.sha256(traj).hexdigest() == c["trajectory_sha256"]
+        assert hashlib.sha256(ev["best"].tobytes()).hexdigest() == c["best_bits_sha256"]
+        assert se == c["sum_entries"]
