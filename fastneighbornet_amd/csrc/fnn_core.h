@@ -90,7 +90,7 @@ struct State {
     int32_t screen_ok;     // the bound is valid for this matrix (finite, |D| < 1e37)
     int32_t rescan_all;    // candidate list overflowed: rescan every unit
     int32_t ncand;         // units in clist
-    int32_t pad_scr;
+    int32_t nonneg;        // no negative entry in the input matrix (then none ever appears)
     uint64_t dmax_bits;    // bit pattern of max |D| over the input matrix
     int64_t n_rescan_units, n_screen_events;  // statistics
     int64_t bytes_streamed;  // matrix bytes the scans had to stream: 2 (bf16 pass) or 8 per entry + rescans
@@ -269,6 +269,12 @@ FNN_HD float screen_delta(const State& st) {
 }
 // (c - 2) * kappa, rounded up
 FNN_HD float screen_cm2k(const State& st) { return (float)(((double)st.c - 2.0) * (double)SCR_KAPPA * 1.000001); }
+
+// For matrices without negative entries mean|h| == mean h, so LB / UB are affine in the mean:
+// LB = k1 * mean - Sp - Sq with k1 <= (c-2)(1 - kappa) and UB = k2 * mean - Sp - Sq with
+// k2 >= (c-2)(1 + kappa); the coefficients are rounded in the safe direction.
+FNN_HD float screen_k1(const State& st) { return (float)((((double)st.c - 2.0) * (1.0 - (double)SCR_KAPPA * 1.000001)) * (1.0 - 2e-7)); }
+FNN_HD float screen_k2(const State& st) { return (float)((((double)st.c - 2.0) * (1.0 + (double)SCR_KAPPA * 1.000001)) * (1.0 + 2e-7)); }
 
 FNN_HD float fminf_(float a, float b) { return __builtin_fminf(a, b); }  // v_min_f32 (no NaN arises when screen_ok)
 FNN_HD float fabsf_(float a) { return __builtin_fabsf(a); }             // a source modifier on the GPU

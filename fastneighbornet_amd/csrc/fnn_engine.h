@@ -160,6 +160,7 @@ class Engine {
         std::memset(&hst, 0, sizeof(hst));
         hst.n = n; hst.m = n; hst.c = n; hst.P = 0; hst.num_nodes = n;
         hst.done = (n <= 3) ? 1 : 0;  // :133-140
+        hst.nonneg = 1;                // cleared by the prep kernel if a negative entry exists
         hst.record_events = opts.record_events ? 1 : 0;
         hst.force_exact_rx = opts.force_exact_rx ? 1 : 0;
         if (be.h2d(dev.st, &hst, sizeof(State)) != FNN_OK)

@@ -228,6 +228,70 @@ __device__ __forceinline__ void screen_tile_fast(const Dev& d, int rbase, int c0
     }
 }
 
+// The same for matrices without negative entries (the usual case: distances): mean|h| == mean h,
+// the brackets are affine in the sum of the entries (coefficients screen_k1 / screen_k2, with
+// the 1/2, 1/4 of the mean folded in), and the per-column term -Sq is applied once per tile
+// (x -> fl(x - Sq) is monotone, so it commutes with the running minimum).  ~5 instead of ~9
+// VALU instructions per entry; the pass is VALU-bound (SQ_ACTIVE_INST_VALU ~ 80 % of a SIMD).
+template <bool NT, int CLS>
+__device__ __forceinline__ void screen_tile_nonneg(const Dev& d, int rbase, int c0, float k1, float k2, float (&lb)[4], float (&ub)[4]) {
+    constexpr int NA = (CLS == SCR_SS) ? 8 : 4;
+    float al[NA], au[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) { al[i] = __builtin_inff(); au[i] = __builtin_inff(); }
+    const float f = (CLS == SCR_PP) ? 0.25f : (CLS == SCR_SP) ? 0.5f : 1.0f;
+    const float a1 = k1 * f, a2 = k2 * f;  // exact scalings
+    const uint16_t* colbase = d.H + c0;
+#pragma unroll 1
+    for (int part = 0; part < SCR_TH / (2 * SCR_BATCH); part++) {
+        const int rb = rbase + 2 * SCR_BATCH * part;
+        uint4 a[SCR_BATCH], b[SCR_BATCH];
+#pragma unroll
+        for (int k = 0; k < SCR_BATCH; k++) {
+            a[k] = ld16h<NT>(colbase + (int64_t)(rb + 2 * k) * d.ld);
+            b[k] = ld16h<NT>(colbase + (int64_t)(rb + 2 * k + 1) * d.ld);
+        }
+#pragma unroll
+        for (int k = 0; k < SCR_BATCH; k++) {
+            const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + rb + 2 * k);
+            const float s0 = (float)sxr.x, s1 = (float)sxr.y;
+            const unsigned aw[4] = {a[k].x, a[k].y, a[k].z, a[k].w};
+            const unsigned bw[4] = {b[k].x, b[k].y, b[k].z, b[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float e00 = bf_lo(aw[j]), e01 = bf_hi(aw[j]), e10 = bf_lo(bw[j]), e11 = bf_hi(bw[j]);
+                if (CLS == SCR_PP) {
+                    const float sum = ((e00 + e01) + e10) + e11;
+                    al[j] = __builtin_fminf(al[j], __builtin_fmaf(a1, sum, -s0));
+                    au[j] = __builtin_fminf(au[j], __builtin_fmaf(a2, sum, -s0));
+                } else if (CLS == SCR_SP) {
+                    const float t0 = e00 + e01, t1 = e10 + e11;
+                    al[j] = __builtin_fminf(al[j], __builtin_fminf(__builtin_fmaf(a1, t0, -s0), __builtin_fmaf(a1, t1, -s1)));
+                    au[j] = __builtin_fminf(au[j], __builtin_fminf(__builtin_fmaf(a2, t0, -s0), __builtin_fmaf(a2, t1, -s1)));
+                } else {
+                    al[2 * j] = __builtin_fminf(al[2 * j], __builtin_fminf(__builtin_fmaf(a1, e00, -s0), __builtin_fmaf(a1, e10, -s1)));
+                    au[2 * j] = __builtin_fminf(au[2 * j], __builtin_fminf(__builtin_fmaf(a2, e00, -s0), __builtin_fmaf(a2, e10, -s1)));
+                    al[2 * j + 1] = __builtin_fminf(al[2 * j + 1], __builtin_fminf(__builtin_fmaf(a1, e01, -s0), __builtin_fmaf(a1, e11, -s1)));
+                    au[2 * j + 1] = __builtin_fminf(au[2 * j + 1], __builtin_fminf(__builtin_fmaf(a2, e01, -s0), __builtin_fmaf(a2, e11, -s1)));
+                }
+            }
+        }
+    }
+    // the column terms, once per tile
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const double2 sv = *reinterpret_cast<const double2*>(d.Sx + c0 + 2 * j);
+        const float q0 = (float)sv.x, q1 = (float)sv.y;
+        if (CLS == SCR_SS) {
+            lb[j] = __builtin_fminf(al[2 * j] - q0, al[2 * j + 1] - q1);
+            ub[j] = __builtin_fminf(au[2 * j] - q0, au[2 * j + 1] - q1);
+        } else {
+            lb[j] = al[j] - q0;
+            ub[j] = au[j] - q0;
+        }
+    }
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void k_screen(Dev d) {
     __shared__ float shl[4], shu[4];
@@ -237,6 +301,8 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
     const int twoP = 2 * st->P;
     const float cm2 = (float)((double)st->c - 2.0);
     const float cm2k = screen_cm2k(*st);
+    const float k1 = screen_k1(*st), k2 = screen_k2(*st);
+    const bool nonneg = st->nonneg != 0;
     const int ntiles = tri_tile_count(m, SCR_TH, SCR_R);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float* lbrec = d.srec;
@@ -257,7 +323,12 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
             else if (cbase >= twoP) cls = SCR_SS;
             else if (rbase >= twoP && cbase + SCR_TW <= twoP) cls = SCR_SP;
         }
-        if (cls == SCR_PP) screen_tile_fast<NT, SCR_PP>(d, rbase, c0, cm2, cm2k, lbv, ubv);
+        if (cls != SCR_GENERIC && nonneg) {
+            if (cls == SCR_PP) screen_tile_nonneg<NT, SCR_PP>(d, rbase, c0, k1, k2, lbv, ubv);
+            else if (cls == SCR_SS) screen_tile_nonneg<NT, SCR_SS>(d, rbase, c0, k1, k2, lbv, ubv);
+            else screen_tile_nonneg<NT, SCR_SP>(d, rbase, c0, k1, k2, lbv, ubv);
+        }
+        else if (cls == SCR_PP) screen_tile_fast<NT, SCR_PP>(d, rbase, c0, cm2, cm2k, lbv, ubv);
         else if (cls == SCR_SS) screen_tile_fast<NT, SCR_SS>(d, rbase, c0, cm2, cm2k, lbv, ubv);
         else if (cls == SCR_SP) screen_tile_fast<NT, SCR_SP>(d, rbase, c0, cm2, cm2k, lbv, ubv);
         else if (c0 < m && c0 <= rbase + SCR_TH - 2) {
@@ -436,6 +507,7 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d) {
 __global__ __launch_bounds__(256) void k_prep_screen(Dev d, int64_t nrows) {
     __shared__ unsigned long long shmax[4];
     unsigned long long b = 0;
+    int neg = 0;
     const int64_t total = nrows * d.ld;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const double v = d.D[i];
@@ -444,6 +516,7 @@ __global__ __launch_bounds__(256) void k_prep_screen(Dev d, int64_t nrows) {
         if (r < d.n && c < d.n) {
             const unsigned long long x = f2u(v) & 0x7FFFFFFFFFFFFFFFULL;
             b = x > b ? x : b;
+            if (v < 0.0) neg = 1;
         }
     }
 #pragma unroll
@@ -458,6 +531,7 @@ __global__ __launch_bounds__(256) void k_prep_screen(Dev d, int64_t nrows) {
         for (int k = 1; k < 4; k++) x = shmax[k] > x ? shmax[k] : x;
         if (x) atomicMax(reinterpret_cast<unsigned long long*>(&d.st->dmax_bits), x);
     }
+    if (__any(neg) && (threadIdx.x & 63) == 0) d.st->nonneg = 0;  // (set to 1 before the launch)
 }
 
 // ------------------------------------------------------------------ record reduction

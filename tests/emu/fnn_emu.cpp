@@ -103,6 +103,9 @@ struct EmuBackend {
                 if (r < d.n && c < d.n && b > mx) mx = b;
             }
         d.st->dmax_bits = mx;
+        for (int64_t r = 0; r < d.n; r++)
+            for (int64_t c = 0; c < d.n; c++)
+                if (d.D[r * d.ld + c] < 0.0) d.st->nonneg = 0;
         return FNN_OK;
     }
 
