@@ -20,7 +20,8 @@ KIND_2WAY, KIND_3WAY, KIND_4WAY, KIND_FINISH = 2, 3, 4, 5
 
 class FnnOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("validate", C.c_int32), ("record_events", C.c_int32),
-                ("force_exact_rx", C.c_int32), ("disable_screen", C.c_int32), ("reserved", C.c_int32 * 11)]
+                ("force_exact_rx", C.c_int32), ("disable_screen", C.c_int32), ("lookahead", C.c_int32),
+                ("lookahead_pairs", C.c_int32), ("reserved", C.c_int32 * 9)]
 
 
 class FnnEvent(C.Structure):
@@ -38,7 +39,9 @@ class FnnStats(C.Structure):
                 ("t_agglom_s", C.c_double), ("t_expand_s", C.c_double), ("t_total_s", C.c_double),
                 ("t_scan_s", C.c_double), ("scan_launches", C.c_int64), ("scan_bytes", C.c_int64),
                 ("n_rx_certified", C.c_int64), ("n_rx_exact", C.c_int64), ("n_screen_events", C.c_int64),
-                ("n_rescan_units", C.c_int64), ("reserved", C.c_int64 * 4)]
+                ("n_rescan_units", C.c_int64), ("n_base_scans", C.c_int64), ("n_window_hits", C.c_int64),
+                ("n_window_fails", C.c_int64), ("window_pairs", C.c_int64), ("bytes_total", C.c_int64),
+                ("reserved", C.c_int64 * 7)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -106,7 +109,8 @@ class Handle:
     """Thin RAII wrapper over an engine handle of either library."""
 
     def __init__(self, api: Api, n: int, device: int = 0, validate: bool = False,
-                 record_events: bool = False, force_exact_rx: bool = False, disable_screen: bool = False):
+                 record_events: bool = False, force_exact_rx: bool = False, disable_screen: bool = False,
+                 lookahead: int = 0, lookahead_pairs: int = 0):
         self.api = api
         self.n = int(n)
         opts = FnnOpts()
@@ -115,6 +119,8 @@ class Handle:
         opts.record_events = 1 if record_events else 0
         opts.force_exact_rx = 1 if force_exact_rx else 0
         opts.disable_screen = 1 if disable_screen else 0
+        opts.lookahead = lookahead
+        opts.lookahead_pairs = lookahead_pairs
         h = C.c_void_p()
         api.check(api.create(self.n, C.byref(opts), C.byref(h)))
         self._h = h

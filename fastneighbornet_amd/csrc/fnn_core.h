@@ -95,6 +95,29 @@ struct State {
     int64_t n_rescan_units, n_screen_events;  // statistics
     int64_t bytes_streamed;  // matrix bytes the scans had to stream: 2 (bf16 pass) or 8 per entry + rescans
     int32_t ev_screened, pad_scr2;
+    // ---- lookahead window (see "Lookahead" below) ----
+    int32_t la_on;          // configured: windows enabled (single rank, screening copy present)
+    int32_t la_K;           // events one window may serve
+    int32_t la_target;      // wanted number of tracked pairs per window
+    int32_t la_min_m;       // windows only while m >= la_min_m (the screened regime)
+    int32_t la_valid;       // a window is open
+    int32_t la_k;           // events completed since the window's base scan (the base event included)
+    int32_t la_np;          // tracked pairs
+    int32_t la_nf;          // clusters created since the base scan ("fresh")
+    int32_t la_hit;         // this event's minimum came from the window (k_track)
+    int32_t la_emit;        // this event's screening pass emits the pairs of a new window
+    int32_t la_count;       // emission counter
+    int32_t la_pcap;        // capacity of the tracked-pair list (<= LA_PCAP)
+    int32_t la_skip, la_backoff;  // after an overflow: base scans that do not try to open a window
+    int32_t la_base_stamp;  // n_events at the base scan: clusters stamped later are fresh
+    int32_t la_have_mprev;
+    float la_theta_pred;    // emission threshold of the open / opening window (fp32)
+    double la_theta_eff;    // acceptance threshold: theta_pred minus the error slack
+    double la_W;            // window width above the previous event's minimum
+    double la_mprev;        // previous event's scan minimum
+    int64_t n_base_scans, n_la_hits, n_la_fail, n_la_overflow, la_pairs_sum, la_items_sum;
+    int32_t ev_timed, pad_la;  // the host brackets this event's scan launch with HIP events
+    int64_t bytes_timed;      // the part of bytes_streamed that belongs to timed scan launches
     // ---- current event ----
     int32_t ev_active, ev_finish, need_rx;
     int32_t sa, sap, sb, sbp;  // slots of Cx, Cx.nbr, Cy, Cy.nbr (-1: none)
@@ -130,8 +153,14 @@ struct Dev {
     float* srec;     // screening: per unit [tile][4] lower bounds, then [tile][4] upper bounds
     float* stile;    // screening: per tile lower bound, then per tile upper bound
     int32_t* clist;  // screening: units that may hold the true minimum
+    int32_t* islot;  // lookahead: node id -> slot (-1: dead); 3n + 8 entries
+    int32_t* cstamp; // lookahead: node id -> n_events + 1 when its current cluster was formed (0: initial)
+    int32_t* tpairs; // lookahead: tracked pairs, 2 node ids each (LA_PCAP pairs)
+    int32_t* fresh;  // lookahead: per fresh cluster {representative id, stamp} (LA_KMAX entries)
+    uint32_t* ticket; // lookahead: arrival counter of k_track's workgroups
     Cand* gsend;     // multi-GPU: this rank's candidate record(s) of the event (<= GATHER_RECS)
     Cand* grecv;     // multi-GPU: all ranks' candidate records
+    int32_t la;      // lookahead windows enabled for this run (k_track is part of the launch sequence)
     int32_t rank, world;  // scan sharding: rank scans the tiles with index = rank (mod world)
     int32_t gather;       // non-zero: candidate records are exchanged between ranks (go to gsend)
     State* st;
@@ -272,8 +301,14 @@ FNN_HD float screen_cm2k(const State& st) { return (float)(((double)st.c - 2.0) 
 
 // For matrices without negative entries mean|h| == mean h, so LB / UB are affine in the mean:
 // LB = k1 * mean - Sp - Sq with k1 <= (c-2)(1 - kappa) and UB = k2 * mean - Sp - Sq with
-// k2 >= (c-2)(1 + kappa); the coefficients are rounded in the safe direction.
-FNN_HD float screen_k1(const State& st) { return (float)((((double)st.c - 2.0) * (1.0 - (double)SCR_KAPPA * 1.000001)) * (1.0 - 2e-7)); }
+// k2 >= (c-2)(1 + kappa); the coefficients are rounded in the safe direction.  With lookahead
+// windows on, the lower bound uses (c - 2 - K) instead of (c - 2): it then also bounds the pair's
+// Q in each of the next K events (see "Lookahead" below); it is merely a little looser now.
+FNN_HD float screen_k1(const State& st) {
+    double cc = (double)st.c - 2.0 - (st.la_on ? (double)st.la_K : 0.0);
+    if (cc < 0.0) cc = 0.0;
+    return (float)((cc * (1.0 - (double)SCR_KAPPA * 1.000001)) * (1.0 - 2e-7));
+}
 FNN_HD float screen_k2(const State& st) { return (float)((((double)st.c - 2.0) * (1.0 + (double)SCR_KAPPA * 1.000001)) * (1.0 + 2e-7)); }
 
 FNN_HD float fminf_(float a, float b) { return __builtin_fminf(a, b); }  // v_min_f32 (no NaN arises when screen_ok)
@@ -313,6 +348,41 @@ FNN_HD void screen_micro(int32_t r0, int32_t c0, int32_t m, int32_t twoP, float 
     }
 }
 
+// The same block for matrices without negative entries: affine brackets (screen_k1 / screen_k2).
+// `emit(row slot, column slot, lb)` is called for every pair of the block with its lower bound
+// (the lookahead window's emission pass; a no-op functor for plain bracketing).
+template <class Emit>
+FNN_HD void screen_micro_nn(int32_t r0, int32_t c0, int32_t m, int32_t twoP, float k1, float k2,
+                            float e00, float e01, float e10, float e11,
+                            float sxr0, float sxr1, float sxc0, float sxc1, Brk& b, Emit&& emit) {
+    if (r0 >= m || c0 >= m || c0 > r0) return;
+    auto take = [&](float mean, float sp, float sq, int32_t rs, int32_t cs) {
+        const float lb = __builtin_fmaf(k1, mean, -sp) - sq;
+        const float ub = __builtin_fmaf(k2, mean, -sp) - sq;
+        b.lb = fminf_(b.lb, lb);
+        b.ub = fminf_(b.ub, ub);
+        emit(rs, cs, lb);
+    };
+    if (r0 < twoP) {
+        if (r0 == c0) return;
+        take((((e00 + e01) + e10) + e11) * 0.25f, sxr0, sxc0, r0, c0);
+    } else if (c0 < twoP) {
+        take((e00 + e01) * 0.5f, sxr0, sxc0, r0, c0);
+        if (r0 + 1 < m) take((e10 + e11) * 0.5f, sxr1, sxc0, r0 + 1, c0);
+    } else {
+        const bool c1ok = (c0 + 1 < m), r1ok = (r0 + 1 < m);
+        if (r0 > c0) {
+            take(e00, sxr0, sxc0, r0, c0);
+            if (c1ok) take(e01, sxr0, sxc1, r0, c0 + 1);
+            if (r1ok) {
+                take(e10, sxr1, sxc0, r0 + 1, c0);
+                if (c1ok) take(e11, sxr1, sxc1, r0 + 1, c0 + 1);
+            }
+        } else if (r1ok) take(e10, sxr1, sxc0, r0 + 1, c0);
+    }
+}
+struct NoEmit { FNN_HD void operator()(int32_t, int32_t, float) const {} };
+
 // triangular tile bookkeeping, shared by the exact scan (R = 16) and the screening pass (R = 32):
 // row tiles of TH rows come in bands of R; a row tile of band g owns g + 1 column tiles
 FNN_HD int32_t tri_tile_count(int32_t m, int32_t TH, int32_t R) {
@@ -340,6 +410,173 @@ FNN_HD void store_d(const Dev& d, int64_t idx, double v) {
 }
 
 // ---------------------------------------------------------------------------
+// Lookahead windows: one screening pass serves up to K events.
+//
+// For a matrix without negative entries and two clusters P, Q that take part in none of the
+// events t .. t+k-1:
+//   * D(P,Q) does not change (only rows / columns of merged nodes are rewritten);
+//   * the coefficient c - 2 drops by one per event, so (c_t - 2 - k) D(P,Q) >= (c_t - 2 - K) D(P,Q);
+//   * S_P never grows: an event replaces the distances to the two merged clusters X, Y by the
+//     distance to the new cluster, and D(P,new) <= D(P,X) + D(P,Y) for all three merge shapes
+//     (2-way: (x+y)/2;  3-way: (x+y+z)/3 against x + (y+z)/2;  4-way: (2(x2+x+y)/3 + y2)/3
+//     against (x2+x)/2 + (y+y2)/2; all entries >= 0), up to a few ulps of rounding.
+// Hence  Q_{t+k}(P,Q) >= (c_t - 2 - K) D(P,Q) - S_P(t) - S_Q(t)  for every k <= K, and the
+// screening pass of event t, run with the coefficient (c_t - 2 - K)(1 - kappa) (screen_k1),
+// yields a lower bound LB_K of the pair's Q in all of the next K events.
+//
+// A base scan therefore also EMITS every pair with LB_K <= theta (the "tracked" pairs, stored
+// as the two representatives' node ids) where theta = previous minimum + W.  In the following
+// events k_track evaluates exactly (fp64, scan_micro: the scan's own body, exact tie-break)
+//   (a) the tracked pairs whose two clusters still exist unchanged, and
+//   (b) every pair that involves a cluster created since the base scan ("fresh": its two rows
+//       are read in full; at most one new cluster per event).
+// Every other live pair is an old, untracked pair with Q >= LB_K - slack > theta - slack =
+// theta_eff.  So if the minimum M over (a) + (b) satisfies M <= theta_eff, it is the global
+// minimum with the reference's tie-break (all ties of M are inside (a) + (b) too), and the event
+// needs no scan at all.  If M > theta_eff, or after K events, the event runs a new base scan.
+// The result never depends on W, K or the capacity: they only decide how often a base scan runs.
+// ---------------------------------------------------------------------------
+constexpr int LA_KMAX = 512;      // fresh clusters per window (>= K)
+constexpr int LA_PCAP = 65536;    // tracked pairs per window
+
+// slack between the fp32 lower bound and the true fp64 Q over the window: the screening slack
+// (screen_delta, applied twice for good measure) plus the rounding drift of the row sums
+// (3 roundings of a value <= n Dmax per event, each <= 2^-53 relative)
+FNN_HD double la_delta(const State& st) {
+    const double dmax = __builtin_bit_cast(double, st.dmax_bits);
+    return 2.0 * (double)screen_delta(st) + 1e-15 * (double)(st.la_K + 1) * ((double)st.n + 4.0) * dmax + 1e-30;
+}
+
+// does k_track serve this event from the open window?
+FNN_HD bool la_active(const State& st) {
+    return st.la_on && st.la_valid && !st.done && st.la_k <= st.la_K && st.la_nf <= LA_KMAX && st.m >= st.la_min_m &&
+           st.m > 4;
+}
+
+// this event runs a scan: close the window; decide whether the screening pass opens a new one
+FNN_HD void la_prepare_base(State& st) {
+    st.la_hit = 0;
+    st.la_valid = 0;
+    st.la_emit = 0;
+    st.la_count = 0;
+    if (st.la_on && st.nonneg && st.screen_ok && !st.done && st.m >= st.la_min_m) {
+        if (st.la_skip > 0) st.la_skip--;
+        else if (st.la_have_mprev) {
+            const double th = st.la_mprev + st.la_W;
+            st.la_theta_pred = (float)th;
+            if (st.la_theta_pred == st.la_theta_pred && st.la_theta_pred < 3e38f && st.la_theta_pred > -3e38f) st.la_emit = 1;
+        }
+    }
+}
+
+// after the scan of a base event (its exact minimum is already known): open the window
+FNN_HD void la_close_base(State& st) {
+    st.n_base_scans++;
+    if (!st.la_emit) return;
+    st.la_emit = 0;
+    const int32_t cnt = st.la_count;
+    const double dmax = __builtin_bit_cast(double, st.dmax_bits);
+    if (cnt > st.la_pcap) {  // too many pairs under the threshold: narrower next time, and back off
+        st.n_la_overflow++;
+        st.la_W *= 0.5;
+        st.la_backoff = st.la_backoff < 1 ? 1 : (st.la_backoff >= 512 ? 1024 : 2 * st.la_backoff);
+        st.la_skip = st.la_backoff;
+        return;
+    }
+    st.la_backoff = 0;
+    st.la_valid = 1;
+    st.la_np = cnt;
+    st.la_k = 0;
+    st.la_nf = 0;
+    st.la_base_stamp = (int32_t)st.n_events;
+    st.la_theta_eff = (double)st.la_theta_pred - la_delta(st);
+    st.la_pairs_sum += cnt;
+    if (cnt > st.la_target) st.la_W *= 0.75;
+    else if (cnt < st.la_target / 4) st.la_W *= 1.5;
+    const double wmin = 1e-6 * dmax + 1e-300, wmax = 1e12 * dmax + 1e-300;
+    if (!(st.la_W >= wmin)) st.la_W = wmin;
+    if (st.la_W > wmax) st.la_W = wmax;
+}
+
+// a new two-node cluster with representative id `rep` exists from the next event on
+FNN_HD void la_note_cluster(const Dev& d, State& st, int32_t rep, int32_t partner) {
+    if (!d.cstamp) return;
+    const int32_t stamp = (int32_t)st.n_events + 1;
+    d.cstamp[rep] = stamp;
+    d.cstamp[partner] = stamp;
+    if (st.la_valid) {
+        if (st.la_nf < LA_KMAX) { d.fresh[2 * st.la_nf] = rep; d.fresh[2 * st.la_nf + 1] = stamp; }
+        st.la_nf++;  // beyond LA_KMAX the window is no longer served (la_active)
+    }
+}
+
+// exact evaluation of the micro-tile that holds the pair of the nodes in slots sa, sb: the scan's
+// own body on the same entries (the tile may hold up to three more live pairs: harmless extras)
+FNN_HD void pair_eval(const Dev& d, int32_t sa, int32_t sb, int32_t m, int32_t twoP, double cm2, Cand& best) {
+    const int32_t r0 = (sa > sb ? sa : sb) & ~1, c0 = (sa > sb ? sb : sa) & ~1;
+    const double* R0 = d.D + (int64_t)r0 * d.ld + c0;
+    const double* R1 = R0 + d.ld;  // rows are padded to an even count: r0 + 1 is always in bounds
+    scan_micro(r0, c0, m, twoP, cm2, R0[0], R0[1], R1[0], R1[1], d.Sx[r0], d.Sx[r0 + 1], d.spos[r0], d.spos[r0 + 1],
+               d.Sx[c0], d.Sx[c0 + 1], d.spos[c0], d.spos[c0 + 1], best);
+}
+
+// all pairs between the fresh two-node cluster in slots (f0, f0 + 1) and the node(s) in slots
+// (s, s + 1), s even: the four entries are read from ROWS f0, f0 + 1 (contiguous in s; the matrix
+// is bit-symmetric) and handed to the scan's body in the orientation it would have met them
+FNN_HD void fresh_eval(const Dev& d, int32_t f0, int32_t s, int32_t m, int32_t twoP, double cm2, Cand& best) {
+    if (s >= m || s == f0) return;
+    const double* F0 = d.D + (int64_t)f0 * d.ld + s;
+    const double* F1 = F0 + d.ld;
+    const double a0 = F0[0], a1 = F0[1], b0 = F1[0], b1 = F1[1];
+    if (f0 > s)
+        scan_micro(f0, s, m, twoP, cm2, a0, a1, b0, b1, d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1],
+                   d.Sx[s], d.Sx[s + 1], d.spos[s], d.spos[s + 1], best);
+    else
+        scan_micro(s, f0, m, twoP, cm2, a0, b0, a1, b1, d.Sx[s], d.Sx[s + 1], d.spos[s], d.spos[s + 1],
+                   d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1], best);
+}
+
+// one work item of k_track: item < np: tracked pair; otherwise (fresh cluster, column pair)
+FNN_HD void track_item(const Dev& d, int64_t item, int32_t np, int32_t nf, int32_t m, int32_t twoP, double cm2,
+                       int32_t base_stamp, Cand& best) {
+    if (item < np) {
+        const int32_t ia = d.tpairs[2 * item], ib = d.tpairs[2 * item + 1];
+        const int32_t sa = d.islot[ia], sb = d.islot[ib];
+        if (sa < 0 || sb < 0 || d.cstamp[ia] > base_stamp || d.cstamp[ib] > base_stamp) return;
+        pair_eval(d, sa, sb, m, twoP, cm2, best);
+        return;
+    }
+    const int64_t r = item - np;
+    const int32_t half = (m + 1) / 2;
+    const int32_t fi = (int32_t)(r / half), cp = (int32_t)(r % half);
+    if (fi >= nf) return;
+    const int32_t id = d.fresh[2 * fi], stamp = d.fresh[2 * fi + 1];
+    const int32_t f0 = d.islot[id];
+    if (f0 < 0 || d.cstamp[id] != stamp) return;  // consumed by a later event
+    fresh_eval(d, f0, 2 * cp, m, twoP, cm2, best);
+}
+FNN_HD int64_t track_item_count(const State& st) {
+    const int32_t nf = st.la_nf < LA_KMAX ? st.la_nf : LA_KMAX;
+    return (int64_t)st.la_np + (int64_t)nf * ((st.m + 1) / 2);
+}
+
+// the window's verdict on the minimum over all items (one thread, after the reduction)
+FNN_HD void la_track_done(const Dev& d, Cand best) {
+    State& st = *d.st;
+    if (best.q <= st.la_theta_eff) {
+        st.la_hit = 1;
+        st.n_la_hits++;
+        d.recs[0] = best;
+        const int64_t items = track_item_count(st);
+        st.la_items_sum += items;
+        st.bytes_streamed += 32 * items;
+    } else {
+        st.n_la_fail++;
+        la_prepare_base(st);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // plan building (single thread)
 // ---------------------------------------------------------------------------
 FNN_HD void emit(State& st, int32_t kind, int32_t a, int32_t b, int32_t c, int32_t d, int32_t e,
@@ -356,6 +593,7 @@ FNN_HD void swap_slots(const Dev& d, int32_t s1, int32_t s2) {
     t = d.spos[s1]; d.spos[s1] = d.spos[s2]; d.spos[s2] = t;
     d.pslot[d.spos[s1]] = s1;
     d.pslot[d.spos[s2]] = s2;
+    if (d.islot) { d.islot[d.sid[s1]] = s1; d.islot[d.sid[s2]] = s2; }
     emit(*d.st, OP_SWAP, s1, s2, 0, 0, 0, 0);
 }
 
@@ -363,6 +601,7 @@ FNN_HD void move_slot(const Dev& d, int32_t src, int32_t dst) {
     d.sid[dst] = d.sid[src];
     d.spos[dst] = d.spos[src];
     d.pslot[d.spos[dst]] = dst;
+    if (d.islot) d.islot[d.sid[dst]] = dst;
     emit(*d.st, OP_MOVE, src, dst, 0, 0, 0, 0);
 }
 
@@ -375,6 +614,7 @@ FNN_HD void agg3_plan(const Dev& d, int32_t X, int32_t Y, int32_t Z, int32_t U, 
     int32_t px = d.spos[X], py = d.spos[Y], pz = d.spos[Z];
     Agg3Rec& r = d.agglog[st.n_agg3++];
     r.u_id = nn + 1; r.x_id = d.sid[X]; r.y_id = d.sid[Y]; r.z_id = d.sid[Z];
+    if (d.islot) { d.islot[r.x_id] = -1; d.islot[r.y_id] = -1; d.islot[r.z_id] = -1; d.islot[nn + 1] = U; d.islot[nn + 2] = V; }
     d.sid[U] = nn + 1;  // u replaces x in the list (:623-625)
     d.sid[V] = nn + 2;  // v replaces z (:630-632)
     d.spos[U] = px;
@@ -501,8 +741,12 @@ FNN_HD void pick(const Dev& d, Cand best) {
     if (st.m == 4 && st.c == 2) { finish_plan(d); return; }
     cur.entries = (int64_t)st.m * (st.m - 1) / 2 - (st.m - st.c);
     cur.best = best.q;
-    st.bytes_streamed += (st.ev_screened ? 2 : 8) * cur.entries +
-                         (st.ev_screened ? (int64_t)(st.rescan_all ? 0 : st.ncand) * SCR_TH * SCR_UW * 8 : 0);
+    if (!st.la_hit) {  // (a window hit has already added the bytes k_track read)
+        const int64_t bytes = (st.ev_screened ? 2 : 8) * cur.entries +
+                              (st.ev_screened ? (int64_t)(st.rescan_all ? 0 : st.ncand) * SCR_TH * SCR_UW * 8 : 0);
+        st.bytes_streamed += bytes;
+        if (st.ev_timed) st.bytes_timed += bytes;
+    }
     st.ev_screened = 0;
     int32_t i = (int32_t)(best.key >> 32), j = (int32_t)(best.key & 0xFFFFFFFFu);
     int32_t a = d.pslot[i], b = d.pslot[j];  // Cx = p, Cy = q
@@ -627,6 +871,7 @@ FNN_HD void decide(const Dev& d, const double rx[4]) {
         st.c -= 1;
         st.U = t0;  // u = x, and x always has the smaller id (Cx.id < Cy.id, :376-380)
         if (d.sid[t0] != cur.u_id) st.error = 3;
+        la_note_cluster(d, st, d.sid[t0], d.sid[t1]);
     } else if (xn < 0 || yn < 0) {
         // agg3way(x, y, y.nbr) (:466) or agg3way(y, x, x.nbr) (:476)
         cur.kind = KIND_3WAY;
@@ -641,6 +886,7 @@ FNN_HD void decide(const Dev& d, const double rx[4]) {
         st.m = m - 1;
         st.c -= 1;
         st.U = 2 * k;
+        la_note_cluster(d, st, nn + 1, nn + 2);
     } else {
         if (m == 4) st.error = 4;  // (:474) unreachable: m == 4 with two pairs is the special finish
         // agg4way(x.nbr, x, y, y.nbr) (:484, :707-726): two agg3way calls
@@ -667,6 +913,7 @@ FNN_HD void decide(const Dev& d, const double rx[4]) {
         st.m = m - 2;
         st.c -= 1;
         st.U = U;
+        la_note_cluster(d, st, nn + 3, nn + 4);
     }
     build_targets(d);
 }
@@ -869,6 +1116,8 @@ FNN_HD void finalize(const Dev& d, double usx) {
         d.Sx[st.U + 1] = 0.0;
     }
     if (st.record_events) d.evlog[st.n_events] = st.cur;
+    if (st.la_valid) st.la_k += 1;
+    if (!st.ev_finish) { st.la_mprev = st.cur.best; st.la_have_mprev = 1; }
     st.n_events += 1;
     st.sum_entries += st.cur.entries;
     if (st.ev_finish || st.m <= 3) st.done = 1;
@@ -887,10 +1136,12 @@ FNN_HD void init_thread(const Dev& d, int32_t k) {
     d.sid[k] = k + 1;
     d.spos[k] = k;
     d.pslot[k] = k;
+    if (d.islot) d.islot[k + 1] = k;
     if (k == 0) {
         // the screening bound needs a finite, float-representable bound on |D| (prep kernel)
         const double dmax = __builtin_bit_cast(double, d.st->dmax_bits);
         d.st->screen_ok = (d.H != nullptr && dmax == dmax && dmax < 1e37) ? 1 : 0;
+        d.st->la_W = 16.0 * dmax;  // first lookahead window width; adapted at every base scan (la_close_base)
     }
 }
 

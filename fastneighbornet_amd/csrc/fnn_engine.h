@@ -50,6 +50,7 @@ class Engine {
     std::vector<Agg3Rec> agglog;
     int32_t last3[3] = {0, 0, 0};
     int32_t batch = 32;    // events enqueued between host round trips in run()
+    int64_t ev_counter = 0;  // events enqueued since begin(): drives the schedule of the lookahead windows' base scans
     // several GPUs: 0 = single, 1 = RCCL all-gather on the stream, 2 = host callback (tests)
     int32_t comm_mode = 0, world = 1, rank = 0;
     fnn_allgather_fn host_fn = nullptr;
@@ -84,6 +85,11 @@ class Engine {
             !(dev.srec = (float*)be.alloc(sizeof(float) * (2 * (size_t)screen_unit_count(n > 0 ? n : 1) + 16))) ||
             !(dev.stile = (float*)be.alloc(sizeof(float) * (2 * (size_t)screen_unit_count(n > 0 ? n : 1) / 4 + 16))) ||
             !(dev.clist = (int32_t*)be.alloc(sizeof(int32_t) * SCR_CAP)) ||
+            !(dev.islot = (int32_t*)be.alloc(sizeof(int32_t) * (3 * nn + 8))) ||
+            !(dev.cstamp = (int32_t*)be.alloc(sizeof(int32_t) * (3 * nn + 8))) ||
+            !(dev.tpairs = (int32_t*)be.alloc(sizeof(int32_t) * 2 * LA_PCAP)) ||
+            !(dev.fresh = (int32_t*)be.alloc(sizeof(int32_t) * 2 * LA_KMAX)) ||
+            !(dev.ticket = (uint32_t*)be.alloc(sizeof(uint32_t) * 4)) ||
             !(dev.gsend = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS)) ||
             !(dev.grecv = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS * 64)) ||
             !(dev.st = (State*)be.alloc(sizeof(State))) ||
@@ -103,7 +109,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.recs); be.free(dev.rxpart); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.recs); be.free(dev.rxpart); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }
@@ -162,9 +168,32 @@ class Engine {
         hst.done = (n <= 3) ? 1 : 0;  // :133-140
         hst.nonneg = 1;                // cleared by the prep kernel if a negative entry exists
         hst.record_events = opts.record_events ? 1 : 0;
+        hst.ev_timed = 1;
         hst.force_exact_rx = opts.force_exact_rx ? 1 : 0;
+        // lookahead windows (fnn_core.h "Lookahead"): single rank with a screening copy
+        {
+            int32_t K = opts.lookahead < 0 ? 0 : (opts.lookahead > 0 ? opts.lookahead : 64);
+            int32_t target = opts.lookahead_pairs > 0 ? opts.lookahead_pairs : 8192;
+            if (const char* e = std::getenv("FNN_LA_K")) K = std::atoi(e);
+            if (const char* e = std::getenv("FNN_LA_TARGET")) target = std::atoi(e);
+            if (K > LA_KMAX) K = LA_KMAX;
+            if (target < 1) target = 1;
+            if (target > LA_PCAP) target = LA_PCAP;
+            hst.la_on = (dev.H && K > 0 && world == 1 && comm_mode == 0) ? 1 : 0;
+            hst.la_K = K > 0 ? K : 0;
+            hst.la_target = target;
+            hst.la_min_m = be.screen_min_m;
+            dev.la = hst.la_on;
+            ev_counter = 0;
+            hst.la_pcap = LA_PCAP;
+            if (const char* e = std::getenv("FNN_LA_PCAP")) { int v = std::atoi(e); if (v >= 1 && v <= LA_PCAP) hst.la_pcap = v; }
+        }
         if (be.h2d(dev.st, &hst, sizeof(State)) != FNN_OK)
             return fail(FNN_EHIP, "fnn_begin: state upload failed (" + be.err() + ")");
+        if (be.memset(dev.islot, 0xFF, sizeof(int32_t) * (3 * (size_t)(n > 0 ? n : 1) + 8)) != FNN_OK ||
+            be.memset(dev.cstamp, 0, sizeof(int32_t) * (3 * (size_t)(n > 0 ? n : 1) + 8)) != FNN_OK ||
+            be.memset(dev.ticket, 0, sizeof(uint32_t) * 4) != FNN_OK)
+            return fail(FNN_EHIP, "fnn_begin: memset failed (" + be.err() + ")");
         if (n > 3) {
             if (dev.H && be.launch_prep_screen(dev, nrows) != FNN_OK)
                 return fail(FNN_EHIP, "fnn_begin: bf16 copy failed (" + be.err() + ")");
@@ -197,7 +226,12 @@ class Engine {
     // A rank contributes nper candidate records (1 after a local reduction, or the scan's
     // GATHER_RECS per-workgroup records as they are).
     int32_t enqueue_event() {
-        if (comm_mode == 0) return be.launch_event(dev, m_bound) == FNN_OK ? FNN_OK : fail(FNN_EHIP, "launch failed (" + be.err() + ")");
+        // lookahead windows: a new window is opened (base scan) at the first two events (the second
+        // one knows the previous minimum) and then every la_K events; in between a scan only runs
+        // if the window fails, which the device finds out by itself
+        const int64_t cnt = ev_counter++;
+        const bool sched = !dev.la || cnt == 0 || (cnt - 1) % (hst.la_K > 0 ? hst.la_K : 1) == 0;
+        if (comm_mode == 0) return be.launch_event(dev, m_bound, sched) == FNN_OK ? FNN_OK : fail(FNN_EHIP, "launch failed (" + be.err() + ")");
         int32_t nper = 1;
         if (be.launch_event_scan(dev, m_bound, &nper) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
         if (comm_mode == 1) {
@@ -292,11 +326,16 @@ class Engine {
         stats.t_expand_s = now_s() - t0;
         stats.n_events = hst.n_events;
         stats.sum_entries = hst.sum_entries;
-        stats.scan_bytes = hst.bytes_streamed;
+        stats.scan_bytes = hst.bytes_timed;
+        stats.bytes_total = hst.bytes_streamed;
         stats.n_rx_certified = hst.n_rx_certified;
         stats.n_rx_exact = hst.n_rx_exact;
         stats.n_screen_events = hst.n_screen_events;
         stats.n_rescan_units = hst.n_rescan_units;
+        stats.n_base_scans = hst.n_base_scans;
+        stats.n_window_hits = hst.n_la_hits;
+        stats.n_window_fails = hst.n_la_fail;
+        stats.window_pairs = hst.la_pairs_sum;
         be.collect_timing(stats);
         return rc;
     }

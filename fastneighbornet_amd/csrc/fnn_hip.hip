@@ -133,6 +133,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(Dev d) {
     Cand best;
     best.q = inf_f64();
     best.key = ~0ULL;
+    if (st->la_hit) return;  // the lookahead window already holds this event's minimum (recs[0])
     if (!st->done) {
         const int m = st->m;
         const int twoP = 2 * st->P;
@@ -292,17 +293,59 @@ __device__ __forceinline__ void screen_tile_nonneg(const Dev& d, int rbase, int 
     }
 }
 
+// Emission pass of a lookahead window (fnn_core.h "Lookahead"): a thread whose columns hold a
+// pair with a lower bound under the window's threshold walks its 32 rows again (they are still in
+// L2) and appends every such pair, as the two representatives' node ids, to the tracked list.
 template <bool NT>
+__device__ __forceinline__ void screen_emit_columns(const Dev& d, int rbase, int c0, int m, int twoP, float k1, float k2, float tp) {
+    State* st = d.st;
+    const int pcap = st->la_pcap;
+    float sxc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        const double2 sv = *reinterpret_cast<const double2*>(d.Sx + c0 + k);
+        sxc[k] = (float)sv.x;
+        sxc[k + 1] = (float)sv.y;
+    }
+    auto emit = [&](int32_t rs, int32_t cs, float lb) {
+        if (!(lb <= tp)) return;
+        const int i = atomicAdd(&st->la_count, 1);
+        if (i < pcap) { d.tpairs[2 * i] = d.sid[rs]; d.tpairs[2 * i + 1] = d.sid[cs]; }
+    };
+    Brk dummy;
+    dummy.lb = __builtin_inff();
+    dummy.ub = __builtin_inff();
+    const uint16_t* colbase = d.H + c0;
+#pragma unroll 1
+    for (int r0 = rbase; r0 < rbase + SCR_TH && r0 < m; r0 += 2) {
+        const uint4 a = ld16h<false>(colbase + (int64_t)r0 * d.ld);
+        const uint4 b = ld16h<false>(colbase + (int64_t)(r0 + 1) * d.ld);
+        const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + r0);
+        const float s0 = (float)sxr.x, s1 = (float)sxr.y;
+        const unsigned aw[4] = {a.x, a.y, a.z, a.w};
+        const unsigned bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            screen_micro_nn(r0, c0 + 2 * j, m, twoP, k1, k2, bf_lo(aw[j]), bf_hi(aw[j]), bf_lo(bw[j]), bf_hi(bw[j]),
+                            s0, s1, sxc[2 * j], sxc[2 * j + 1], dummy, emit);
+    }
+}
+
+// SCHED only separates, by kernel name, the host-scheduled base scans of the lookahead windows
+// (always real work) from the launches that run only when a window failed (mostly no-ops).
+template <bool NT, bool SCHED>
 __global__ __launch_bounds__(256) void k_screen(Dev d) {
     __shared__ float shl[4], shu[4];
     const State* st = d.st;
-    if (st->done) return;
+    if (st->done || st->la_hit) return;
     const int m = st->m;
     const int twoP = 2 * st->P;
     const float cm2 = (float)((double)st->c - 2.0);
     const float cm2k = screen_cm2k(*st);
     const float k1 = screen_k1(*st), k2 = screen_k2(*st);
     const bool nonneg = st->nonneg != 0;
+    const bool emit = st->la_emit != 0;
+    const float tp = st->la_theta_pred;
     const int ntiles = tri_tile_count(m, SCR_TH, SCR_R);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float* lbrec = d.srec;
@@ -362,9 +405,14 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
                     const unsigned aw[4] = {a[k].x, a[k].y, a[k].z, a[k].w};
                     const unsigned bw[4] = {b[k].x, b[k].y, b[k].z, b[k].w};
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        screen_micro(r0, c0 + 2 * j, m, twoP, cm2, cm2k, bf_lo(aw[j]), bf_hi(aw[j]), bf_lo(bw[j]), bf_hi(bw[j]),
-                                     sxr0, sxr1, sxc[2 * j], sxc[2 * j + 1], bk[j]);
+                    for (int j = 0; j < 4; j++) {
+                        if (nonneg)
+                            screen_micro_nn(r0, c0 + 2 * j, m, twoP, k1, k2, bf_lo(aw[j]), bf_hi(aw[j]), bf_lo(bw[j]), bf_hi(bw[j]),
+                                            sxr0, sxr1, sxc[2 * j], sxc[2 * j + 1], bk[j], NoEmit());
+                        else
+                            screen_micro(r0, c0 + 2 * j, m, twoP, cm2, cm2k, bf_lo(aw[j]), bf_hi(aw[j]), bf_lo(bw[j]), bf_hi(bw[j]),
+                                         sxr0, sxr1, sxc[2 * j], sxc[2 * j + 1], bk[j]);
+                    }
                 }
             }
 #pragma unroll
@@ -372,6 +420,7 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
         }
         float lb = __builtin_fminf(__builtin_fminf(lbv[0], lbv[1]), __builtin_fminf(lbv[2], lbv[3]));
         float ub = __builtin_fminf(__builtin_fminf(ubv[0], ubv[1]), __builtin_fminf(ubv[2], ubv[3]));
+        if (emit && lb <= tp) screen_emit_columns<NT>(d, rbase, c0, m, twoP, k1, k2, tp);
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             lb = __builtin_fminf(lb, __shfl_down(lb, off, 64));
@@ -384,6 +433,56 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
             ubt[t] = __builtin_fminf(__builtin_fminf(shu[0], shu[1]), __builtin_fminf(shu[2], shu[3]));
         }
         __syncthreads();
+    }
+}
+
+// k_track: serve the event from the open lookahead window (fnn_core.h "Lookahead").  The work
+// items (tracked pairs, then the rows of the clusters created since the base scan) are spread over
+// the grid; the last workgroup to arrive reduces the per-workgroup minima and decides whether the
+// window certifies the minimum (la_hit: the scan kernels of this event return at once) or the
+// event has to scan.  force_base: the host's schedule asks for a new window at this event.
+constexpr int TRK_THREADS = 256;
+__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed) {
+    __shared__ Cand sh[TRK_THREADS / 64];
+    __shared__ int lastflag;
+    State* st = d.st;
+    if (st->done) return;
+    if (force_base || !la_active(*st)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { st->ev_timed = timed; la_prepare_base(*st); }
+        return;
+    }
+    const int m = st->m, twoP = 2 * st->P, np = st->la_np, base_stamp = st->la_base_stamp;
+    const int nf = st->la_nf < LA_KMAX ? st->la_nf : LA_KMAX;
+    const double cm2 = (double)st->c - 2.0;
+    const int64_t items = track_item_count(*st);
+    Cand best;
+    best.q = inf_f64();
+    best.key = ~0ULL;
+    for (int64_t it = (int64_t)blockIdx.x * TRK_THREADS + threadIdx.x; it < items; it += (int64_t)gridDim.x * TRK_THREADS)
+        track_item(d, it, np, nf, m, twoP, cm2, base_stamp, best);
+    best = block_reduce<TRK_THREADS / 64>(best, sh);
+    if (threadIdx.x == 0) {
+        d.recs[blockIdx.x] = best;
+        __threadfence();
+        lastflag = atomicAdd(d.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+    }
+    __syncthreads();
+    if (!lastflag) return;
+    __threadfence();
+    best.q = inf_f64();
+    best.key = ~0ULL;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += TRK_THREADS) {
+        Cand c;
+        c.q = __builtin_nontemporal_load(&d.recs[i].q);
+        c.key = __builtin_nontemporal_load(&d.recs[i].key);
+        if (cand_better(c, best)) best = c;
+    }
+    __syncthreads();
+    best = block_reduce<TRK_THREADS / 64>(best, sh);
+    if (threadIdx.x == 0) {
+        *d.ticket = 0u;
+        st->ev_timed = timed;
+        la_track_done(d, best);
     }
 }
 
@@ -435,6 +534,7 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d) {
     Cand best;
     best.q = inf_f64();
     best.key = ~0ULL;
+    if (st->la_hit) return;  // the lookahead window already holds this event's minimum (recs[0])
     if (st->done) {  // nothing to scan: leave "no candidate" records
         if (tid == 0) (d.gather ? d.gsend : d.recs)[blockIdx.x] = best;
         return;
@@ -499,6 +599,7 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d) {
             st->n_screen_events += 1;
             st->n_rescan_units += all ? (int64_t)(4 * ntiles) / d.world : (int64_t)count;
             st->ev_screened = 1;
+            la_close_base(*st);  // (the screening pass may have emitted the pairs of a new lookahead window)
         }
     }
 }
@@ -568,6 +669,7 @@ __global__ __launch_bounds__(256) void k_rx_fill(Dev d, const Cand* src, int nre
     Cand best;
     best.q = inf_f64();
     best.key = ~0ULL;
+    if (st->la_hit) nrecs = 1;  // the lookahead window's minimum, left in recs[0] by k_track
     if (!st->done)
         for (int i = threadIdx.x; i < nrecs; i += 256) {
             const Cand c = src[i];
@@ -977,6 +1079,8 @@ struct HipBackend {
     const char* (*p_ncclGetErrorString)(int) = nullptr;
     std::string comm_err;
     int scan_grid = 8192;   // workgroups of the scan (FNN_SCAN_GRID)
+    int unsched_grid = 2048; // workgroups of the screening launches that only run when a lookahead window fails (FNN_UNSCHED_GRID)
+    int track_grid = 256;   // workgroups of k_track (FNN_TRACK_GRID)
     bool scan_nt = true;    // non-temporal matrix loads in the scan (FNN_SCAN_NT)
 
     std::string err() const { return comm_err.empty() ? std::string(hipGetErrorString(last)) : comm_err; }
@@ -1027,6 +1131,8 @@ struct HipBackend {
             return fail(FNN_EHIP, "hipStreamCreate failed (" + err() + ")");
         if (const char* e = std::getenv("FNN_SCAN_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) scan_grid = v; }
         if (const char* e = std::getenv("FNN_SCAN_NT")) scan_nt = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FNN_UNSCHED_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) unsched_grid = v; }
+        if (const char* e = std::getenv("FNN_TRACK_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) track_grid = v; }
         if (const char* e = std::getenv("FNN_SCREEN_MIN_M")) { int v = std::atoi(e); if (v >= 8) screen_min_m = v; }
         opened = true;
         return FNN_OK;
@@ -1141,17 +1247,30 @@ struct HipBackend {
         return dim3((unsigned)(nt < scan_grid ? (nt > 0 ? nt : 1) : scan_grid));
     }
     bool use_screen(const Dev& d, int32_t m_bound) const { return d.H != nullptr && m_bound >= screen_min_m; }
-    // the scan of one event; returns the number of per-workgroup records it leaves in d.recs
-    int enqueue_scan(const Dev& d, int32_t m_bound) {
+    // the scan of one event; returns the number of per-workgroup records it leaves in d.recs.
+    // With lookahead windows (d.la) k_track goes first: it either serves the event from the open
+    // window (the scan kernels then return at once) or lets the scan run.  `sched`: the host's
+    // schedule opens a new window at this event, so the scan is certain to run: only those
+    // launches (and the plain fp64 scans) are timed for the roofline figure.
+    int enqueue_scan(const Dev& d, int32_t m_bound, bool sched) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (timing) { e0 = next_event(); e1 = next_event(); }
+        const bool screen = use_screen(d, m_bound);
+        const bool timed = timing && (sched || !screen);
+        if (d.la) hipLaunchKernelGGL(k_track, dim3(track_grid), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0);
+        if (timed) { e0 = next_event(); e1 = next_event(); }
         int nrecs;
-        if (use_screen(d, m_bound)) {
+        if (screen) {
             int nt = (tri_tile_count(m_bound, SCR_TH, SCR_R) + d.world - 1) / d.world;
-            dim3 gs((unsigned)(nt < scan_grid ? (nt > 0 ? nt : 1) : scan_grid));
+            const int want = sched ? scan_grid : unsched_grid;
+            dim3 gs((unsigned)(nt < want ? (nt > 0 ? nt : 1) : want));
             if (e0) (void)hipEventRecord(e0, stream);
-            if (scan_nt) hipLaunchKernelGGL(k_screen<true>, gs, dim3(256), 0, stream, d);
-            else hipLaunchKernelGGL(k_screen<false>, gs, dim3(256), 0, stream, d);
+            if (sched) {
+                if (scan_nt) hipLaunchKernelGGL((k_screen<true, true>), gs, dim3(256), 0, stream, d);
+                else hipLaunchKernelGGL((k_screen<false, true>), gs, dim3(256), 0, stream, d);
+            } else {
+                if (scan_nt) hipLaunchKernelGGL((k_screen<true, false>), gs, dim3(256), 0, stream, d);
+                else hipLaunchKernelGGL((k_screen<false, false>), gs, dim3(256), 0, stream, d);
+            }
             if (e1) (void)hipEventRecord(e1, stream);
             hipLaunchKernelGGL(k_resolve, dim3(RES_BLOCKS), dim3(1024), 0, stream, d);
             nrecs = RES_BLOCKS;
@@ -1163,7 +1282,7 @@ struct HipBackend {
             if (e1) (void)hipEventRecord(e1, stream);
             nrecs = (int)gs.x;
         }
-        scan_launches++;
+        if (timed) scan_launches++;
         return nrecs;
     }
     // everything after the scan; `src` holds the nrecs candidate records to reduce
@@ -1175,16 +1294,16 @@ struct HipBackend {
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d);
     }
     // single GPU: the whole event
-    int32_t launch_event(const Dev& d, int32_t m_bound) {
+    int32_t launch_event(const Dev& d, int32_t m_bound, bool sched) {
         if (m_bound < 1) m_bound = 1;
-        int nrecs = enqueue_scan(d, m_bound);
+        int nrecs = enqueue_scan(d, m_bound, sched);
         enqueue_rest(d, m_bound, (const Cand*)d.recs, nrecs);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
     // several GPUs: scan of this rank's tiles ... (all-gather of the candidate records) ... the rest
     int32_t launch_event_scan(const Dev& d, int32_t m_bound, int32_t* nper) {
         if (m_bound < 1) m_bound = 1;
-        int nrecs = enqueue_scan(d, m_bound);
+        int nrecs = enqueue_scan(d, m_bound, true);
         if (nrecs == RES_BLOCKS && use_screen(d, m_bound)) {
             *nper = nrecs;  // k_resolve has written its per-workgroup records straight into d.gsend
         } else {

@@ -57,7 +57,10 @@ typedef struct fnn_opts {
                               live nodes first stream an fp32 copy of the matrix (half the bytes) to
                               find, within a rigorous error bound, the few tile units that can hold
                               the minimum, and only those are rescanned in fp64 (same result) */
-    int32_t reserved[11];
+    int32_t lookahead;     /* events one screening pass may serve ("lookahead window"): 0 = default
+                              (64), < 0 = off (every event scans), > 0 = that many; same result either way */
+    int32_t lookahead_pairs;/* wanted number of tracked pairs per window (0 = default 8192) */
+    int32_t reserved[9];
 } fnn_opts;
 
 /* One agglomeration event == one iteration of the loop of
@@ -83,13 +86,18 @@ typedef struct fnn_stats {
     double  t_total_s;       /* matrix resident on device -> order on host */
     double  t_scan_s;        /* sum of scan-kernel durations (HIP events), 0 unless timing enabled */
     int64_t scan_launches;   /* number of scan-kernel launches */
-    int64_t scan_bytes;      /* matrix bytes those launches had to stream: per event E_t entries at 4 B
-                                (fp32 screening pass) or 8 B (plain fp64 scan), plus the fp64 rescans */
+    int64_t scan_bytes;      /* matrix bytes the TIMED scan launches had to stream: per event E_t entries at
+                                2 B (bf16 screening pass) or 8 B (plain fp64 scan), plus the fp64 rescans */
     int64_t n_rx_certified;  /* events whose 4-candidate choice was certified from tree sums */
     int64_t n_rx_exact;      /* events that needed the exact sequential ComputeRx sums */
     int64_t n_screen_events; /* events whose scan went through the fp32 screening pass */
     int64_t n_rescan_units;  /* 32 x 256 units rescanned in fp64 over those events */
-    int64_t reserved[4];
+    int64_t n_base_scans;    /* events that ran a scan (all of them without lookahead windows) */
+    int64_t n_window_hits;   /* events whose minimum came from an open lookahead window (no scan) */
+    int64_t n_window_fails;  /* events whose window could not certify the minimum (they rescanned) */
+    int64_t window_pairs;    /* tracked pairs summed over all windows */
+    int64_t bytes_total;     /* matrix bytes read by ALL scan work of the run (timed or not, window items too) */
+    int64_t reserved[7];
 } fnn_stats;
 
 typedef struct fnn_handle fnn_handle;

@@ -132,7 +132,8 @@ struct EmuBackend {
                                 d.Sx[c0], c1 ? d.Sx[c0 + 1] : 0.0, d.spos[c0], c1 ? d.spos[c0 + 1] : 0, best);
             }
     }
-    // k_screen + k_resolve: bf16 screening with per-pair brackets, candidate units, exact rescan
+    // k_screen + k_resolve: bf16 screening with per-pair brackets, candidate units, exact rescan;
+    // on a base scan of a lookahead window the pass also emits the pairs to track
     fnn::Cand scan_screened(const fnn::Dev& d) {
         fnn::State& st = *d.st;
         fnn::Cand best;
@@ -141,10 +142,17 @@ struct EmuBackend {
         if (st.done) return best;
         const int32_t m = st.m, twoP = 2 * st.P;
         const float cm2 = (float)((double)st.c - 2.0), cm2k = fnn::screen_cm2k(st);
+        const float k1 = fnn::screen_k1(st), k2 = fnn::screen_k2(st);
+        const bool nn = st.nonneg != 0;
         const int32_t nunits = fnn::screen_unit_count(m);
         const float finf = (float)fnn::inf_f64();
         float* lbrec = d.srec;
         float* ubrec = d.srec + nunits;
+        auto emit = [&](int32_t rs, int32_t cs, float lb) {
+            if (!st.la_emit || !(lb <= st.la_theta_pred)) return;
+            const int32_t i = st.la_count++;
+            if (i < st.la_pcap) { d.tpairs[2 * i] = d.sid[rs]; d.tpairs[2 * i + 1] = d.sid[cs]; }
+        };
         for (int32_t u : thread_order(nunits)) {
             fnn::Brk b{finf, finf};
             if ((u / 4) % d.world == d.rank) {
@@ -156,16 +164,18 @@ struct EmuBackend {
                         const uint16_t* R0 = d.H + (int64_t)r0 * d.ld;
                         const uint16_t* R1 = d.H + (int64_t)(r0 + 1) * d.ld;
                         bool r1 = r0 + 1 < m, c1 = c0 + 1 < m;
-                        fnn::screen_micro(r0, c0, m, twoP, cm2, cm2k, fnn::bf16_to_float(R0[c0]), fnn::bf16_to_float(R0[c0 + 1]),
-                                          fnn::bf16_to_float(R1[c0]), fnn::bf16_to_float(R1[c0 + 1]),
-                                          (float)d.Sx[r0], r1 ? (float)d.Sx[r0 + 1] : 0.f,
-                                          (float)d.Sx[c0], c1 ? (float)d.Sx[c0 + 1] : 0.f, b);
+                        const float e00 = fnn::bf16_to_float(R0[c0]), e01 = fnn::bf16_to_float(R0[c0 + 1]);
+                        const float e10 = fnn::bf16_to_float(R1[c0]), e11 = fnn::bf16_to_float(R1[c0 + 1]);
+                        const float s0 = (float)d.Sx[r0], s1 = r1 ? (float)d.Sx[r0 + 1] : 0.f;
+                        const float q0 = (float)d.Sx[c0], q1 = c1 ? (float)d.Sx[c0 + 1] : 0.f;
+                        if (nn) fnn::screen_micro_nn(r0, c0, m, twoP, k1, k2, e00, e01, e10, e11, s0, s1, q0, q1, b, emit);
+                        else fnn::screen_micro(r0, c0, m, twoP, cm2, cm2k, e00, e01, e10, e11, s0, s1, q0, q1, b);
                     }
             }
             lbrec[u] = b.lb;
             ubrec[u] = b.ub;
         }
-        // k_resolve: smallest upper bound, then the units whose lower bound does not exceed it
+    // k_resolve: smallest upper bound, then the units whose lower bound does not exceed it
         float ubg = finf;
         for (int32_t u = 0; u < nunits; u++) ubg = fnn::fminf_(ubg, ubrec[u]);
         const float thr = ubg + 2.0f * fnn::screen_delta(st);
@@ -185,12 +195,26 @@ struct EmuBackend {
         } else {
             for (int32_t i : thread_order(st.ncand)) { rescan_unit(d, d.clist[i], best); st.n_rescan_units++; }
         }
+        fnn::la_close_base(st);
         return best;
     }
 
     // k_scan over this rank's share of the micro-tiles
-    fnn::Cand scan_local(const fnn::Dev& d) {
+    fnn::Cand scan_local(const fnn::Dev& d, bool sched = true) {
         fnn::State& st = *d.st;
+        st.ev_timed = sched ? 1 : 0;
+        // k_track: serve the event from the open lookahead window if it can certify the minimum
+        if (!sched && fnn::la_active(st)) {
+            fnn::Cand tb;
+            tb.q = fnn::inf_f64();
+            tb.key = ~0ULL;
+            const int32_t nf = st.la_nf < fnn::LA_KMAX ? st.la_nf : fnn::LA_KMAX;
+            const double cm2t = (double)st.c - 2.0;
+            for (int32_t it : thread_order((int32_t)fnn::track_item_count(st)))
+                fnn::track_item(d, it, st.la_np, nf, st.m, 2 * st.P, cm2t, st.la_base_stamp, tb);
+            fnn::la_track_done(d, tb);
+            if (st.la_hit) return d.recs[0];
+        } else fnn::la_prepare_base(st);
         if (d.H && st.m >= screen_min_m) return scan_screened(d);
         fnn::Cand best;
         best.q = fnn::inf_f64();
@@ -215,7 +239,7 @@ struct EmuBackend {
         }
         return best;
     }
-    int32_t launch_event(const fnn::Dev& d, int32_t m_bound) { return event_rest(d, m_bound, scan_local(d)); }
+    int32_t launch_event(const fnn::Dev& d, int32_t m_bound, bool sched) { return event_rest(d, m_bound, scan_local(d, sched)); }
     int32_t launch_event_scan(const fnn::Dev& d, int32_t, int32_t* nper) {
         // contribute 3 records (the real one plus two "none") to exercise the multi-record exchange
         fnn::Cand none;

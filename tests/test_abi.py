@@ -50,5 +50,5 @@ def test_struct_layouts_match_header():
     from fastneighbornet_amd import _capi
     assert C.sizeof(_capi.FnnEvent) == 48
     assert C.sizeof(_capi.FnnOpts) == 64
-    assert C.sizeof(_capi.FnnStats) == 9 * 8 + 8 * 8
+    assert C.sizeof(_capi.FnnStats) == 25 * 8  # 18 named 8-byte fields + reserved[7]
     assert _capi.EVENT_DTYPE.itemsize == 48

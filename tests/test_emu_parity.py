@@ -109,13 +109,56 @@ def test_fp32_screening_keeps_the_exact_result(emu_api, oracle):
         Dh = oracle.synth(n, 6) * 1e300                     # beyond float range: screening must switch itself off
         compare_trajectory(emu_api, oracle, Dh, deep=True, deep_every=3)
         # statistics: screening really ran and rescanned only a fraction of the units
-        with Handle(emu_api, 400) as h:
+        with Handle(emu_api, 400, lookahead=-1) as h:
             h.set_matrix(oracle.synth(400, 7))
             order, st = h.run()
-        assert st.n_screen_events > 300 and 0 < st.n_rescan_units
+        assert st.n_screen_events > 300 and 0 < st.n_rescan_units and st.n_window_hits == 0
         with Handle(emu_api, 400, disable_screen=True) as h:
             h.set_matrix(oracle.synth(400, 7))
             order2, st2 = h.run()
         assert st2.n_screen_events == 0 and (order == order2).all()
     finally:
         lib.emu_set_screen_debug(0, 0)
+
+
+def test_lookahead_windows_keep_the_exact_result(emu_api, oracle, monkeypatch):
+    """A base scan also emits the pairs whose lower bound for the next K events lies under a
+    threshold; the following events take their minimum from those pairs plus the rows of the
+    clusters created since, and rescan when that cannot be certified.  Whatever K, the wanted list
+    size and the capacity are, every trajectory must match the oracle bit for bit."""
+    rng = np.random.default_rng(11)
+    two = rng.integers(1, 3, size=(70, 70)).astype(np.float64); two = np.triu(two, 1); two = two + two.T
+    neg = oracle.synth(60, 5) - 0.5
+    np.fill_diagonal(neg, 0.0)
+    cases = [(oracle.synth(n, seed, dist), every) for n, seed, dist, every in
+             [(9, 1, "uniform53", 1), (33, 2, "dec4", 1), (64, 3, "uniform53", 1), (131, 4, "uniform53", 3),
+              (200, 5, "dec4", 7), (330, 6, "uniform53", 17)]] + [(two, 3), (neg, 3), (np.ones((40, 40)) - np.eye(40), 1)]
+    total_hits = total_fails = 0
+    for K, target, pcap, mode in [(1, 8192, 0, 0), (3, 4, 0, 2), (8, 64, 0, 4), (64, 8192, 0, 8), (64, 1, 0, 1),
+                                  (512, 8192, 0, 5), (16, 8192, 7, 2), (64, 65536, 300, 6)]:
+        if pcap:
+            monkeypatch.setenv("FNN_LA_PCAP", str(pcap))
+        else:
+            monkeypatch.delenv("FNN_LA_PCAP", raising=False)
+        emu_api.set_order_mode(mode)
+        for D, every in cases:
+            compare_trajectory(emu_api, oracle, D, deep=True, deep_every=every, lookahead=K, lookahead_pairs=target)
+        n = 260
+        D = oracle.synth(n, 9)
+        o_ref, ev_ref, se = oracle.run(D)
+        with Handle(emu_api, n, record_events=True, lookahead=K, lookahead_pairs=target) as h:
+            h.set_matrix(D)
+            order, st = h.run()
+            ev = h.events()
+        assert (order == o_ref).all() and st.sum_entries == se
+        assert (ev["best"].view(np.int64) == ev_ref["best"].view(np.int64)).all()
+        # every event is served by a window or scans (the last few, below 8 live nodes, scan unscreened)
+        assert st.n_events - 8 <= st.n_base_scans + st.n_window_hits <= st.n_events
+        total_hits += st.n_window_hits
+        total_fails += st.n_window_fails
+    assert total_hits > 500 and total_fails > 0
+    # negative entries: the monotonicity argument does not hold, windows stay closed
+    with Handle(emu_api, 60) as h:
+        h.set_matrix(neg)
+        _, st = h.run()
+    assert st.n_window_hits == 0

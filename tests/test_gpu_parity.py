@@ -127,16 +127,20 @@ def test_full_size_invariants(hip_api):
         order, st = h.run()
         ev = h.events()
     check_order(order, n)
-    # the screening pass + exact rescans must reproduce the plain fp64 scan event by event
-    with Handle(hip_api, n, record_events=True, disable_screen=True) as h:
-        h.synth(1, "uniform53")
-        order_plain, st_plain = h.run()
-        ev_plain = h.events()
-    assert st.n_screen_events > 20000 and st_plain.n_screen_events == 0
-    assert (order == order_plain).all()
-    for f in ("m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id"):
-        assert (ev[f] == ev_plain[f]).all(), f
-    assert (bits(ev["best"]) == bits(ev_plain["best"])).all()
+    assert st.n_window_hits > 20000 and st.n_base_scans < 5000
+    # lookahead windows, per-event screening + exact rescans, and the plain fp64 scan of every
+    # event must give the same trajectory event by event
+    for kw in (dict(lookahead=-1), dict(disable_screen=True)):
+        with Handle(hip_api, n, record_events=True, **kw) as h:
+            h.synth(1, "uniform53")
+            order_plain, st_plain = h.run()
+            ev_plain = h.events()
+        assert st_plain.n_window_hits == 0
+        assert (st_plain.n_screen_events == 0) if "disable_screen" in kw else (st_plain.n_screen_events > 20000)
+        assert (order == order_plain).all()
+        for f in ("m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id"):
+            assert (ev[f] == ev_plain[f]).all(), f
+        assert (bits(ev["best"]) == bits(ev_plain["best"])).all()
     assert st.n_events == len(ev)
     # clusters drop by exactly one per event; c <= m <= 2c; counters follow the event kinds
     assert (np.diff(ev["c_before"]) == -1).all()
@@ -169,6 +173,14 @@ from common import compare_trajectory
 a = fa.api()
 for n, seed, dist in [(40, 1, "uniform53"), (300, 2, "dec4"), (1100, 3, "uniform53"), (2100, 4, "uniform53")]:
     compare_trajectory(a, O, O.synth(n, seed, dist), deep=(n < 1000), deep_every=11)
+# lookahead windows: every combination of window length / wanted list size / capacity must give the
+# oracle's trajectory (k_track, the emission pass of k_screen, window failures, list overflow)
+for K, target, pcap in [(-1, 0, 0), (1, 0, 0), (3, 4, 0), (8, 64, 0), (64, 1, 0), (512, 60000, 0), (16, 8192, 7), (64, 65536, 300)]:
+    if pcap: os.environ["FNN_LA_PCAP"] = str(pcap)
+    else: os.environ.pop("FNN_LA_PCAP", None)
+    for n, seed, dist in [(33, 1, "uniform53"), (200, 2, "dec4"), (700, 3, "uniform53")]:
+        compare_trajectory(a, O, O.synth(n, seed, dist), deep=(n < 300), deep_every=7, lookahead=K, lookahead_pairs=target)
+os.environ.pop("FNN_LA_PCAP", None)
 rng = np.random.default_rng(3)
 n = 300
 A = rng.integers(1, 3, size=(n, n)).astype(np.float64); A = np.triu(A, 1); A = A + A.T
@@ -181,7 +193,11 @@ with Handle(a, 3000) as h:
     h.synth(7, "uniform53"); order, st = h.run()
 o_ref, _, _ = O.run(O.synth(3000, 7), threads=8)
 assert (order == o_ref).all()
-assert st.n_screen_events > 2000 and st.n_rescan_units > 0
+assert st.n_window_hits > 2000 and st.n_base_scans > 20 and st.n_rescan_units > 0
+with Handle(a, 3000, lookahead=-1) as h:
+    h.synth(7, "uniform53"); order, st = h.run()
+assert (order == o_ref).all()
+assert st.n_screen_events > 2000 and st.n_window_hits == 0
 print("SCREEN_OK", st.n_screen_events, st.n_rescan_units)
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -201,7 +217,8 @@ def test_screened_run_equals_plain_fp64_run(hip_api):
             order, st = h.run()
             runs.append((order, h.events(), st))
     (o0, e0, s0), (o1, e1, s1) = runs
-    assert s0.n_screen_events == 0 and s1.n_screen_events > 1000
+    assert s0.n_screen_events == 0 and s0.n_window_hits == 0
+    assert s1.n_window_hits > 1000 and s1.n_base_scans > 10   # lookahead windows served most screened events
     assert (o0 == o1).all()
     for f in ("m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id", "entries"):
         assert (e0[f] == e1[f]).all(), f
@@ -218,7 +235,7 @@ def test_screened_run_against_the_oracle(hip_api, oracle):
         h.set_matrix(D, chunk_rows=1024)
         order, st = h.run()
         ev = h.events()
-    assert st.n_screen_events > 2000
+    assert st.n_window_hits > 1000
     assert (order == o_ref).all()
     assert st.sum_entries == se and st.n_events == len(ev_ref)
     for f in ("m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id", "entries"):

@@ -19,4 +19,7 @@ for n in sizes:
               f"scan_GBps={gb / max(st.t_scan_s, 1e-9):.1f} whole_GBps={gb / st.t_total_s:.1f} "
               f"per_event_overhead_us={(st.t_agglom_s - st.t_scan_s) / max(st.n_events, 1) * 1e6:.1f} "
               f"rx_certified={st.n_rx_certified} rx_exact={st.n_rx_exact} screen_events={st.n_screen_events} "
-              f"rescan_units_per_event={st.n_rescan_units / max(st.n_screen_events, 1):.1f}", flush=True)
+              f"rescan_units_per_event={st.n_rescan_units / max(st.n_screen_events, 1):.1f} "
+              f"base_scans={st.n_base_scans} window_hits={st.n_window_hits} window_fails={st.n_window_fails} "
+              f"pairs_per_window={st.window_pairs / max(st.n_base_scans, 1):.0f} bytes_total={st.bytes_total / 1e12:.3f}TB "
+              f"timed_launches={st.scan_launches}", flush=True)
