@@ -33,6 +33,12 @@
 #else
 #define FNN_HD inline
 #endif
+// post-increment of a counter shared by the threads of a launch (a plain ++ in the CPU emulation)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FNN_ATOMIC_INC(p) atomicAdd((p), 1)
+#else
+#define FNN_ATOMIC_INC(p) ((*(p))++)
+#endif
 
 namespace fnn {
 
@@ -104,6 +110,8 @@ struct State {
     int32_t la_k;           // events completed since the window's base scan (the base event included)
     int32_t la_np;          // tracked pairs
     int32_t la_nf;          // clusters created since the base scan ("fresh")
+    int32_t la_nf_done;     // ... of which the first la_nf_done have had their rows swept (pairs inserted)
+    int32_t la_prev_end;    // how the previous window ended: 0 schedule, 1 could not certify, 2 list overflow
     int32_t la_hit;         // this event's minimum came from the window (k_track)
     int32_t la_emit;        // this event's screening pass emits the pairs of a new window
     int32_t la_count;       // emission counter
@@ -114,9 +122,10 @@ struct State {
     float la_theta_pred;    // emission threshold of the open / opening window (fp32)
     double la_theta_eff;    // acceptance threshold: theta_pred minus the error slack
     double la_W;            // window width above the previous event's minimum
+    double la_coef;         // c - 2 - K of the base scan: the coefficient of the window's lower bounds
     double la_mprev;        // previous event's scan minimum
     int64_t n_base_scans, n_la_hits, n_la_fail, n_la_overflow, la_pairs_sum, la_items_sum;
-    int32_t ev_timed, pad_la;  // the host brackets this event's scan launch with HIP events
+    int32_t ev_timed, la_k_prev;  // the host brackets this event's scan launch with HIP events
     int64_t bytes_timed;      // the part of bytes_streamed that belongs to timed scan launches
     // ---- current event ----
     int32_t ev_active, ev_finish, need_rx;
@@ -152,12 +161,14 @@ struct Dev {
     uint16_t* H;     // bf16 screening copy of D (same geometry, H[r][c] == bf16(D[r][c]))
     float* srec;     // screening: per unit [tile][4] lower bounds, then [tile][4] upper bounds
     float* stile;    // screening: per tile lower bound, then per tile upper bound
+    uint64_t* shit;  // screening: per unit, the lanes (8 columns each) that hold a pair under the window's threshold
     int32_t* clist;  // screening: units that may hold the true minimum
     int32_t* islot;  // lookahead: node id -> slot (-1: dead); 3n + 8 entries
     int32_t* cstamp; // lookahead: node id -> n_events + 1 when its current cluster was formed (0: initial)
-    int32_t* tpairs; // lookahead: tracked pairs, 2 node ids each (LA_PCAP pairs)
+    int32_t* tpairs; // lookahead: tracked pairs {id a, id b, cstamp a, cstamp b} (LA_PCAP records)
     int32_t* fresh;  // lookahead: per fresh cluster {representative id, stamp} (LA_KMAX entries)
     uint32_t* ticket; // lookahead: arrival counter of k_track's workgroups
+    double* lalog;   // lookahead diagnostics: per base scan {event, m, W, pairs, events served by the previous window} (LA_LOGCAP records)
     Cand* gsend;     // multi-GPU: this rank's candidate record(s) of the event (<= GATHER_RECS)
     Cand* grecv;     // multi-GPU: all ranks' candidate records
     int32_t la;      // lookahead windows enabled for this run (k_track is part of the launch sequence)
@@ -213,10 +224,13 @@ FNN_HD double qval(double cm2, double dpq, double sxa, int32_t pa, double sxb, i
 // One 2x2 micro-tile of the scan: rows r0, r0+1 (r0 even), columns c0, c0+1
 // (c0 even, c0 <= r0).  e[r][c] are the four matrix entries.  Sx / pos of the two
 // rows and two columns are passed in.  Follows NeighborNetCanonical.java:151-178.
-FNN_HD void scan_micro(int32_t r0, int32_t c0, int32_t m, int32_t twoP, double cm2,
-                       double e00, double e01, double e10, double e11,
-                       double sxr0, double sxr1, int32_t pr0, int32_t pr1,
-                       double sxc0, double sxc1, int32_t pc0, int32_t pc1, Cand& best) {
+// Every cluster pair of the tile goes to sink(q, dpq, sx row node, sx column node, pos row node,
+// pos column node, row slot, column slot); scan_micro's sink keeps the best (Q, i, j).
+template <class Sink>
+FNN_HD void scan_micro_t(int32_t r0, int32_t c0, int32_t m, int32_t twoP, double cm2,
+                         double e00, double e01, double e10, double e11,
+                         double sxr0, double sxr1, int32_t pr0, int32_t pr1,
+                         double sxc0, double sxc1, int32_t pc0, int32_t pc1, Sink&& sink) {
     if (r0 >= m || c0 >= m) return;
     if (r0 < twoP) {
         // rows are one two-node cluster; c0 <= r0 < 2P so the columns are one too
@@ -226,30 +240,40 @@ FNN_HD void scan_micro(int32_t r0, int32_t c0, int32_t m, int32_t twoP, double c
         double dpq;
         if (pr0 > pc0) dpq = (((e00 + e01) + e10) + e11) / 4.0;
         else dpq = (((e00 + e10) + e01) + e11) / 4.0;
-        consider(qval(cm2, dpq, sxr0, pr0, sxc0, pc0), pr0, pc0, best);
+        sink(qval(cm2, dpq, sxr0, pr0, sxc0, pc0), dpq, sxr0, sxc0, pr0, pc0, r0, c0);
     } else if (c0 < twoP) {
         // rows are singletons, columns one two-node cluster: 2-term mean (:165/:167,
         // the two forms add the same two entries in the same order)
         double d0 = (e00 + e01) / 2.0;
-        consider(qval(cm2, d0, sxr0, pr0, sxc0, pc0), pr0, pc0, best);
+        sink(qval(cm2, d0, sxr0, pr0, sxc0, pc0), d0, sxr0, sxc0, pr0, pc0, r0, c0);
         if (r0 + 1 < m) {
             double d1 = (e10 + e11) / 2.0;
-            consider(qval(cm2, d1, sxr1, pr1, sxc0, pc0), pr1, pc0, best);
+            sink(qval(cm2, d1, sxr1, pr1, sxc0, pc0), d1, sxr1, sxc0, pr1, pc0, r0 + 1, c0);
         }
     } else {
         // singletons x singletons: Dpq = D[p][q] (:163); only row > column
         bool c1ok = (c0 + 1 < m), r1ok = (r0 + 1 < m);
         if (r0 > c0) {
-            consider(qval(cm2, e00, sxr0, pr0, sxc0, pc0), pr0, pc0, best);
-            if (c1ok) consider(qval(cm2, e01, sxr0, pr0, sxc1, pc1), pr0, pc1, best);
+            sink(qval(cm2, e00, sxr0, pr0, sxc0, pc0), e00, sxr0, sxc0, pr0, pc0, r0, c0);
+            if (c1ok) sink(qval(cm2, e01, sxr0, pr0, sxc1, pc1), e01, sxr0, sxc1, pr0, pc1, r0, c0 + 1);
             if (r1ok) {
-                consider(qval(cm2, e10, sxr1, pr1, sxc0, pc0), pr1, pc0, best);
-                if (c1ok) consider(qval(cm2, e11, sxr1, pr1, sxc1, pc1), pr1, pc1, best);
+                sink(qval(cm2, e10, sxr1, pr1, sxc0, pc0), e10, sxr1, sxc0, pr1, pc0, r0 + 1, c0);
+                if (c1ok) sink(qval(cm2, e11, sxr1, pr1, sxc1, pc1), e11, sxr1, sxc1, pr1, pc1, r0 + 1, c0 + 1);
             }
         } else {  // diagonal micro-tile: only (r0+1, c0)
-            if (r1ok) consider(qval(cm2, e10, sxr1, pr1, sxc0, pc0), pr1, pc0, best);
+            if (r1ok) sink(qval(cm2, e10, sxr1, pr1, sxc0, pc0), e10, sxr1, sxc0, pr1, pc0, r0 + 1, c0);
         }
     }
+}
+struct BestSink {
+    Cand& best;
+    FNN_HD void operator()(double q, double, double, double, int32_t pa, int32_t pb, int32_t, int32_t) const { consider(q, pa, pb, best); }
+};
+FNN_HD void scan_micro(int32_t r0, int32_t c0, int32_t m, int32_t twoP, double cm2,
+                       double e00, double e01, double e10, double e11,
+                       double sxr0, double sxr1, int32_t pr0, int32_t pr1,
+                       double sxc0, double sxc1, int32_t pc0, int32_t pc1, Cand& best) {
+    scan_micro_t(r0, c0, m, twoP, cm2, e00, e01, e10, e11, sxr0, sxr1, pr0, pr1, sxc0, sxc1, pc0, pc1, BestSink{best});
 }
 
 // ---------------------------------------------------------------------------
@@ -428,8 +452,10 @@ FNN_HD void store_d(const Dev& d, int64_t idx, double v) {
 // as the two representatives' node ids) where theta = previous minimum + W.  In the following
 // events k_track evaluates exactly (fp64, scan_micro: the scan's own body, exact tie-break)
 //   (a) the tracked pairs whose two clusters still exist unchanged, and
-//   (b) every pair that involves a cluster created since the base scan ("fresh": its two rows
-//       are read in full; at most one new cluster per event).
+//   (b) every pair that involves a cluster created since the base scan ("fresh"): the event after
+//       its creation sweeps the new cluster's two rows in full, and every pair whose bound
+//       (c_base - 2 - K) D - S_P - S_Q (exact fp64 this time) lies under theta joins the tracked
+//       list; the others are untracked pairs like any other from then on.
 // Every other live pair is an old, untracked pair with Q >= LB_K - slack > theta - slack =
 // theta_eff.  So if the minimum M over (a) + (b) satisfies M <= theta_eff, it is the global
 // minimum with the reference's tie-break (all ties of M are inside (a) + (b) too), and the event
@@ -438,6 +464,7 @@ FNN_HD void store_d(const Dev& d, int64_t idx, double v) {
 // ---------------------------------------------------------------------------
 constexpr int LA_KMAX = 512;      // fresh clusters per window (>= K)
 constexpr int LA_PCAP = 65536;    // tracked pairs per window
+constexpr int LA_LOGCAP = 8192;   // diagnostic records (one per base scan)
 
 // slack between the fp32 lower bound and the true fp64 Q over the window: the screening slack
 // (screen_delta, applied twice for good measure) plus the rounding drift of the row sums
@@ -456,6 +483,7 @@ FNN_HD bool la_active(const State& st) {
 // this event runs a scan: close the window; decide whether the screening pass opens a new one
 FNN_HD void la_prepare_base(State& st) {
     st.la_hit = 0;
+    if (st.la_valid) st.la_k_prev = st.la_k;
     st.la_valid = 0;
     st.la_emit = 0;
     st.la_count = 0;
@@ -470,15 +498,22 @@ FNN_HD void la_prepare_base(State& st) {
 }
 
 // after the scan of a base event (its exact minimum is already known): open the window
-FNN_HD void la_close_base(State& st) {
+FNN_HD void la_close_base(State& st, double* lalog) {
+    if (lalog && st.n_base_scans < LA_LOGCAP) {
+        double* r = lalog + 5 * st.n_base_scans;
+        r[0] = (double)st.n_events; r[1] = (double)st.m; r[2] = st.la_emit ? st.la_W : -1.0;
+        r[3] = st.la_emit ? (double)st.la_count : -1.0; r[4] = (double)st.la_k_prev;
+    }
     st.n_base_scans++;
     if (!st.la_emit) return;
     st.la_emit = 0;
     const int32_t cnt = st.la_count;
     const double dmax = __builtin_bit_cast(double, st.dmax_bits);
+    const int32_t prev_end = st.la_prev_end;
+    st.la_prev_end = 0;
     if (cnt > st.la_pcap) {  // too many pairs under the threshold: narrower next time, and back off
         st.n_la_overflow++;
-        st.la_W *= 0.5;
+        st.la_W *= 0.6;
         st.la_backoff = st.la_backoff < 1 ? 1 : (st.la_backoff >= 512 ? 1024 : 2 * st.la_backoff);
         st.la_skip = st.la_backoff;
         return;
@@ -488,14 +523,29 @@ FNN_HD void la_close_base(State& st) {
     st.la_np = cnt;
     st.la_k = 0;
     st.la_nf = 0;
+    st.la_nf_done = 0;
     st.la_base_stamp = (int32_t)st.n_events;
     st.la_theta_eff = (double)st.la_theta_pred - la_delta(st);
+    st.la_coef = (double)st.c - 2.0 - (double)st.la_K;
+    if (st.la_coef < 0.0) st.la_coef = 0.0;
     st.la_pairs_sum += cnt;
-    if (cnt > st.la_target) st.la_W *= 0.75;
-    else if (cnt < st.la_target / 4) st.la_W *= 1.5;
+    // width for the next window: wide enough to last its K events, narrow enough for the list
+    if (prev_end == 2) st.la_W *= 0.7;
+    else if (prev_end == 1 && cnt < st.la_pcap / 2) st.la_W *= 1.25;
+    else if (cnt > st.la_target) st.la_W *= 0.9;
     const double wmin = 1e-6 * dmax + 1e-300, wmax = 1e12 * dmax + 1e-300;
     if (!(st.la_W >= wmin)) st.la_W = wmin;
     if (st.la_W > wmax) st.la_W = wmax;
+}
+
+// append a pair (representatives' node ids) to the window's tracked list
+FNN_HD void la_append(const Dev& d, int32_t ia, int32_t ib) {
+    State& st = *d.st;
+    const int32_t i = FNN_ATOMIC_INC(&st.la_count);
+    if (i < st.la_pcap) {
+        int32_t* t = d.tpairs + 4 * (int64_t)i;
+        t[0] = ia; t[1] = ib; t[2] = d.cstamp[ia]; t[3] = d.cstamp[ib];
+    }
 }
 
 // a new two-node cluster with representative id `rep` exists from the next event on
@@ -522,56 +572,90 @@ FNN_HD void pair_eval(const Dev& d, int32_t sa, int32_t sb, int32_t m, int32_t t
 
 // all pairs between the fresh two-node cluster in slots (f0, f0 + 1) and the node(s) in slots
 // (s, s + 1), s even: the four entries are read from ROWS f0, f0 + 1 (contiguous in s; the matrix
-// is bit-symmetric) and handed to the scan's body in the orientation it would have met them
-FNN_HD void fresh_eval(const Dev& d, int32_t f0, int32_t s, int32_t m, int32_t twoP, double cm2, Cand& best) {
+// is bit-symmetric) and handed to the scan's body in the orientation it would have met them.
+// Besides competing for this event's minimum, a pair whose lower bound for the rest of the window
+// lies under the threshold joins the tracked list.
+struct SweepSink {
+    const Dev& d;
+    Cand& best;
+    double coef, th;
+    FNN_HD void operator()(double q, double dpq, double sxa, double sxb, int32_t pa, int32_t pb, int32_t rs, int32_t cs) const {
+        consider(q, pa, pb, best);
+        const double lbf = (coef * dpq - sxa) - sxb;
+        if (lbf <= th) la_append(d, d.sid[rs], d.sid[cs]);
+    }
+};
+FNN_HD void fresh_eval(const Dev& d, int32_t f0, int32_t s, int32_t m, int32_t twoP, double cm2, double coef, double th, Cand& best) {
     if (s >= m || s == f0) return;
     const double* F0 = d.D + (int64_t)f0 * d.ld + s;
     const double* F1 = F0 + d.ld;
     const double a0 = F0[0], a1 = F0[1], b0 = F1[0], b1 = F1[1];
+    const SweepSink sink{d, best, coef, th};
     if (f0 > s)
-        scan_micro(f0, s, m, twoP, cm2, a0, a1, b0, b1, d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1],
-                   d.Sx[s], d.Sx[s + 1], d.spos[s], d.spos[s + 1], best);
+        scan_micro_t(f0, s, m, twoP, cm2, a0, a1, b0, b1, d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1],
+                     d.Sx[s], d.Sx[s + 1], d.spos[s], d.spos[s + 1], sink);
     else
-        scan_micro(s, f0, m, twoP, cm2, a0, b0, a1, b1, d.Sx[s], d.Sx[s + 1], d.spos[s], d.spos[s + 1],
-                   d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1], best);
+        scan_micro_t(s, f0, m, twoP, cm2, a0, b0, a1, b1, d.Sx[s], d.Sx[s + 1], d.spos[s], d.spos[s + 1],
+                     d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1], sink);
 }
 
-// one work item of k_track: item < np: tracked pair; otherwise (fresh cluster, column pair)
-FNN_HD void track_item(const Dev& d, int64_t item, int32_t np, int32_t nf, int32_t m, int32_t twoP, double cm2,
-                       int32_t base_stamp, Cand& best) {
-    if (item < np) {
-        const int32_t ia = d.tpairs[2 * item], ib = d.tpairs[2 * item + 1];
+// one work item of k_track: item < np: tracked pair; otherwise (unswept fresh cluster, column pair)
+struct TrackArgs {
+    int32_t np, nf0, nf, m, twoP;
+    double cm2, coef, th;
+};
+FNN_HD TrackArgs track_args(const State& st) {
+    TrackArgs a;
+    a.np = st.la_np;
+    a.nf = st.la_nf < LA_KMAX ? st.la_nf : LA_KMAX;
+    a.nf0 = st.la_nf_done < a.nf ? st.la_nf_done : a.nf;
+    a.m = st.m;
+    a.twoP = 2 * st.P;
+    a.cm2 = (double)st.c - 2.0;
+    a.coef = st.la_coef;
+    a.th = (double)st.la_theta_pred;
+    return a;
+}
+FNN_HD int64_t track_item_count(const TrackArgs& a) { return (int64_t)a.np + (int64_t)(a.nf - a.nf0) * ((a.m + 1) / 2); }
+FNN_HD void track_item(const Dev& d, int64_t item, const TrackArgs& a, Cand& best) {
+    if (item < a.np) {
+        const int32_t* t = d.tpairs + 4 * item;
+        const int32_t ia = t[0], ib = t[1];
         const int32_t sa = d.islot[ia], sb = d.islot[ib];
-        if (sa < 0 || sb < 0 || d.cstamp[ia] > base_stamp || d.cstamp[ib] > base_stamp) return;
-        pair_eval(d, sa, sb, m, twoP, cm2, best);
+        if (sa < 0 || sb < 0 || d.cstamp[ia] != t[2] || d.cstamp[ib] != t[3]) return;  // a cluster is gone or was re-formed
+        pair_eval(d, sa, sb, a.m, a.twoP, a.cm2, best);
         return;
     }
-    const int64_t r = item - np;
-    const int32_t half = (m + 1) / 2;
-    const int32_t fi = (int32_t)(r / half), cp = (int32_t)(r % half);
-    if (fi >= nf) return;
+    const int64_t r = item - a.np;
+    const int32_t half = (a.m + 1) / 2;
+    const int32_t fi = a.nf0 + (int32_t)(r / half), cp = (int32_t)(r % half);
+    if (fi >= a.nf) return;
     const int32_t id = d.fresh[2 * fi], stamp = d.fresh[2 * fi + 1];
     const int32_t f0 = d.islot[id];
-    if (f0 < 0 || d.cstamp[id] != stamp) return;  // consumed by a later event
-    fresh_eval(d, f0, 2 * cp, m, twoP, cm2, best);
-}
-FNN_HD int64_t track_item_count(const State& st) {
-    const int32_t nf = st.la_nf < LA_KMAX ? st.la_nf : LA_KMAX;
-    return (int64_t)st.la_np + (int64_t)nf * ((st.m + 1) / 2);
+    if (f0 < 0 || d.cstamp[id] != stamp) return;  // already consumed by a later event
+    fresh_eval(d, f0, 2 * cp, a.m, a.twoP, a.cm2, a.coef, a.th, best);
 }
 
 // the window's verdict on the minimum over all items (one thread, after the reduction)
-FNN_HD void la_track_done(const Dev& d, Cand best) {
+FNN_HD void la_track_done(const Dev& d, Cand best, const TrackArgs& a) {
     State& st = *d.st;
     if (best.q <= st.la_theta_eff) {
         st.la_hit = 1;
         st.n_la_hits++;
         d.recs[0] = best;
-        const int64_t items = track_item_count(st);
+        const int64_t items = track_item_count(a);
         st.la_items_sum += items;
         st.bytes_streamed += 32 * items;
+        st.la_nf_done = a.nf;
+        if (st.la_count > st.la_pcap) {  // the sweep found more pairs than the list can take: this
+            st.la_valid = 0;             // event is served, the next one opens a new window
+            st.la_k_prev = st.la_k;
+            st.la_prev_end = 2;
+            st.n_la_overflow++;
+        } else st.la_np = st.la_count;
     } else {
         st.n_la_fail++;
+        st.la_prev_end = 1;
         la_prepare_base(st);
     }
 }

@@ -51,6 +51,7 @@ class Engine {
     int32_t last3[3] = {0, 0, 0};
     int32_t batch = 32;    // events enqueued between host round trips in run()
     int64_t ev_counter = 0;  // events enqueued since begin(): drives the schedule of the lookahead windows' base scans
+    int64_t sched_at = 0;    // event count at which the host expects the open window to have served its K events
     // several GPUs: 0 = single, 1 = RCCL all-gather on the stream, 2 = host callback (tests)
     int32_t comm_mode = 0, world = 1, rank = 0;
     fnn_allgather_fn host_fn = nullptr;
@@ -84,12 +85,14 @@ class Engine {
             !(dev.rxpart = (double*)be.alloc(sizeof(double) * 8 * (nn / 256 + 2))) ||
             !(dev.srec = (float*)be.alloc(sizeof(float) * (2 * (size_t)screen_unit_count(n > 0 ? n : 1) + 16))) ||
             !(dev.stile = (float*)be.alloc(sizeof(float) * (2 * (size_t)screen_unit_count(n > 0 ? n : 1) / 4 + 16))) ||
+            !(dev.shit = (uint64_t*)be.alloc(sizeof(uint64_t) * ((size_t)screen_unit_count(n > 0 ? n : 1) + 16))) ||
             !(dev.clist = (int32_t*)be.alloc(sizeof(int32_t) * SCR_CAP)) ||
             !(dev.islot = (int32_t*)be.alloc(sizeof(int32_t) * (3 * nn + 8))) ||
             !(dev.cstamp = (int32_t*)be.alloc(sizeof(int32_t) * (3 * nn + 8))) ||
-            !(dev.tpairs = (int32_t*)be.alloc(sizeof(int32_t) * 2 * LA_PCAP)) ||
+            !(dev.tpairs = (int32_t*)be.alloc(sizeof(int32_t) * 4 * LA_PCAP)) ||
             !(dev.fresh = (int32_t*)be.alloc(sizeof(int32_t) * 2 * LA_KMAX)) ||
             !(dev.ticket = (uint32_t*)be.alloc(sizeof(uint32_t) * 4)) ||
+            !(dev.lalog = (double*)be.alloc(sizeof(double) * 5 * LA_LOGCAP)) ||
             !(dev.gsend = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS)) ||
             !(dev.grecv = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS * 64)) ||
             !(dev.st = (State*)be.alloc(sizeof(State))) ||
@@ -109,7 +112,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.recs); be.free(dev.rxpart); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.recs); be.free(dev.rxpart); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lalog); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }
@@ -173,7 +176,7 @@ class Engine {
         // lookahead windows (fnn_core.h "Lookahead"): single rank with a screening copy
         {
             int32_t K = opts.lookahead < 0 ? 0 : (opts.lookahead > 0 ? opts.lookahead : 64);
-            int32_t target = opts.lookahead_pairs > 0 ? opts.lookahead_pairs : 8192;
+            int32_t target = opts.lookahead_pairs > 0 ? opts.lookahead_pairs : 32768;
             if (const char* e = std::getenv("FNN_LA_K")) K = std::atoi(e);
             if (const char* e = std::getenv("FNN_LA_TARGET")) target = std::atoi(e);
             if (K > LA_KMAX) K = LA_KMAX;
@@ -185,6 +188,7 @@ class Engine {
             hst.la_min_m = be.screen_min_m;
             dev.la = hst.la_on;
             ev_counter = 0;
+            sched_at = 0;
             hst.la_pcap = LA_PCAP;
             if (const char* e = std::getenv("FNN_LA_PCAP")) { int v = std::atoi(e); if (v >= 1 && v <= LA_PCAP) hst.la_pcap = v; }
         }
@@ -223,6 +227,11 @@ class Engine {
     }
 
     // one event: scan (+ exchange of the per-rank candidates) + the rest of the sequence.
+    // after a state download: when will the open window have served its K events?
+    void resync_schedule() {
+        if (!dev.la) return;
+        sched_at = hst.la_valid ? ev_counter + (hst.la_K + 1 > hst.la_k ? hst.la_K + 1 - hst.la_k : 0) : ev_counter;
+    }
     // A rank contributes nper candidate records (1 after a local reduction, or the scan's
     // GATHER_RECS per-workgroup records as they are).
     int32_t enqueue_event() {
@@ -230,7 +239,8 @@ class Engine {
         // one knows the previous minimum) and then every la_K events; in between a scan only runs
         // if the window fails, which the device finds out by itself
         const int64_t cnt = ev_counter++;
-        const bool sched = !dev.la || cnt == 0 || (cnt - 1) % (hst.la_K > 0 ? hst.la_K : 1) == 0;
+        const bool sched = !dev.la || cnt <= 1 || cnt >= sched_at;
+        if (sched) sched_at = cnt + hst.la_K + 1;
         if (comm_mode == 0) return be.launch_event(dev, m_bound, sched) == FNN_OK ? FNN_OK : fail(FNN_EHIP, "launch failed (" + be.err() + ")");
         int32_t nper = 1;
         if (be.launch_event_scan(dev, m_bound, &nper) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
@@ -259,6 +269,7 @@ class Engine {
         rc = pull_state();
         if (rc != FNN_OK) return rc;
         m_bound = hst.m;
+        resync_schedule();
         if (std::getenv("FNN_DEBUG")) {
             std::fprintf(stderr, "[fnn] m=%d c=%d P=%d nn=%d done=%d active=%d finish=%d need_rx=%d sa=%d sap=%d sb=%d sbp=%d xs=%d ys=%d U=%d nops=%d m_old=%d P_old=%d err=%d\n",
                          hst.m, hst.c, hst.P, hst.num_nodes, hst.done, hst.ev_active, hst.ev_finish, hst.need_rx, hst.sa,
@@ -286,6 +297,7 @@ class Engine {
             int32_t rc = pull_state();
             if (rc != FNN_OK) return rc;
             m_bound = hst.m;
+            resync_schedule();
             if (hst.done) ended = true;
         }
         stats.t_agglom_s = now_s() - t0;

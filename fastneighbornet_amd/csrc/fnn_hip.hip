@@ -293,41 +293,79 @@ __device__ __forceinline__ void screen_tile_nonneg(const Dev& d, int rbase, int 
     }
 }
 
-// Emission pass of a lookahead window (fnn_core.h "Lookahead"): a thread whose columns hold a
-// pair with a lower bound under the window's threshold walks its 32 rows again (they are still in
-// L2) and appends every such pair, as the two representatives' node ids, to the tracked list.
-template <bool NT>
-__device__ __forceinline__ void screen_emit_columns(const Dev& d, int rbase, int c0, int m, int twoP, float k1, float k2, float tp) {
+// Emission pass of a lookahead window (fnn_core.h "Lookahead"), k_emit: k_screen has marked, per
+// unit (32 rows x 512 columns, one wave of a screening tile), the lanes whose 8 columns hold a
+// pair with a lower bound under the window's threshold.  A wave takes such a lane's 32 x 8 block,
+// one 2 x 2 micro-tile per lane, and appends every pair under the threshold, as the two
+// representatives' node ids, to the tracked list.
+constexpr int EMIT_LDS = 2048;  // pairs a workgroup of k_emit collects before it reserves their place in the list
+__global__ __launch_bounds__(256) void k_emit(Dev d) {
+    // (one device-scope atomic on a single address costs ~50 ns on this multi-XCD part: the pairs
+    //  are collected per workgroup in LDS and get their place in the list with ONE atomic add)
+    __shared__ int lcount, lbase;
+    __shared__ int2 lbuf[EMIT_LDS];
     State* st = d.st;
-    const int pcap = st->la_pcap;
-    float sxc[8];
-#pragma unroll
-    for (int k = 0; k < 8; k += 2) {
-        const double2 sv = *reinterpret_cast<const double2*>(d.Sx + c0 + k);
-        sxc[k] = (float)sv.x;
-        sxc[k + 1] = (float)sv.y;
-    }
+    if (st->done || st->la_hit || !st->la_emit) return;
+    const int m = st->m, twoP = 2 * st->P, pcap = st->la_pcap;
+    const float k1 = screen_k1(*st), k2 = screen_k2(*st), tp = st->la_theta_pred;
+    const int nunits = 4 * tri_tile_count(m, SCR_TH, SCR_R);
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), nwaves = (int)gridDim.x * 4;
+    if (threadIdx.x == 0) lcount = 0;
+    __syncthreads();
     auto emit = [&](int32_t rs, int32_t cs, float lb) {
         if (!(lb <= tp)) return;
-        const int i = atomicAdd(&st->la_count, 1);
-        if (i < pcap) { d.tpairs[2 * i] = d.sid[rs]; d.tpairs[2 * i + 1] = d.sid[cs]; }
+        const int i = atomicAdd(&lcount, 1);
+        if (i < EMIT_LDS) lbuf[i] = make_int2(d.sid[rs], d.sid[cs]);
     };
-    Brk dummy;
-    dummy.lb = __builtin_inff();
-    dummy.ub = __builtin_inff();
-    const uint16_t* colbase = d.H + c0;
-#pragma unroll 1
-    for (int r0 = rbase; r0 < rbase + SCR_TH && r0 < m; r0 += 2) {
-        const uint4 a = ld16h<false>(colbase + (int64_t)r0 * d.ld);
-        const uint4 b = ld16h<false>(colbase + (int64_t)(r0 + 1) * d.ld);
-        const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + r0);
-        const float s0 = (float)sxr.x, s1 = (float)sxr.y;
-        const unsigned aw[4] = {a.x, a.y, a.z, a.w};
-        const unsigned bw[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            screen_micro_nn(r0, c0 + 2 * j, m, twoP, k1, k2, bf_lo(aw[j]), bf_hi(aw[j]), bf_lo(bw[j]), bf_hi(bw[j]),
-                            s0, s1, sxc[2 * j], sxc[2 * j + 1], dummy, emit);
+    for (int ub = wave * 64; ub < nunits; ub += nwaves * 64) {
+        // 64 units per step: every lane fetches one unit's mask, the wave then serves the marked ones
+        const int myu = ub + lane;
+        unsigned long long mymask = 0;
+        if (myu < nunits && d.srec[myu] <= tp) mymask = d.shit[myu];
+        unsigned long long any = __ballot(mymask != 0);
+        while (any) {
+            const int src = __builtin_ctzll(any);
+            any &= any - 1;
+            const int u = ub + src;
+            unsigned long long mask = (unsigned long long)__shfl((long long)mymask, src, 64);
+            int rt, ct;
+            tri_tile_decode(u >> 2, SCR_R, rt, ct);
+            const int rbase = rt * SCR_TH, cunit = ct * SCR_TW + (u & 3) * SCR_UW;
+            while (mask) {
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                // lane i: row pair i / 4, column pair i % 4 of the marked lane's 32 x 8 block
+                const int r0 = rbase + 2 * (lane >> 2), c0 = cunit + 8 * l + 2 * (lane & 3);
+                if (r0 >= m || c0 >= m || c0 > r0) continue;
+                const unsigned a = *reinterpret_cast<const unsigned*>(d.H + (int64_t)r0 * d.ld + c0);
+                const unsigned b = *reinterpret_cast<const unsigned*>(d.H + (int64_t)(r0 + 1) * d.ld + c0);
+                const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + r0);
+                const double2 sxc = *reinterpret_cast<const double2*>(d.Sx + c0);
+                Brk dummy;
+                dummy.lb = __builtin_inff();
+                dummy.ub = __builtin_inff();
+                screen_micro_nn(r0, c0, m, twoP, k1, k2, bf_lo(a), bf_hi(a), bf_lo(b), bf_hi(b),
+                                (float)sxr.x, (float)sxr.y, (float)sxc.x, (float)sxc.y, dummy, emit);
+            }
+        }
+    }
+    __syncthreads();
+    const int total = lcount;
+    if (total == 0) return;
+    // a workgroup that found more than it can hold reports a count beyond the capacity, so that the
+    // window is not opened (la_close_base treats it as an overflow)
+    if (threadIdx.x == 0) lbase = atomicAdd(&st->la_count, total > EMIT_LDS ? pcap + 1 : total);
+    __syncthreads();
+    if (total > EMIT_LDS) return;
+    const int base = lbase;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int idx = base + i;
+        if (idx < pcap) {
+            const int2 pr = lbuf[i];
+            int32_t* t = d.tpairs + 4 * (int64_t)idx;
+            t[0] = pr.x; t[1] = pr.y; t[2] = d.cstamp[pr.x]; t[3] = d.cstamp[pr.y];
+        }
     }
 }
 
@@ -344,8 +382,7 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
     const float cm2k = screen_cm2k(*st);
     const float k1 = screen_k1(*st), k2 = screen_k2(*st);
     const bool nonneg = st->nonneg != 0;
-    const bool emit = st->la_emit != 0;
-    const float tp = st->la_theta_pred;
+    const float tp = st->la_emit ? st->la_theta_pred : -__builtin_inff();
     const int ntiles = tri_tile_count(m, SCR_TH, SCR_R);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     float* lbrec = d.srec;
@@ -420,13 +457,13 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
         }
         float lb = __builtin_fminf(__builtin_fminf(lbv[0], lbv[1]), __builtin_fminf(lbv[2], lbv[3]));
         float ub = __builtin_fminf(__builtin_fminf(ubv[0], ubv[1]), __builtin_fminf(ubv[2], ubv[3]));
-        if (emit && lb <= tp) screen_emit_columns<NT>(d, rbase, c0, m, twoP, k1, k2, tp);
+        const unsigned long long hitmask = __ballot(lb <= tp);  // lanes k_emit has to look at
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             lb = __builtin_fminf(lb, __shfl_down(lb, off, 64));
             ub = __builtin_fminf(ub, __shfl_down(ub, off, 64));
         }
-        if (lane == 0) { lbrec[4 * t + w] = lb; ubrec[4 * t + w] = ub; shl[w] = lb; shu[w] = ub; }
+        if (lane == 0) { lbrec[4 * t + w] = lb; ubrec[4 * t + w] = ub; shl[w] = lb; shu[w] = ub; d.shit[4 * t + w] = hitmask; }
         __syncthreads();
         if (threadIdx.x == 0) {
             lbt[t] = __builtin_fminf(__builtin_fminf(shl[0], shl[1]), __builtin_fminf(shl[2], shl[3]));
@@ -441,25 +478,27 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
 // the grid; the last workgroup to arrive reduces the per-workgroup minima and decides whether the
 // window certifies the minimum (la_hit: the scan kernels of this event return at once) or the
 // event has to scan.  force_base: the host's schedule asks for a new window at this event.
-constexpr int TRK_THREADS = 256;
+constexpr int TRK_THREADS = 1024;  // few, large workgroups: every workgroup costs one same-address atomic (~50 ns each)
 __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed) {
     __shared__ Cand sh[TRK_THREADS / 64];
     __shared__ int lastflag;
     State* st = d.st;
     if (st->done) return;
     if (force_base || !la_active(*st)) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) { st->ev_timed = timed; la_prepare_base(*st); }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            st->ev_timed = timed;
+            if (st->la_valid) st->la_prev_end = 0;  // the window ends on schedule
+            la_prepare_base(*st);
+        }
         return;
     }
-    const int m = st->m, twoP = 2 * st->P, np = st->la_np, base_stamp = st->la_base_stamp;
-    const int nf = st->la_nf < LA_KMAX ? st->la_nf : LA_KMAX;
-    const double cm2 = (double)st->c - 2.0;
-    const int64_t items = track_item_count(*st);
+    const TrackArgs ta = track_args(*st);
+    const int64_t items = track_item_count(ta);
     Cand best;
     best.q = inf_f64();
     best.key = ~0ULL;
     for (int64_t it = (int64_t)blockIdx.x * TRK_THREADS + threadIdx.x; it < items; it += (int64_t)gridDim.x * TRK_THREADS)
-        track_item(d, it, np, nf, m, twoP, cm2, base_stamp, best);
+        track_item(d, it, ta, best);
     best = block_reduce<TRK_THREADS / 64>(best, sh);
     if (threadIdx.x == 0) {
         d.recs[blockIdx.x] = best;
@@ -482,7 +521,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     if (threadIdx.x == 0) {
         *d.ticket = 0u;
         st->ev_timed = timed;
-        la_track_done(d, best);
+        la_track_done(d, best, ta);
     }
 }
 
@@ -599,7 +638,7 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d) {
             st->n_screen_events += 1;
             st->n_rescan_units += all ? (int64_t)(4 * ntiles) / d.world : (int64_t)count;
             st->ev_screened = 1;
-            la_close_base(*st);  // (the screening pass may have emitted the pairs of a new lookahead window)
+            la_close_base(*st, d.lalog);  // (the screening pass may have emitted the pairs of a new lookahead window)
         }
     }
 }
@@ -1080,7 +1119,8 @@ struct HipBackend {
     std::string comm_err;
     int scan_grid = 8192;   // workgroups of the scan (FNN_SCAN_GRID)
     int unsched_grid = 2048; // workgroups of the screening launches that only run when a lookahead window fails (FNN_UNSCHED_GRID)
-    int track_grid = 256;   // workgroups of k_track (FNN_TRACK_GRID)
+    int emit_grid = 256;    // workgroups of k_emit (FNN_EMIT_GRID)
+    int track_grid = 32;    // workgroups of k_track (FNN_TRACK_GRID)
     bool scan_nt = true;    // non-temporal matrix loads in the scan (FNN_SCAN_NT)
 
     std::string err() const { return comm_err.empty() ? std::string(hipGetErrorString(last)) : comm_err; }
@@ -1132,6 +1172,7 @@ struct HipBackend {
         if (const char* e = std::getenv("FNN_SCAN_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) scan_grid = v; }
         if (const char* e = std::getenv("FNN_SCAN_NT")) scan_nt = std::atoi(e) != 0;
         if (const char* e = std::getenv("FNN_UNSCHED_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) unsched_grid = v; }
+        if (const char* e = std::getenv("FNN_EMIT_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) emit_grid = v; }
         if (const char* e = std::getenv("FNN_TRACK_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) track_grid = v; }
         if (const char* e = std::getenv("FNN_SCREEN_MIN_M")) { int v = std::atoi(e); if (v >= 8) screen_min_m = v; }
         opened = true;
@@ -1272,6 +1313,7 @@ struct HipBackend {
                 else hipLaunchKernelGGL((k_screen<false, false>), gs, dim3(256), 0, stream, d);
             }
             if (e1) (void)hipEventRecord(e1, stream);
+            if (d.la) hipLaunchKernelGGL(k_emit, dim3(emit_grid), dim3(256), 0, stream, d);
             hipLaunchKernelGGL(k_resolve, dim3(RES_BLOCKS), dim3(1024), 0, stream, d);
             nrecs = RES_BLOCKS;
         } else {
@@ -1424,6 +1466,14 @@ int32_t fnn_get_live_matrix(fnn_handle* h, double* out) {
     if (!out) return fnn::fail(FNN_EINVAL, "fnn_get_live_matrix: out is NULL");
     FNN_TRY(return h->eng.get_live_matrix(out);)
 }
+int64_t fnn_debug_window_log(fnn_handle* h, double* out, int64_t max_records) {
+    if (!h) return fnn::fail(FNN_EINVAL, "NULL handle");
+    if (h->eng.pull_state() != FNN_OK) return FNN_EHIP;
+    int64_t k = h->eng.hst.n_base_scans < fnn::LA_LOGCAP ? h->eng.hst.n_base_scans : fnn::LA_LOGCAP;
+    if (k > max_records) k = max_records;
+    if (out && k > 0 && h->eng.be.d2h(out, h->eng.dev.lalog, sizeof(double) * 5 * (size_t)k) != FNN_OK) return FNN_EHIP;
+    return k;
+}
 int32_t fnn_set_scan_timing(fnn_handle* h, int32_t enable) {
     FNN_NEED(h);
     h->eng.be.timing = enable != 0;
@@ -1510,6 +1560,19 @@ int32_t fnn_test_chain_sum(int32_t device, const double* host_buf, int32_t m, in
     }
     hipLaunchKernelGGL(fnn::k_test_chain<fnn::CH_EPT>, dim3(1), dim3(fnn::CH_T), 0, 0, dbuf, m, guard_bits, dout, dst);
     e = hipDeviceSynchronize();
+    if (std::getenv("FNN_CHAIN_TIME")) {  // development aid: average duration of the kernel
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, 0);
+        for (int i = 0; i < 50; i++)
+            hipLaunchKernelGGL(fnn::k_test_chain<fnn::CH_EPT>, dim3(1), dim3(fnn::CH_T), 0, 0, dbuf, m, guard_bits, dout, dst);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        std::fprintf(stderr, "[fnn] k_test_chain m=%d: %.2f us per launch\n", m, ms * 1e3 / 50);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
     fnn::ChainStats hs{0, 0, 0, 0};
     if (e == hipSuccess) e = hipMemcpy(out, dout, 8, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(&hs, dst, sizeof(hs), hipMemcpyDeviceToHost);

@@ -59,7 +59,7 @@ typedef struct fnn_opts {
                               the minimum, and only those are rescanned in fp64 (same result) */
     int32_t lookahead;     /* events one screening pass may serve ("lookahead window"): 0 = default
                               (64), < 0 = off (every event scans), > 0 = that many; same result either way */
-    int32_t lookahead_pairs;/* wanted number of tracked pairs per window (0 = default 8192) */
+    int32_t lookahead_pairs;/* wanted number of tracked pairs per window (0 = default 32768) */
     int32_t reserved[9];
 } fnn_opts;
 
@@ -147,6 +147,11 @@ int32_t fnn_get_nodes(fnn_handle* h, int32_t* id, int32_t* nbr_id, double* Sx);
 /* Sub-matrix of live nodes in reference position order: out[i*m + j] =
  * D[N[i].distID][N[j].distID], m = num_active. */
 int32_t fnn_get_live_matrix(fnn_handle* h, double* out);
+
+/* Diagnostic: one record of 5 doubles per scanned event of the last run {events done, live nodes,
+ * window width W (-1: no window opened), pairs emitted, events the previous window served}; returns
+ * the number of records copied (at most 8192 are kept). */
+int64_t fnn_debug_window_log(fnn_handle* h, double* out, int64_t max_records);
 
 /* Enable per-launch HIP-event timing of the scan kernel (bench.py's roofline
  * figure).  Adds two event records per scan launch. */

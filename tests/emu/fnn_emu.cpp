@@ -149,9 +149,7 @@ struct EmuBackend {
         float* lbrec = d.srec;
         float* ubrec = d.srec + nunits;
         auto emit = [&](int32_t rs, int32_t cs, float lb) {
-            if (!st.la_emit || !(lb <= st.la_theta_pred)) return;
-            const int32_t i = st.la_count++;
-            if (i < st.la_pcap) { d.tpairs[2 * i] = d.sid[rs]; d.tpairs[2 * i + 1] = d.sid[cs]; }
+            if (st.la_emit && lb <= st.la_theta_pred) fnn::la_append(d, d.sid[rs], d.sid[cs]);
         };
         for (int32_t u : thread_order(nunits)) {
             fnn::Brk b{finf, finf};
@@ -195,7 +193,7 @@ struct EmuBackend {
         } else {
             for (int32_t i : thread_order(st.ncand)) { rescan_unit(d, d.clist[i], best); st.n_rescan_units++; }
         }
-        fnn::la_close_base(st);
+        fnn::la_close_base(st, d.lalog);
         return best;
     }
 
@@ -208,13 +206,14 @@ struct EmuBackend {
             fnn::Cand tb;
             tb.q = fnn::inf_f64();
             tb.key = ~0ULL;
-            const int32_t nf = st.la_nf < fnn::LA_KMAX ? st.la_nf : fnn::LA_KMAX;
-            const double cm2t = (double)st.c - 2.0;
-            for (int32_t it : thread_order((int32_t)fnn::track_item_count(st)))
-                fnn::track_item(d, it, st.la_np, nf, st.m, 2 * st.P, cm2t, st.la_base_stamp, tb);
-            fnn::la_track_done(d, tb);
+            const fnn::TrackArgs ta = fnn::track_args(st);
+            for (int32_t it : thread_order((int32_t)fnn::track_item_count(ta))) fnn::track_item(d, it, ta, tb);
+            fnn::la_track_done(d, tb, ta);
             if (st.la_hit) return d.recs[0];
-        } else fnn::la_prepare_base(st);
+        } else {
+            if (st.la_valid) st.la_prev_end = 0;
+            fnn::la_prepare_base(st);
+        }
         if (d.H && st.m >= screen_min_m) return scan_screened(d);
         fnn::Cand best;
         best.q = fnn::inf_f64();
