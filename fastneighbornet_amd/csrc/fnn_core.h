@@ -114,7 +114,7 @@ struct State {
     int32_t la_prev_end;    // how the previous window ended: 0 schedule, 1 could not certify, 2 list overflow
     int32_t la_hit;         // this event's minimum came from the window (k_track)
     int32_t la_emit;        // this event's screening pass emits the pairs of a new window
-    int32_t la_count;       // emission counter
+    int32_t la_count_unused; // (the append counter of the tracked list lives outside the control block: Dev.lacnt)
     int32_t la_pcap;        // capacity of the tracked-pair list (<= LA_PCAP)
     int32_t la_skip, la_backoff;  // after an overflow: base scans that do not try to open a window
     int32_t la_base_stamp;  // n_events at the base scan: clusters stamped later are fresh
@@ -127,6 +127,9 @@ struct State {
     int64_t n_base_scans, n_la_hits, n_la_fail, n_la_overflow, la_pairs_sum, la_items_sum;
     int32_t ev_timed, la_k_prev;  // the host brackets this event's scan launch with HIP events
     int64_t bytes_timed;      // the part of bytes_streamed that belongs to timed scan launches
+    int64_t n_ev_persistent;  // events completed inside the persistent event kernel
+    int64_t n_su_exact;       // ... of which the sweep had to wait for the exact row sum of the new cluster
+    int64_t ev_ticks[8];      // k_events, workgroup 0: 100 MHz ticks spent in phases A, B, C, wait for the chain, D, barriers
     // ---- current event ----
     int32_t ev_active, ev_finish, need_rx;
     int32_t sa, sap, sb, sbp;  // slots of Cx, Cx.nbr, Cy, Cy.nbr (-1: none)
@@ -168,6 +171,10 @@ struct Dev {
     int32_t* tpairs; // lookahead: tracked pairs {id a, id b, cstamp a, cstamp b} (LA_PCAP records)
     int32_t* fresh;  // lookahead: per fresh cluster {representative id, stamp} (LA_KMAX entries)
     uint32_t* ticket; // lookahead: arrival counter of k_track's workgroups
+    int32_t* lacnt;  // lookahead: append counter of the tracked list (its own word: the control block may be
+                     // cached in LDS by the persistent event kernel while every thread appends)
+    double* upart;   // persistent event kernel: per main workgroup {sum, sum of magnitudes} of the new cluster's row-sum addends
+    uint32_t* evctl; // persistent event kernel: barrier counter, epochs, mailbox (EvCtl)
     double* lalog;   // lookahead diagnostics: per base scan {event, m, W, pairs, events served by the previous window} (LA_LOGCAP records)
     Cand* gsend;     // multi-GPU: this rank's candidate record(s) of the event (<= GATHER_RECS)
     Cand* grecv;     // multi-GPU: all ranks' candidate records
@@ -481,12 +488,12 @@ FNN_HD bool la_active(const State& st) {
 }
 
 // this event runs a scan: close the window; decide whether the screening pass opens a new one
-FNN_HD void la_prepare_base(State& st) {
+FNN_HD void la_prepare_base(State& st, int32_t* lacnt) {
     st.la_hit = 0;
     if (st.la_valid) st.la_k_prev = st.la_k;
     st.la_valid = 0;
     st.la_emit = 0;
-    st.la_count = 0;
+    *lacnt = 0;
     if (st.la_on && st.nonneg && st.screen_ok && !st.done && st.m >= st.la_min_m) {
         if (st.la_skip > 0) st.la_skip--;
         else if (st.la_have_mprev) {
@@ -498,16 +505,16 @@ FNN_HD void la_prepare_base(State& st) {
 }
 
 // after the scan of a base event (its exact minimum is already known): open the window
-FNN_HD void la_close_base(State& st, double* lalog) {
+FNN_HD void la_close_base(State& st, double* lalog, const int32_t* lacnt) {
     if (lalog && st.n_base_scans < LA_LOGCAP) {
         double* r = lalog + 5 * st.n_base_scans;
         r[0] = (double)st.n_events; r[1] = (double)st.m; r[2] = st.la_emit ? st.la_W : -1.0;
-        r[3] = st.la_emit ? (double)st.la_count : -1.0; r[4] = (double)st.la_k_prev;
+        r[3] = st.la_emit ? (double)*lacnt : -1.0; r[4] = (double)st.la_k_prev;
     }
     st.n_base_scans++;
     if (!st.la_emit) return;
     st.la_emit = 0;
-    const int32_t cnt = st.la_count;
+    const int32_t cnt = *lacnt;
     const double dmax = __builtin_bit_cast(double, st.dmax_bits);
     const int32_t prev_end = st.la_prev_end;
     st.la_prev_end = 0;
@@ -541,7 +548,7 @@ FNN_HD void la_close_base(State& st, double* lalog) {
 // append a pair (representatives' node ids) to the window's tracked list
 FNN_HD void la_append(const Dev& d, int32_t ia, int32_t ib) {
     State& st = *d.st;
-    const int32_t i = FNN_ATOMIC_INC(&st.la_count);
+    const int32_t i = FNN_ATOMIC_INC(d.lacnt);
     if (i < st.la_pcap) {
         int32_t* t = d.tpairs + 4 * (int64_t)i;
         t[0] = ia; t[1] = ib; t[2] = d.cstamp[ia]; t[3] = d.cstamp[ib];
@@ -585,24 +592,29 @@ struct SweepSink {
         if (lbf <= th) la_append(d, d.sid[rs], d.sid[cs]);
     }
 };
-FNN_HD void fresh_eval(const Dev& d, int32_t f0, int32_t s, int32_t m, int32_t twoP, double cm2, double coef, double th, Cand& best) {
+FNN_HD void fresh_eval(const Dev& d, int32_t f0, int32_t s, int32_t m, int32_t twoP, double cm2, double coef, double th,
+                       double sxf0, double sxf1, Cand& best) {
     if (s >= m || s == f0) return;
     const double* F0 = d.D + (int64_t)f0 * d.ld + s;
     const double* F1 = F0 + d.ld;
     const double a0 = F0[0], a1 = F0[1], b0 = F1[0], b1 = F1[1];
     const SweepSink sink{d, best, coef, th};
     if (f0 > s)
-        scan_micro_t(f0, s, m, twoP, cm2, a0, a1, b0, b1, d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1],
+        scan_micro_t(f0, s, m, twoP, cm2, a0, a1, b0, b1, sxf0, sxf1, d.spos[f0], d.spos[f0 + 1],
                      d.Sx[s], d.Sx[s + 1], d.spos[s], d.spos[s + 1], sink);
     else
         scan_micro_t(s, f0, m, twoP, cm2, a0, b0, a1, b1, d.Sx[s], d.Sx[s + 1], d.spos[s], d.spos[s + 1],
-                     d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1], sink);
+                     sxf0, sxf1, d.spos[f0], d.spos[f0 + 1], sink);
 }
 
 // one work item of k_track: item < np: tracked pair; otherwise (unswept fresh cluster, column pair)
 struct TrackArgs {
     int32_t np, nf0, nf, m, twoP;
     double cm2, coef, th;
+    // persistent event kernel: the swept cluster's exact row sum may still be on its way; the sweep
+    // then runs with the tree-ordered sum `sxu` and its pairs compete in a separate record
+    int32_t approx;
+    double sxu;
 };
 FNN_HD TrackArgs track_args(const State& st) {
     TrackArgs a;
@@ -614,10 +626,13 @@ FNN_HD TrackArgs track_args(const State& st) {
     a.cm2 = (double)st.c - 2.0;
     a.coef = st.la_coef;
     a.th = (double)st.la_theta_pred;
+    a.approx = 0;
+    a.sxu = 0.0;
     return a;
 }
 FNN_HD int64_t track_item_count(const TrackArgs& a) { return (int64_t)a.np + (int64_t)(a.nf - a.nf0) * ((a.m + 1) / 2); }
-FNN_HD void track_item(const Dev& d, int64_t item, const TrackArgs& a, Cand& best) {
+// `bestu` receives the swept pairs when the sweep runs on an approximate row sum (a.approx)
+FNN_HD void track_item(const Dev& d, int64_t item, const TrackArgs& a, Cand& best, Cand& bestu) {
     if (item < a.np) {
         const int32_t* t = d.tpairs + 4 * item;
         const int32_t ia = t[0], ib = t[1];
@@ -633,30 +648,42 @@ FNN_HD void track_item(const Dev& d, int64_t item, const TrackArgs& a, Cand& bes
     const int32_t id = d.fresh[2 * fi], stamp = d.fresh[2 * fi + 1];
     const int32_t f0 = d.islot[id];
     if (f0 < 0 || d.cstamp[id] != stamp) return;  // already consumed by a later event
-    fresh_eval(d, f0, 2 * cp, a.m, a.twoP, a.cm2, a.coef, a.th, best);
+    // (insertion with the approximate sum: its error, ~1e-16 m n Dmax, is far inside the gap la_delta ~ 1e-6 n Dmax
+    //  between the insertion threshold theta_pred and the acceptance threshold theta_eff)
+    if (a.approx) fresh_eval(d, f0, 2 * cp, a.m, a.twoP, a.cm2, a.coef, a.th, a.sxu, a.sxu, bestu);
+    else fresh_eval(d, f0, 2 * cp, a.m, a.twoP, a.cm2, a.coef, a.th, d.Sx[f0], d.Sx[f0 + 1], best);
 }
+FNN_HD void track_item(const Dev& d, int64_t item, const TrackArgs& a, Cand& best) { track_item(d, item, a, best, best); }
 
 // the window's verdict on the minimum over all items (one thread, after the reduction)
+FNN_HD void la_track_hit(const Dev& d, const TrackArgs& a);
 FNN_HD void la_track_done(const Dev& d, Cand best, const TrackArgs& a) {
     State& st = *d.st;
     if (best.q <= st.la_theta_eff) {
+        d.recs[0] = best;
+        la_track_hit(d, a);
+    } else {
+        st.n_la_fail++;
+        st.la_prev_end = 1;
+        la_prepare_base(st, d.lacnt);
+    }
+}
+FNN_HD void la_track_hit(const Dev& d, const TrackArgs& a) {
+    State& st = *d.st;
+    {
         st.la_hit = 1;
         st.n_la_hits++;
-        d.recs[0] = best;
         const int64_t items = track_item_count(a);
         st.la_items_sum += items;
         st.bytes_streamed += 32 * items;
         st.la_nf_done = a.nf;
-        if (st.la_count > st.la_pcap) {  // the sweep found more pairs than the list can take: this
+        const int32_t cnt = *d.lacnt;
+        if (cnt > st.la_pcap) {  // the sweep found more pairs than the list can take: this
             st.la_valid = 0;             // event is served, the next one opens a new window
             st.la_k_prev = st.la_k;
             st.la_prev_end = 2;
             st.n_la_overflow++;
-        } else st.la_np = st.la_count;
-    } else {
-        st.n_la_fail++;
-        st.la_prev_end = 1;
-        la_prepare_base(st);
+        } else st.la_np = cnt;
     }
 }
 
@@ -1075,9 +1102,9 @@ FNN_HD void op_thread(const Dev& d, const Op& op, int32_t k) {
 }
 
 // updateClusterDistances(u), per-node part (NetMakerOriginal.java:520-533). New layout.
-FNN_HD void add_thread(const Dev& d, int32_t s) {
+FNN_HD double add_thread(const Dev& d, int32_t s) {
     const State& st = *d.st;
-    if (s >= st.m) return;
+    if (s >= st.m) return 0.0;
     int32_t twoP = 2 * st.P;
     int32_t U = st.U, V = st.U + 1;
     const double* D = d.D; const int64_t ld = d.ld;
@@ -1093,6 +1120,7 @@ FNN_HD void add_thread(const Dev& d, int32_t s) {
         val = dpu;
     }
     d.chain[chain_addr(d.spos[s])] = val;  // adding +0.0 to a running sum that starts at +0.0 changes no bit
+    return val;  // (this node's addend of the new cluster's row sum)
 }
 
 FNN_HD double tgt_value(const Tgt& t, const double* D, int64_t ld, int32_t c) {
@@ -1111,13 +1139,13 @@ FNN_HD double tgt_value(const Tgt& t, const double* D, int64_t ld, int32_t c) {
 // Reads only rows of involved slots at its own column(s) and writes only entries with
 // exactly one index equal to its own column(s), so it cannot conflict with any other thread;
 // the involved slots themselves are handled by update_special_*.
-FNN_HD void update_bulk(const Dev& d, int32_t k) {
+FNN_HD double update_bulk(const Dev& d, int32_t k) {
     const State& st = *d.st;
-    if (k >= st.m_old) return;
+    if (k >= st.m_old) return 0.0;
     const int32_t twoP = 2 * st.P_old;
     const bool paired = k < twoP;
-    if (paired && (k & 1)) return;  // the even thread of a two-node cluster does both columns
-    for (int i = 0; i < st.nS; i++) if (st.S[i] == k) return;
+    if (paired && (k & 1)) return 0.0;  // the even thread of a two-node cluster does both columns
+    for (int i = 0; i < st.nS; i++) if (st.S[i] == k) return 0.0;
     double* D = d.D; const int64_t ld = d.ld;
     double sx0 = 0.0, sx1 = 0.0;
     if (!st.ev_finish) {
@@ -1173,23 +1201,29 @@ FNN_HD void update_bulk(const Dev& d, int32_t k) {
             d.Sx[k + 1] = sx1 + dpu;
             d.chain[chain_addr(d.spos[k + 1])] = 0.0;
         }
+        return dpu;  // (this cluster's addend of the new cluster's row sum)
     }
+    return 0.0;
 }
 
 // The involved slots (<= MAX_S columns) go through the per-column bodies above in phases:
 // phase 0 subtract, phases 1..nops one micro-op each, last phase add.  Within a phase the
 // columns are independent; phases are separated by a workgroup barrier on the GPU.
 FNN_HD int32_t update_special_phases(const State& st) { return st.nops + 2; }
-FNN_HD void update_special(const Dev& d, int32_t phase, int32_t i) {
+FNN_HD double update_special(const Dev& d, int32_t phase, int32_t i) {
     const State& st = *d.st;
-    if (i >= st.nS) return;
+    if (i >= st.nS) return 0.0;
     const int32_t k = st.S[i];
     if (phase == 0) { if (!st.ev_finish) subtract_thread(d, k); }
     else if (phase <= st.nops) { Op op = st.ops[phase - 1]; op_thread(d, op, k); }
-    else { if (!st.ev_finish) add_thread(d, k); }
+    else { if (!st.ev_finish) return add_thread(d, k); }
+    return 0.0;
 }
 
 // u.Sx = sequential sum; u.nbr.Sx = u.Sx (:518-519, 532, 535); close the event
+// everything that closes an event except the new cluster's exact row sum (the persistent event
+// kernel computes that sum beside the next event, see k_events)
+FNN_HD void close_event(const Dev& d);
 FNN_HD void finalize(const Dev& d, double usx) {
     State& st = *d.st;
     if (!st.ev_finish) {
@@ -1199,6 +1233,10 @@ FNN_HD void finalize(const Dev& d, double usx) {
         d.Sx[st.U] = 0.0;
         d.Sx[st.U + 1] = 0.0;
     }
+    close_event(d);
+}
+FNN_HD void close_event(const Dev& d) {
+    State& st = *d.st;
     if (st.record_events) d.evlog[st.n_events] = st.cur;
     if (st.la_valid) st.la_k += 1;
     if (!st.ev_finish) { st.la_mprev = st.cur.best; st.la_have_mprev = 1; }

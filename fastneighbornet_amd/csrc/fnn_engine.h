@@ -92,7 +92,10 @@ class Engine {
             !(dev.tpairs = (int32_t*)be.alloc(sizeof(int32_t) * 4 * LA_PCAP)) ||
             !(dev.fresh = (int32_t*)be.alloc(sizeof(int32_t) * 2 * LA_KMAX)) ||
             !(dev.ticket = (uint32_t*)be.alloc(sizeof(uint32_t) * 4)) ||
+            !(dev.lacnt = (int32_t*)be.alloc(256)) ||
             !(dev.lalog = (double*)be.alloc(sizeof(double) * 5 * LA_LOGCAP)) ||
+            !(dev.upart = (double*)be.alloc(sizeof(double) * 2 * 64)) ||
+            !(dev.evctl = (uint32_t*)be.alloc(1024)) ||
             !(dev.gsend = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS)) ||
             !(dev.grecv = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS * 64)) ||
             !(dev.st = (State*)be.alloc(sizeof(State))) ||
@@ -112,7 +115,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.recs); be.free(dev.rxpart); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lalog); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.recs); be.free(dev.rxpart); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.lalog); be.free(dev.upart); be.free(dev.evctl); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }
@@ -196,7 +199,7 @@ class Engine {
             return fail(FNN_EHIP, "fnn_begin: state upload failed (" + be.err() + ")");
         if (be.memset(dev.islot, 0xFF, sizeof(int32_t) * (3 * (size_t)(n > 0 ? n : 1) + 8)) != FNN_OK ||
             be.memset(dev.cstamp, 0, sizeof(int32_t) * (3 * (size_t)(n > 0 ? n : 1) + 8)) != FNN_OK ||
-            be.memset(dev.ticket, 0, sizeof(uint32_t) * 4) != FNN_OK)
+            be.memset(dev.ticket, 0, sizeof(uint32_t) * 4) != FNN_OK || be.memset(dev.lacnt, 0, 256) != FNN_OK)
             return fail(FNN_EHIP, "fnn_begin: memset failed (" + be.err() + ")");
         if (n > 3) {
             if (dev.H && be.launch_prep_screen(dev, nrows) != FNN_OK)
@@ -227,6 +230,8 @@ class Engine {
     }
 
     // one event: scan (+ exchange of the per-rank candidates) + the rest of the sequence.
+    // window hits run inside the persistent event kernel (single rank, screened regime)
+    bool use_events() const { return dev.la && be.persistent && comm_mode == 0 && m_bound >= be.screen_min_m; }
     // after a state download: when will the open window have served its K events?
     void resync_schedule() {
         if (!dev.la) return;
@@ -234,12 +239,14 @@ class Engine {
     }
     // A rank contributes nper candidate records (1 after a local reduction, or the scan's
     // GATHER_RECS per-workgroup records as they are).
-    int32_t enqueue_event() {
+    // force_sched: -1 = follow the schedule, 0 / 1 = the caller knows whether this event scans
+    int32_t enqueue_event(int force_sched = -1) {
         // lookahead windows: a new window is opened (base scan) at the first two events (the second
         // one knows the previous minimum) and then every la_K events; in between a scan only runs
         // if the window fails, which the device finds out by itself
         const int64_t cnt = ev_counter++;
-        const bool sched = !dev.la || cnt <= 1 || cnt >= sched_at;
+        bool sched = !dev.la || cnt <= 1 || cnt >= sched_at;
+        if (force_sched >= 0) sched = force_sched != 0;
         if (sched) sched_at = cnt + hst.la_K + 1;
         if (comm_mode == 0) return be.launch_event(dev, m_bound, sched) == FNN_OK ? FNN_OK : fail(FNN_EHIP, "launch failed (" + be.err() + ")");
         int32_t nper = 1;
@@ -263,11 +270,22 @@ class Engine {
     int32_t step(fnn_event* ev) {
         if (!begun) return fail(FNN_ESTATE, "fnn_step: call fnn_begin first");
         if (ended) return 0;
-        int32_t rc = enqueue_event();
-        if (rc != FNN_OK) return rc;
-        if (be.sync() != FNN_OK) return fail(FNN_EHIP, "fnn_step: sync failed (" + be.err() + ")");
-        rc = pull_state();
-        if (rc != FNN_OK) return rc;
+        int32_t rc;
+        bool served = false;
+        if (use_events() && hst.la_valid) {  // one event inside the persistent kernel, if the open window can serve it
+            const int64_t before = hst.n_events;
+            if (be.launch_events(dev, 1) != FNN_OK || be.sync() != FNN_OK) return fail(FNN_EHIP, "fnn_step: launch failed (" + be.err() + ")");
+            rc = pull_state();
+            if (rc != FNN_OK) return rc;
+            served = hst.n_events > before;
+        }
+        if (!served) {
+            rc = enqueue_event(use_events() ? (hst.la_valid ? 0 : 1) : -1);
+            if (rc != FNN_OK) return rc;
+            if (be.sync() != FNN_OK) return fail(FNN_EHIP, "fnn_step: sync failed (" + be.err() + ")");
+            rc = pull_state();
+            if (rc != FNN_OK) return rc;
+        }
         m_bound = hst.m;
         resync_schedule();
         if (std::getenv("FNN_DEBUG")) {
@@ -290,7 +308,10 @@ class Engine {
         double t0 = now_s();
         while (!ended) {
             for (int i = 0; i < batch; i++) {
-                int32_t rce = enqueue_event();
+                // the persistent kernel serves the open window; whatever event is left then needs a scan
+                const bool evm = use_events();
+                if (evm && be.launch_events(dev, hst.la_K + 2) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
+                int32_t rce = enqueue_event(evm ? 1 : -1);
                 if (rce != FNN_OK) return rce;
             }
             if (be.sync() != FNN_OK) return fail(FNN_EHIP, "fnn_run: sync failed (" + be.err() + ")");
@@ -348,6 +369,8 @@ class Engine {
         stats.n_window_hits = hst.n_la_hits;
         stats.n_window_fails = hst.n_la_fail;
         stats.window_pairs = hst.la_pairs_sum;
+        stats.n_events_persistent = hst.n_ev_persistent;
+        stats.n_sweeps_exact = hst.n_su_exact;
         be.collect_timing(stats);
         return rc;
     }

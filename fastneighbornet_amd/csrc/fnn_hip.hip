@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void k_emit(Dev d) {
     if (total == 0) return;
     // a workgroup that found more than it can hold reports a count beyond the capacity, so that the
     // window is not opened (la_close_base treats it as an overflow)
-    if (threadIdx.x == 0) lbase = atomicAdd(&st->la_count, total > EMIT_LDS ? pcap + 1 : total);
+    if (threadIdx.x == 0) lbase = atomicAdd(d.lacnt, total > EMIT_LDS ? pcap + 1 : total);
     __syncthreads();
     if (total > EMIT_LDS) return;
     const int base = lbase;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             st->ev_timed = timed;
             if (st->la_valid) st->la_prev_end = 0;  // the window ends on schedule
-            la_prepare_base(*st);
+            la_prepare_base(*st, d.lacnt);
         }
         return;
     }
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d) {
             st->n_screen_events += 1;
             st->n_rescan_units += all ? (int64_t)(4 * ntiles) / d.world : (int64_t)count;
             st->ev_screened = 1;
-            la_close_base(*st, d.lalog);  // (the screening pass may have emitted the pairs of a new lookahead window)
+            la_close_base(*st, d.lalog, d.lacnt);  // (the screening pass may have emitted the pairs of a new lookahead window)
         }
     }
 }
@@ -962,10 +962,7 @@ __device__ __forceinline__ void decide_on_lds_copy(const Dev& d, State& lst, con
     }
 }
 
-__global__ __launch_bounds__(CH_T) void k_decide4(Dev d, int nparts) {
-    __shared__ ChainLds<CH_EPT> L;
-    __shared__ State lst;
-    __shared__ double red[8];
+__device__ __forceinline__ void decide4_body(const Dev& d, int nparts, ChainLds<CH_EPT>& L, State& lst, double* red) {
     State* st = d.st;
     if (!st->ev_active || st->ev_finish) return;
     const int need_rx = st->need_rx;
@@ -1004,6 +1001,13 @@ __global__ __launch_bounds__(CH_T) void k_decide4(Dev d, int nparts) {
     decide_on_lds_copy(d, lst, rxa, need_rx != 0, certified);
 }
 
+__global__ __launch_bounds__(CH_T) void k_decide4(Dev d, int nparts) {
+    __shared__ ChainLds<CH_EPT> L;
+    __shared__ State lst;
+    __shared__ double red[8];
+    decide4_body(d, nparts, L, lst, red);
+}
+
 // ------------------------------------------------------------------ k_update
 // subtract + every micro-op + add of one event in ONE launch (fnn_core.h: update_bulk /
 // update_special).  The last workgroup handles the <= 8 involved slots in phases.
@@ -1029,6 +1033,354 @@ __global__ __launch_bounds__(CH_T) void k_finalize(Dev d) {
     double usx = 0.0;
     if (!st->ev_finish) usx = block_chain_sum<CH_EPT>(d.chain, st->m, CH_GUARD_BITS, L, nullptr);
     if (threadIdx.x == 0) finalize(d, usx);
+}
+
+// ------------------------------------------------------------------ k_events
+// Persistent event kernel: while a lookahead window is open, whole events run inside ONE launch.
+// gridDim.x - 1 "main" workgroups of 1024 threads share the slots (thread-stride loops) and meet
+// at four grid barriers per event:
+//   A  track: tracked pairs + the sweep of the newest cluster's rows        (k_track's body)
+//   B  everybody reduces the records, checks the window, forms Cx / Cy, ComputeRx terms (k_rx_fill's)
+//   C  workgroup 0: certified 4-candidate choice + merge plan                (k_decide4's)
+//   D  fused update of all columns, the involved slots in the last main workgroup (k_update's),
+//      close of the event.
+// The exact sequential row sum of the new cluster u (k_finalize's chain, ~20 us) is computed by the
+// extra "chain" workgroup BESIDE phases A - C of the next event: only u's own row sweep needs u.Sx
+// there, and it runs on the tree-ordered sum first.  Its pairs compete in a separate record; the
+// tree sum is within eps of the exact one, so if the best swept pair is further than the margin
+// above the best other pair, the winner (an exactly evaluated pair) is certain.  Otherwise the main
+// workgroups wait for the chain and sweep once more with the exact sum.  Phase D of the next event
+// (the first to modify u.Sx) always waits for the chain.  Anything but a window hit (window
+// expired or failed, loop end, too few live nodes) makes all workgroups leave; the host-driven
+// launch sequence then handles that event.
+struct EvCtl {  // zeroed by the host before every launch; hot words on separate cache lines
+    unsigned bar_count, pad0[31];
+    unsigned upd_epoch, pad1[31];    // events (1-based, this launch) whose update is complete
+    unsigned chain_epoch, pad2[31];  // events whose exact u.Sx has been written
+    unsigned stop, abort_, pad3[30]; // stop: main workgroups have left after `stop - 1` events
+    int req_m, req_U, pad4[30];      // mailbox of the chain request
+};
+static_assert(sizeof(EvCtl) <= 1024, "EvCtl");
+
+constexpr long EV_SPIN_LIMIT = 4000000;  // ~ seconds; a wait this long means something is broken: give up, never hang
+
+__device__ __forceinline__ unsigned ev_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ev_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// thread 0 waits until *p >= want (or the abort flag); returns false on abort / timeout
+__device__ __forceinline__ bool ev_wait(EvCtl* ctl, const unsigned* p, unsigned want) {
+    __shared__ int ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long spins = 0;
+        int good = 1;
+        while (ev_load(p) < want) {
+            if (ev_load(&ctl->abort_) || ++spins > EV_SPIN_LIMIT) { ev_store(&ctl->abort_, 1u); good = 0; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __threadfence();
+        ok = good;
+    }
+    __syncthreads();
+    return ok != 0;
+}
+// barrier over the nmain main workgroups; `round` counts this workgroup's barriers
+__device__ __forceinline__ bool ev_barrier(EvCtl* ctl, unsigned& round, unsigned nmain) {
+    __syncthreads();
+    round += 1;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(&ctl->bar_count, 1u);
+    }
+    return ev_wait(ctl, &ctl->bar_count, round * nmain);
+}
+
+__device__ __forceinline__ Cand ev_reduce_records(const Cand* recs, int n, Cand* sh) {
+    Cand best;
+    best.q = inf_f64();
+    best.key = ~0ULL;
+    for (int i = threadIdx.x; i < n; i += CH_T) {
+        Cand c = recs[i];
+        if (cand_better(c, best)) best = c;
+    }
+    __syncthreads();
+    best = block_reduce<CH_T / 64>(best, sh);
+    __shared__ Cand bc;
+    if (threadIdx.x == 0) bc = best;
+    __syncthreads();
+    best = bc;
+    __syncthreads();
+    return best;
+}
+
+constexpr int EV_REC_U = 256, EV_REC_X = 512;  // offsets of the swept-pair records in d.recs
+
+__global__ __launch_bounds__(CH_T) void k_events(Dev d, int max_events) {
+    __shared__ ChainLds<CH_EPT> L;
+    __shared__ State lst;
+    __shared__ double red[16][10];
+    __shared__ Cand shc[16];
+    __shared__ int zsh[6];
+    State* st = d.st;
+    EvCtl* ctl = reinterpret_cast<EvCtl*>(d.evctl);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nmain = (int)gridDim.x - 1, w = (int)blockIdx.x;
+
+    if (w == nmain) {
+        // ---- the chain workgroup: exact sequential row sum of the new cluster of every event
+        for (unsigned e = 1;; e++) {
+            __shared__ int go;
+            __syncthreads();
+            if (tid == 0) {
+                long spins = 0;
+                int g = 1;
+                while (ev_load(&ctl->upd_epoch) < e) {
+                    const unsigned stop = ev_load(&ctl->stop);
+                    if (stop != 0 && stop <= e) { g = 0; break; }  // the main workgroups left after e - 1 events
+                    if (ev_load(&ctl->abort_) || ++spins > 8 * EV_SPIN_LIMIT) { ev_store(&ctl->abort_, 1u); g = 0; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __threadfence();
+                go = g;
+            }
+            __syncthreads();
+            if (!go) return;
+            const int cm = ctl->req_m, cu = ctl->req_U;
+            const double usx = block_chain_sum<CH_EPT>(d.chain, cm, CH_GUARD_BITS, L, nullptr);
+            if (tid == 0) {
+                d.Sx[cu] = usx;      // u.Sx and u.nbr.Sx (NetMakerOriginal.java:532, 535)
+                d.Sx[cu + 1] = usx;
+                __threadfence();
+                ev_store(&ctl->chain_epoch, e);
+            }
+        }
+    }
+
+    // ---- main workgroups.  Every workgroup works on an LDS copy of the control block (one coalesced
+    // load instead of dozens of dependent global accesses); workgroup 0 is its only writer and
+    // publishes it before the barrier that ends a phase in which it changed.
+    long long tk = 0, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool prof = (w == 0 && tid == 0);
+#define EV_TICK(slot) do { if (prof) { const long long now_ = (long long)wall_clock64(); tacc[slot] += now_ - tk; tk = now_; } } while (0)
+    if (prof) tk = (long long)wall_clock64();
+    constexpr int NW = (int)(sizeof(State) / 4);
+    auto state_in = [&]() {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(st);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&lst);
+        __syncthreads();
+        for (int i = tid; i < NW; i += CH_T) dst[i] = src[i];
+        __syncthreads();
+    };
+    auto state_out = [&]() {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&lst);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(st);
+        __syncthreads();
+        for (int i = tid; i < NW; i += CH_T) dst[i] = src[i];
+    };
+    Dev dl = d;
+    dl.st = &lst;
+    unsigned round = 0;
+    int ev = 0;
+    bool aborted = false, failed = false;
+    for (;; ev++) {
+        if (w != 0 || ev == 0) state_in();
+        if (ev >= max_events || lst.done || lst.error || !la_active(lst)) break;
+        // ---- A: track
+        TrackArgs ta = track_args(lst);
+        double eps_u = 0.0;
+        if (ev > 0 && ta.nf > ta.nf0) {  // the newest cluster's exact row sum is on its way: tree-ordered sum first
+            if (tid < 64) {
+                double su = 0.0, sa = 0.0;
+                for (int b = tid; b < nmain; b += 64) { su += d.upart[2 * b]; sa += d.upart[2 * b + 1]; }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) { su += __shfl_down(su, off, 64); sa += __shfl_down(sa, off, 64); }
+                if (tid == 0) { red[0][8] = su; red[0][9] = sa; }
+            }
+            __syncthreads();
+            ta.approx = 1;
+            ta.sxu = red[0][8];
+            // both the sequential and the tree order are within gamma_m sum|terms| of the exact sum
+            eps_u = 4.0 * ((double)ta.m + 8.0) * 1.1102230246251565e-16 * red[0][9];
+            __syncthreads();
+        }
+        const int64_t items = track_item_count(ta);
+        Cand bo, bu;
+        bo.q = inf_f64(); bo.key = ~0ULL;
+        bu = bo;
+        for (int64_t it = (int64_t)w * CH_T + tid; it < items; it += (int64_t)nmain * CH_T) track_item(d, it, ta, bo, bu);
+        bo = block_reduce<CH_T / 64>(bo, shc);
+        if (tid == 0) d.recs[w] = bo;
+        __syncthreads();
+        bu = block_reduce<CH_T / 64>(bu, shc);
+        if (tid == 0) d.recs[EV_REC_U + w] = bu;
+        EV_TICK(0);
+        if (!ev_barrier(ctl, round, nmain)) { aborted = true; break; }
+        EV_TICK(5);
+        // ---- B: the event's minimum; every main workgroup derives the same verdict
+        bo = ev_reduce_records(d.recs, nmain, shc);
+        Cand best = bo;
+        if (ta.approx) {
+            bu = ev_reduce_records(d.recs + EV_REC_U, nmain, shc);
+            // |Q~ - Q| <= eps_u + the roundings of (c-2) D - Sp - Sq, each <= 2^-53 of a term <= (c + 2n) Dmax
+            const double dmax = __builtin_bit_cast(double, lst.dmax_bits);
+            const double margin = 2.0 * eps_u + 64.0 * 1.1102230246251565e-16 * ((double)lst.n + 4.0) * dmax * 3.0 + 1e-300;
+            const bool certain = (bu.q - margin > bo.q) || (bu.q == inf_f64());
+            if (!certain) {
+                // a swept pair may be the minimum: wait for the exact row sum, sweep again
+                if (!ev_wait(ctl, &ctl->chain_epoch, (unsigned)ev)) { aborted = true; break; }
+                Cand bx;
+                bx.q = inf_f64(); bx.key = ~0ULL;
+                for (int64_t it = (int64_t)ta.np + (int64_t)w * CH_T + tid; it < items; it += (int64_t)nmain * CH_T) {
+                    // sweep items only; the exact pass must not insert the pairs a second time
+                    const int64_t r = it - ta.np;
+                    const int32_t half = (ta.m + 1) / 2;
+                    const int32_t fi = ta.nf0 + (int32_t)(r / half), cp = (int32_t)(r % half);
+                    if (fi >= ta.nf) continue;
+                    const int32_t id = d.fresh[2 * fi], stamp = d.fresh[2 * fi + 1];
+                    const int32_t f0 = d.islot[id];
+                    if (f0 < 0 || d.cstamp[id] != stamp) continue;
+                    const int32_t s2 = 2 * cp;
+                    if (s2 >= ta.m || s2 == f0) continue;
+                    const double* F0 = d.D + (int64_t)f0 * d.ld + s2;
+                    const double* F1 = F0 + d.ld;
+                    const double a0 = F0[0], a1 = F0[1], b0 = F1[0], b1 = F1[1];
+                    if (f0 > s2)
+                        scan_micro(f0, s2, ta.m, ta.twoP, ta.cm2, a0, a1, b0, b1, d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1],
+                                   d.Sx[s2], d.Sx[s2 + 1], d.spos[s2], d.spos[s2 + 1], bx);
+                    else
+                        scan_micro(s2, f0, ta.m, ta.twoP, ta.cm2, a0, b0, a1, b1, d.Sx[s2], d.Sx[s2 + 1], d.spos[s2], d.spos[s2 + 1],
+                                   d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1], bx);
+                }
+                bx = block_reduce<CH_T / 64>(bx, shc);
+                if (tid == 0) d.recs[EV_REC_X + w] = bx;
+                if (!ev_barrier(ctl, round, nmain)) { aborted = true; break; }
+                bu = ev_reduce_records(d.recs + EV_REC_X, nmain, shc);
+                if (w == 0 && tid == 0) lst.n_su_exact++;
+                if (cand_better(bu, best)) best = bu;
+            }
+            // certain: every swept pair's exact Q is strictly above bo.q, so bo wins as it stands
+        }
+        if (!(best.q <= lst.la_theta_eff)) { failed = true; break; }  // the window cannot certify this event: the host-driven path scans
+        // Cx / Cy, ComputeRx terms + tree partial sums (k_rx_fill's body over this workgroup's slots)
+        if (tid == 0) {
+            int32_t z[4];
+            const bool need = pick_slots(dl, best, z);
+            zsh[0] = z[0]; zsh[1] = z[1]; zsh[2] = z[2]; zsh[3] = z[3]; zsh[4] = need ? 1 : 0;
+        }
+        __syncthreads();
+        {
+            const int32_t z[4] = {zsh[0], zsh[1], zsh[2], zsh[3]};
+            const bool need = zsh[4] != 0;
+            const int32_t m = ta.m, twoP = ta.twoP;
+            double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (need) {
+                for (int32_t sl = w * CH_T + tid; sl < m; sl += nmain * CH_T) {
+                    double term[4];
+                    rx_fill_thread(d, sl, m, twoP, z, term);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { v[k] += term[k]; v[4 + k] += term[k] < 0.0 ? -term[k] : term[k]; }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v[k] += __shfl_down(v[k], off, 64);
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) red[wv][k] = v[k];
+                }
+                __syncthreads();
+                if (tid < 8) {
+                    double acc = 0.0;
+                    for (int q = 0; q < CH_T / 64; q++) acc += red[q][tid];
+                    d.rxpart[(size_t)w * 8 + tid] = acc;
+                }
+            }
+        }
+        if (w == 0) {
+            __syncthreads();
+            if (tid == 0) {
+                la_track_hit(dl, ta);
+                pick(dl, best);
+            }
+            state_out();
+        }
+        EV_TICK(1);
+        if (!ev_barrier(ctl, round, nmain)) { aborted = true; break; }
+        EV_TICK(5);
+        // ---- C: 4-candidate choice + merge plan (on workgroup 0's copy of the control block)
+        if (w == 0) {
+            decide4_body(dl, nmain, L, lst, &red[0][0]);
+            state_out();
+        }
+        EV_TICK(2);
+        if (!ev_barrier(ctl, round, nmain)) { aborted = true; break; }
+        EV_TICK(5);
+        // ---- D: fused update; from here on u.Sx of the PREVIOUS event must be exact
+        // (the update reads the plan from the published control block: uniform global loads are cheaper
+        //  here than LDS reads)
+        if (ev > 0 && !ev_wait(ctl, &ctl->chain_epoch, (unsigned)ev)) { aborted = true; break; }
+        EV_TICK(3);
+        {
+            double dsum = 0.0, dabs = 0.0;
+            const int32_t m_old = st->m_old;
+            for (int32_t k = w * CH_T + tid; k < m_old; k += nmain * CH_T) {
+                const double v = update_bulk(d, k);
+                dsum += v;
+                dabs += v < 0.0 ? -v : v;
+            }
+            if (w == nmain - 1) {
+                const int nph = update_special_phases(*st);
+                for (int ph = 0; ph < nph; ph++) {
+                    const double v = update_special(d, ph, tid);
+                    dsum += v;
+                    dabs += v < 0.0 ? -v : v;
+                    __syncthreads();
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                dsum += __shfl_down(dsum, off, 64);
+                dabs += __shfl_down(dabs, off, 64);
+            }
+            if (lane == 0) { red[wv][8] = dsum; red[wv][9] = dabs; }
+            __syncthreads();
+            if (tid == 0) {
+                double a = 0.0, b = 0.0;
+                for (int q = 0; q < CH_T / 64; q++) { a += red[q][8]; b += red[q][9]; }
+                d.upart[2 * w] = a;
+                d.upart[2 * w + 1] = b;
+            }
+            if (w == 0) {
+                if (tid == 0) {
+                    ctl->req_m = lst.m;  // (the chain covers the positions of the new layout, as k_finalize does)
+                    ctl->req_U = lst.U;
+                    close_event(dl);     // everything of finalize() but u.Sx, which the chain workgroup delivers
+                    lst.n_ev_persistent++;
+                }
+                state_out();
+            }
+        }
+        EV_TICK(4);
+        if (!ev_barrier(ctl, round, nmain)) { aborted = true; break; }
+        EV_TICK(5);
+        if (w == 0 && tid == 0) { __threadfence(); ev_store(&ctl->upd_epoch, (unsigned)(ev + 1)); }
+    }
+    // `ev` events were completed by this launch; the chain workgroup leaves once it has served them.
+    // (Workgroup 0's copy equals the published control block here: every break happens before it
+    //  changes anything in the current event.)
+    if (w == 0 && tid == 0) {
+        for (int q = 0; q < 8; q++) st->ev_ticks[q] += tacc[q];
+        if (aborted || ev_load(&ctl->abort_)) st->error = 9;
+        if (failed) {  // as k_track records it: the window ends here, the next launch sequence opens a new one
+            st->n_la_fail++;
+            st->la_prev_end = 1;
+            la_prepare_base(*st, d.lacnt);
+        }
+        __threadfence();
+        ev_store(&ctl->stop, (unsigned)(ev + 1));
+    }
+#undef EV_TICK
 }
 
 // diagnostic entry: the block chain sum on an arbitrary buffer (tests)
@@ -1120,6 +1472,9 @@ struct HipBackend {
     int scan_grid = 8192;   // workgroups of the scan (FNN_SCAN_GRID)
     int unsched_grid = 2048; // workgroups of the screening launches that only run when a lookahead window fails (FNN_UNSCHED_GRID)
     int emit_grid = 256;    // workgroups of k_emit (FNN_EMIT_GRID)
+    int events_grid = 16;   // main workgroups of k_events (FNN_EVENTS_GRID); one more computes the chains
+    bool persistent = false; // FNN_PERSISTENT=1: run window hits inside the persistent event kernel k_events (experimental:
+                             // correct, but slower than one launch sequence per event)
     int track_grid = 32;    // workgroups of k_track (FNN_TRACK_GRID)
     bool scan_nt = true;    // non-temporal matrix loads in the scan (FNN_SCAN_NT)
 
@@ -1172,6 +1527,8 @@ struct HipBackend {
         if (const char* e = std::getenv("FNN_SCAN_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) scan_grid = v; }
         if (const char* e = std::getenv("FNN_SCAN_NT")) scan_nt = std::atoi(e) != 0;
         if (const char* e = std::getenv("FNN_UNSCHED_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) unsched_grid = v; }
+        if (const char* e = std::getenv("FNN_EVENTS_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 63) events_grid = v; }
+        if (const char* e = std::getenv("FNN_PERSISTENT")) persistent = std::atoi(e) != 0;
         if (const char* e = std::getenv("FNN_EMIT_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) emit_grid = v; }
         if (const char* e = std::getenv("FNN_TRACK_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) track_grid = v; }
         if (const char* e = std::getenv("FNN_SCREEN_MIN_M")) { int v = std::atoi(e); if (v >= 8) screen_min_m = v; }
@@ -1342,6 +1699,12 @@ struct HipBackend {
         enqueue_rest(d, m_bound, (const Cand*)d.recs, nrecs);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
+    // persistent event kernel: serves up to max_events window hits in one launch (no-op otherwise)
+    int32_t launch_events(const Dev& d, int32_t max_events) {
+        if (!HIPOK(hipMemsetAsync(d.evctl, 0, sizeof(EvCtl), stream))) return FNN_EHIP;
+        hipLaunchKernelGGL(k_events, dim3(events_grid + 1), dim3(CH_T), 0, stream, d, (int)max_events);
+        return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
+    }
     // several GPUs: scan of this rank's tiles ... (all-gather of the candidate records) ... the rest
     int32_t launch_event_scan(const Dev& d, int32_t m_bound, int32_t* nper) {
         if (m_bound < 1) m_bound = 1;
@@ -1473,6 +1836,13 @@ int64_t fnn_debug_window_log(fnn_handle* h, double* out, int64_t max_records) {
     if (k > max_records) k = max_records;
     if (out && k > 0 && h->eng.be.d2h(out, h->eng.dev.lalog, sizeof(double) * 5 * (size_t)k) != FNN_OK) return FNN_EHIP;
     return k;
+}
+int32_t fnn_debug_event_ticks(fnn_handle* h, int64_t* out8) {
+    FNN_NEED(h);
+    if (!out8) return fnn::fail(FNN_EINVAL, "fnn_debug_event_ticks: out8 is NULL");
+    if (h->eng.pull_state() != FNN_OK) return FNN_EHIP;
+    for (int q = 0; q < 8; q++) out8[q] = h->eng.hst.ev_ticks[q];
+    return FNN_OK;
 }
 int32_t fnn_set_scan_timing(fnn_handle* h, int32_t enable) {
     FNN_NEED(h);

@@ -97,7 +97,9 @@ typedef struct fnn_stats {
     int64_t n_window_fails;  /* events whose window could not certify the minimum (they rescanned) */
     int64_t window_pairs;    /* tracked pairs summed over all windows */
     int64_t bytes_total;     /* matrix bytes read by ALL scan work of the run (timed or not, window items too) */
-    int64_t reserved[7];
+    int64_t n_events_persistent; /* events completed inside the persistent event kernel (k_events) */
+    int64_t n_sweeps_exact;  /* ... whose sweep of the newest cluster's rows had to wait for its exact row sum */
+    int64_t reserved[5];
 } fnn_stats;
 
 typedef struct fnn_handle fnn_handle;
@@ -152,6 +154,10 @@ int32_t fnn_get_live_matrix(fnn_handle* h, double* out);
  * window width W (-1: no window opened), pairs emitted, events the previous window served}; returns
  * the number of records copied (at most 8192 are kept). */
 int64_t fnn_debug_window_log(fnn_handle* h, double* out, int64_t max_records);
+
+/* Diagnostic: 100 MHz ticks workgroup 0 of the persistent event kernel spent in {phase A, B, C, waiting for
+ * the chain, phase D, grid barriers, -, -} over the last run. */
+int32_t fnn_debug_event_ticks(fnn_handle* h, int64_t* out8);
 
 /* Enable per-launch HIP-event timing of the scan kernel (bench.py's roofline
  * figure).  Adds two event records per scan launch. */

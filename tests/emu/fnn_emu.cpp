@@ -44,6 +44,8 @@ struct EmuBackend {
     static constexpr int64_t kColPad = 2048;
     int32_t screen_min_n() const { return 8; }   // tiny on purpose: the CPU tests exercise screening
     int32_t screen_min_m = 8;
+    bool persistent = false;  // (the persistent event kernel exists only on the GPU)
+    int32_t launch_events(const fnn::Dev&, int32_t) { return FNN_OK; }
     std::string err() const { return "emu"; }
     int32_t open(int32_t) { return FNN_OK; }
     void close() {}
@@ -193,7 +195,7 @@ struct EmuBackend {
         } else {
             for (int32_t i : thread_order(st.ncand)) { rescan_unit(d, d.clist[i], best); st.n_rescan_units++; }
         }
-        fnn::la_close_base(st, d.lalog);
+        fnn::la_close_base(st, d.lalog, d.lacnt);
         return best;
     }
 
@@ -212,7 +214,7 @@ struct EmuBackend {
             if (st.la_hit) return d.recs[0];
         } else {
             if (st.la_valid) st.la_prev_end = 0;
-            fnn::la_prepare_base(st);
+            fnn::la_prepare_base(st, d.lacnt);
         }
         if (d.H && st.m >= screen_min_m) return scan_screened(d);
         fnn::Cand best;
