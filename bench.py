@@ -8,12 +8,15 @@ resident in HBM when the step starts.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--taxa 32768] [--seed 1]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU): every rank
-holds the whole matrix and scans 1/N of each event's tiles; one 16-byte candidate per rank is
-all-gathered per event with RCCL on the engine's stream and every rank applies the same
-deterministic update (DESIGN.md "Multi-GPU").  The job is ONE problem instance, so the metric
-is a strong-scaling time.  If the RCCL communicator cannot be created the ranks agree to let
-rank 0 compute alone (reported in config.parallelism).
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU).  With the
+lookahead windows a run streams the matrix only ~500 times instead of 32767 times; what is left
+is a chain of ~32767 latency-bound events that does not shard (a per-event exchange over xGMI
+costs more than the amortised scan it would split, DESIGN.md "Multi-GPU").  So N > 1 runs N
+independent replicas (rank r orders the matrix of seed + r): weak scaling, `value` = the slowest
+replica's seconds per order.  FNN_BENCH_SHARD=1 selects the sharded-scan engine instead (every
+event scans 1/N of the tiles on each rank, one all-gather per event with RCCL on the engine's
+stream; lookahead windows off): ONE problem instance, strong scaling; if its RCCL communicator
+cannot be created the ranks agree to let rank 0 compute alone (reported in config.parallelism).
 
 Prints ONE JSON line on rank 0.
 """
@@ -105,7 +108,12 @@ def main():
     h = None
     parallelism = "single GPU"
     sharded = False
-    if world > 1:
+    shard_mode = os.environ.get("FNN_BENCH_SHARD") == "1"
+    replicas = world > 1 and not shard_mode
+    if replicas:
+        parallelism = (f"replicas only: {world} independent orders (seed + rank), one per GPU, no data-path "
+                       f"collective; value = the slowest replica")
+    if world > 1 and shard_mode:
         ok, why = 1, ""
         try:
             h = Handle(api, n, device=dev_index)
@@ -126,14 +134,16 @@ def main():
                 h.close()
                 h = None
             parallelism = f"rank 0 computes alone (communicator setup failed: {why or 'on another rank'})"
-    worker = sharded or rank == 0
+    worker = sharded or replicas or rank == 0
     if worker and h is None:
         h = Handle(api, n, device=dev_index)
     if worker:
         api.set_scan_timing(h._h, 1)
 
+    seed = args.seed + (rank if replicas else 0)
+
     def one_step():
-        h.synth(args.seed, "uniform53")  # matrix generated in HBM (2-3 ms at n = 32768)
+        h.synth(seed, "uniform53")  # matrix generated in HBM (2-3 ms at n = 32768)
         return h.run()
 
     for _ in range(args.warmup):
@@ -155,14 +165,20 @@ def main():
     if rank == 0:
         order, st = last
         sec = elapsed / args.steps
-        scan_bytes = float(st.scan_bytes)            # bytes at the element size actually streamed (4 or 8 B / entry)
         fp64_equiv = 8.0 * float(st.sum_entries)     # BASELINE.md's 8 * sum E_t, for reference
         assert sorted(order[1:].tolist()) == list(range(1, n + 1)) and order[0] == 0 and order[1] == 1
         share = args.gpus if sharded else 1  # this rank's launches cover 1/share of the entries
-        scan_gbps = scan_bytes / share / max(st.t_scan_s, 1e-12) / 1e9
+        # dominant streaming kernel: the bf16 screening pass.  With lookahead windows the timed launches
+        # are the host-scheduled base scans (kernel name k_screen<true, true>); the unscheduled ones
+        # (window failures) are the same kernel on a smaller grid and are not part of this figure.
+        have_screen = st.scan_launches > 0
+        k_bytes = float(st.scan_bytes) if have_screen else float(st.plain_bytes)
+        k_time = st.t_scan_s if have_screen else st.t_plain_s
+        k_launches = int(st.scan_launches if have_screen else st.plain_launches)
+        scan_gbps = k_bytes / share / max(k_time, 1e-12) / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_screen_summary_n32768.json")
-        if n == 32768 and args.gpus == 1 and os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_screen_windows_summary_n32768.json")
+        if n == 32768 and args.gpus == 1 and have_screen and os.path.exists(pmc):
             traffic = round(json.load(open(pmc))["hbm_bytes_per_launch_avg"], 1)
         out = {
             "metric": f"sec to circular order, n={n} taxa (+ achieved HBM GB/s)",
@@ -173,7 +189,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(sec * 1e3, 2),
             "higher_is_better": False,
-            "scaling": "strong",
+            "scaling": "strong" if (sharded or (world > 1 and not replicas)) else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -184,32 +200,41 @@ def main():
                 "n_taxa": n,
                 "events": int(st.n_events),
                 "sum_entries": int(st.sum_entries),
-                "algorithmic_bytes": int(scan_bytes),
-                "algorithmic_bytes_note": ("E_t entries per event at 2 B when the event's scan is the bf16 screening pass "
-                                           "(m >= 8192) or 8 B for the plain fp64 scan, plus the fp64 rescans of the "
-                                           "candidate units; 8 * sum E_t would be %d" % int(fp64_equiv)),
+                "fp64_every_event_bytes": int(fp64_equiv),
+                "bytes_read_by_all_scan_work": int(st.bytes_total),
+                "lookahead_windows": {"events_with_a_scan": int(st.n_base_scans), "events_served_by_a_window": int(st.n_window_hits),
+                                      "windows_that_could_not_certify": int(st.n_window_fails),
+                                      "tracked_pairs_per_window": round(st.window_pairs / max(st.n_base_scans, 1), 1)},
                 "screening": {"events": int(st.n_screen_events), "rescanned_units_32x512": int(st.n_rescan_units)},
             },
-            "hbm_gbps_whole_run": round(scan_bytes / sec / 1e9, 1),
-            "hbm_frac_whole_run": round(scan_bytes / sec / 1e9 / (HBM_PEAK_GBPS * max(args.gpus, 1)), 4),
+            "hbm_gbps_whole_run": round(float(st.bytes_total) / sec / 1e9, 1),
+            "hbm_frac_whole_run": round(float(st.bytes_total) / sec / 1e9 / HBM_PEAK_GBPS, 4),
             "rx_decisions": {"certified_from_tree_sums": int(st.n_rx_certified), "exact_sequential_sums": int(st.n_rx_exact)},
             "phases_s": {"init": round(st.t_init_s, 4), "agglomerate": round(st.t_agglom_s, 4),
-                         "expand": round(st.t_expand_s, 4), "scan_kernel_sum": round(st.t_scan_s, 4)},
+                         "expand": round(st.t_expand_s, 4), "screen_kernel_sum": round(st.t_scan_s, 4),
+                         "plain_scan_kernel_sum": round(st.t_plain_s, 4)},
             "roofline": {
-                "kernel": "fnn::k_screen (bf16 pass, 95.8 % of the streamed bytes; fnn::k_scan fp64 for m < 8192)",
+                "kernel": ("fnn::k_screen<true, true> (bf16 screening pass; the scheduled base scans of the lookahead windows)"
+                           if have_screen else "fnn::k_scan<true> (plain fp64 scan)"),
                 "bound": "hbm",
                 "achieved": round(scan_gbps, 1),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(scan_gbps / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
-                "traffic_note": ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                 "workload (FETCH_SIZE x2 per the gfx950 correction), profiles/r01/pmc_screen_summary_n32768.json"
+                "traffic_note": ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel "
+                                 "(FETCH_SIZE x2 per the gfx950 correction), profiles/r01/pmc_screen_windows_summary_n32768.json"
                                  if traffic else None),
-                "launches": int(st.scan_launches),
-                "avg_launch_us": round(st.t_scan_s / max(st.scan_launches, 1) * 1e6, 2),
-                "algorithmic_bytes_per_launch_avg": round(scan_bytes / share / max(st.scan_launches, 1), 1),
+                "launches": k_launches,
+                "avg_launch_us": round(k_time / max(k_launches, 1) * 1e6, 2),
+                "algorithmic_bytes_per_launch_avg": round(k_bytes / share / max(k_launches, 1), 1),
+                "algorithmic_bytes_note": "per launch: E_t = m(m-1)/2 - (m-c) entries at 2 B (the bf16 copy) + the fp64 rescans of "
+                                          "the candidate units (32 x 512 x 8 B each)",
                 "per_gpu": args.gpus > 1,
+                "plain_fp64_scan": {"kernel": "fnn::k_scan<true> (events below the screening threshold of 8192 live nodes)",
+                                    "launches": int(st.plain_launches),
+                                    "achieved": round(float(st.plain_bytes) / max(st.t_plain_s, 1e-12) / 1e9, 1),
+                                    "avg_launch_us": round(st.t_plain_s / max(st.plain_launches, 1) * 1e6, 2)},
             },
         }
         try:
@@ -223,7 +248,7 @@ def main():
             h.close()
         if not args.no_cpu_baseline and args.gpus == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(n, args.seed, int(st.sum_entries))
+                out["cpu_baseline"] = cpu_baseline(n, seed, int(st.sum_entries))
             except Exception as e:  # the baseline is reported, never required
                 out["cpu_baseline"] = {"value": None, "unit": "s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}

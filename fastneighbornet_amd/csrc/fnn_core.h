@@ -126,7 +126,8 @@ struct State {
     double la_mprev;        // previous event's scan minimum
     int64_t n_base_scans, n_la_hits, n_la_fail, n_la_overflow, la_pairs_sum, la_items_sum;
     int32_t ev_timed, la_k_prev;  // the host brackets this event's scan launch with HIP events
-    int64_t bytes_timed;      // the part of bytes_streamed that belongs to timed scan launches
+    int64_t bytes_timed;      // the part of bytes_streamed that belongs to timed screening launches (k_screen + rescans)
+    int64_t bytes_plain;      // ... and to the plain fp64 scans (k_scan; always timed)
     int64_t n_ev_persistent;  // events completed inside the persistent event kernel
     int64_t n_su_exact;       // ... of which the sweep had to wait for the exact row sum of the new cluster
     int64_t ev_ticks[8];      // k_events, workgroup 0: 100 MHz ticks spent in phases A, B, C, wait for the chain, D, barriers
@@ -856,7 +857,8 @@ FNN_HD void pick(const Dev& d, Cand best) {
         const int64_t bytes = (st.ev_screened ? 2 : 8) * cur.entries +
                               (st.ev_screened ? (int64_t)(st.rescan_all ? 0 : st.ncand) * SCR_TH * SCR_UW * 8 : 0);
         st.bytes_streamed += bytes;
-        if (st.ev_timed) st.bytes_timed += bytes;
+        if (!st.ev_screened) st.bytes_plain += bytes;
+        else if (st.ev_timed) st.bytes_timed += bytes;
     }
     st.ev_screened = 0;
     int32_t i = (int32_t)(best.key >> 32), j = (int32_t)(best.key & 0xFFFFFFFFu);

@@ -478,7 +478,8 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
 // the grid; the last workgroup to arrive reduces the per-workgroup minima and decides whether the
 // window certifies the minimum (la_hit: the scan kernels of this event return at once) or the
 // event has to scan.  force_base: the host's schedule asks for a new window at this event.
-constexpr int TRK_THREADS = 1024;  // few, large workgroups: every workgroup costs one same-address atomic (~50 ns each)
+constexpr int TRK_THREADS = 256;
+constexpr int TRK_GROUP = 16;  // arrival tickets in two levels: same-address device-scope atomics cost ~50 ns each
 __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed) {
     __shared__ Cand sh[TRK_THREADS / 64];
     __shared__ int lastflag;
@@ -503,7 +504,16 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     if (threadIdx.x == 0) {
         d.recs[blockIdx.x] = best;
         __threadfence();
-        lastflag = atomicAdd(d.ticket, 1u) == gridDim.x - 1 ? 1 : 0;
+        // last of its group of TRK_GROUP workgroups -> last of the groups (counters 128 bytes apart)
+        const unsigned g = blockIdx.x / TRK_GROUP, ngroups = (gridDim.x + TRK_GROUP - 1) / TRK_GROUP;
+        const unsigned gsize = g + 1 < ngroups ? (unsigned)TRK_GROUP : gridDim.x - g * TRK_GROUP;
+        int last = 0;
+        if (atomicAdd(d.ticket + 32 * (g + 1), 1u) == gsize - 1) {
+            d.ticket[32 * (g + 1)] = 0u;
+            __threadfence();
+            last = atomicAdd(d.ticket, 1u) == ngroups - 1 ? 1 : 0;
+        }
+        lastflag = last;
     }
     __syncthreads();
     if (!lastflag) return;
@@ -1457,9 +1467,10 @@ struct HipBackend {
     // scan timing
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
+    std::vector<char> ev_kind;   // per event pair: 1 = screening pass (k_screen), 0 = plain fp64 scan (k_scan)
     size_t ev_used = 0;
-    double scan_ms = 0.0;
-    int64_t scan_launches = 0;
+    double scan_ms = 0.0, plain_ms = 0.0;       // k_screen launches / k_scan launches
+    int64_t scan_launches = 0, plain_launches = 0;
     int* d_bad = nullptr;
     // RCCL (dlopen'ed: the process may already hold PyTorch's copy of the library)
     void* rccl_lib = nullptr;
@@ -1475,7 +1486,7 @@ struct HipBackend {
     int events_grid = 16;   // main workgroups of k_events (FNN_EVENTS_GRID); one more computes the chains
     bool persistent = false; // FNN_PERSISTENT=1: run window hits inside the persistent event kernel k_events (experimental:
                              // correct, but slower than one launch sequence per event)
-    int track_grid = 32;    // workgroups of k_track (FNN_TRACK_GRID)
+    int track_grid = 128;   // workgroups of k_track (FNN_TRACK_GRID)
     bool scan_nt = true;    // non-temporal matrix loads in the scan (FNN_SCAN_NT)
 
     std::string err() const { return comm_err.empty() ? std::string(hipGetErrorString(last)) : comm_err; }
@@ -1530,7 +1541,7 @@ struct HipBackend {
         if (const char* e = std::getenv("FNN_EVENTS_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 63) events_grid = v; }
         if (const char* e = std::getenv("FNN_PERSISTENT")) persistent = std::atoi(e) != 0;
         if (const char* e = std::getenv("FNN_EMIT_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) emit_grid = v; }
-        if (const char* e = std::getenv("FNN_TRACK_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) track_grid = v; }
+        if (const char* e = std::getenv("FNN_TRACK_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 1024) track_grid = v; }
         if (const char* e = std::getenv("FNN_SCREEN_MIN_M")) { int v = std::atoi(e); if (v >= 8) screen_min_m = v; }
         opened = true;
         return FNN_OK;
@@ -1586,9 +1597,10 @@ struct HipBackend {
     void drain_timing() {
         for (size_t i = 0; i + 1 < ev_used; i += 2) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]) == hipSuccess) scan_ms += ms;
+            if (hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]) == hipSuccess) (ev_kind[i / 2] ? scan_ms : plain_ms) += ms;
         }
         ev_used = 0;
+        ev_kind.clear();
     }
     int32_t sync() {
         if (!HIPOK(hipStreamSynchronize(stream))) return FNN_EHIP;
@@ -1598,8 +1610,10 @@ struct HipBackend {
     void collect_timing(fnn_stats& s) {
         s.t_scan_s = scan_ms * 1e-3;
         s.scan_launches = scan_launches;
+        s.t_plain_s = plain_ms * 1e-3;
+        s.plain_launches = plain_launches;
     }
-    void reset_timing() { scan_ms = 0.0; scan_launches = 0; ev_used = 0; }
+    void reset_timing() { scan_ms = plain_ms = 0.0; scan_launches = plain_launches = 0; ev_used = 0; ev_kind.clear(); }
 
     hipEvent_t next_event() {
         if (ev_used == ev_pool.size()) {
@@ -1655,7 +1669,7 @@ struct HipBackend {
         const bool screen = use_screen(d, m_bound);
         const bool timed = timing && (sched || !screen);
         if (d.la) hipLaunchKernelGGL(k_track, dim3(track_grid), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0);
-        if (timed) { e0 = next_event(); e1 = next_event(); }
+        if (timed) { e0 = next_event(); e1 = next_event(); ev_kind.push_back(screen ? 1 : 0); }
         int nrecs;
         if (screen) {
             int nt = (tri_tile_count(m_bound, SCR_TH, SCR_R) + d.world - 1) / d.world;
@@ -1681,7 +1695,7 @@ struct HipBackend {
             if (e1) (void)hipEventRecord(e1, stream);
             nrecs = (int)gs.x;
         }
-        if (timed) scan_launches++;
+        if (timed) (screen ? scan_launches : plain_launches)++;
         return nrecs;
     }
     // everything after the scan; `src` holds the nrecs candidate records to reduce

@@ -84,10 +84,11 @@ typedef struct fnn_stats {
     double  t_agglom_s;      /* agglomNodes loop, device time incl. launches */
     double  t_expand_s;      /* expandNodes on the host (:246-325) */
     double  t_total_s;       /* matrix resident on device -> order on host */
-    double  t_scan_s;        /* sum of scan-kernel durations (HIP events), 0 unless timing enabled */
-    int64_t scan_launches;   /* number of scan-kernel launches */
-    int64_t scan_bytes;      /* matrix bytes the TIMED scan launches had to stream: per event E_t entries at
-                                2 B (bf16 screening pass) or 8 B (plain fp64 scan), plus the fp64 rescans */
+    double  t_scan_s;        /* sum of the durations of the timed k_screen launches (HIP events; 0 unless timing
+                                is enabled): all of them without lookahead windows, the scheduled base scans with */
+    int64_t scan_launches;   /* number of those launches */
+    int64_t scan_bytes;      /* matrix bytes those launches had to stream: E_t entries at 2 B (bf16 screening
+                                copy) per launch, plus the fp64 rescans of the candidate units */
     int64_t n_rx_certified;  /* events whose 4-candidate choice was certified from tree sums */
     int64_t n_rx_exact;      /* events that needed the exact sequential ComputeRx sums */
     int64_t n_screen_events; /* events whose scan went through the fp32 screening pass */
@@ -99,7 +100,10 @@ typedef struct fnn_stats {
     int64_t bytes_total;     /* matrix bytes read by ALL scan work of the run (timed or not, window items too) */
     int64_t n_events_persistent; /* events completed inside the persistent event kernel (k_events) */
     int64_t n_sweeps_exact;  /* ... whose sweep of the newest cluster's rows had to wait for its exact row sum */
-    int64_t reserved[5];
+    double  t_plain_s;       /* sum of the durations of the plain fp64 scan launches (k_scan; m below the screening threshold) */
+    int64_t plain_launches;  /* number of those launches */
+    int64_t plain_bytes;     /* 8 * E_t summed over them */
+    int64_t reserved[2];
 } fnn_stats;
 
 typedef struct fnn_handle fnn_handle;

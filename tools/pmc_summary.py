@@ -1,6 +1,6 @@
 """Summarise rocprofv3 --pmc passes over the scan kernel into profiles/<round>/pmc_scan_summary.json.
 
-usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <algorithmic_bytes_total> <out.json>
+usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <algorithmic_bytes_total> <out.json> [kernel substring]
 
 Corrections follow MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so
@@ -10,25 +10,31 @@ import json
 import sys
 
 
+KERNEL = None
+
+
 def load(path, name):
     vals = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            if r["Counter_Name"] == name and ("k_scan" in r["Kernel_Name"] or "k_screen" in r["Kernel_Name"]):
+            ok = (KERNEL in r["Kernel_Name"]) if KERNEL else ("k_scan" in r["Kernel_Name"] or "k_screen" in r["Kernel_Name"])
+            if r["Counter_Name"] == name and ok:
                 vals.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     vals.sort()
     return [v for _, v in vals]
 
 
 def main():
+    global KERNEL
     fetch_csv, write_csv, algo_total, out = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4]
+    KERNEL = sys.argv[5] if len(sys.argv) > 5 else None
     fetch = load(fetch_csv, "FETCH_SIZE")
     write = load(write_csv, "WRITE_SIZE") if write_csv != "-" else []
     n = len(fetch)
     fetch_b = sum(fetch) * 1024.0 * 2.0
     write_b = sum(write) * 1024.0
     res = {
-        "kernel": "fnn::k_screen<true> (+ fnn::k_scan<true> for m < 8192)",
+        "kernel": KERNEL or "fnn::k_screen<true> (+ fnn::k_scan<true> for m < 8192)",
         "launches": n,
         "FETCH_SIZE_KiB_sum_raw": sum(fetch),
         "WRITE_SIZE_KiB_sum_raw": sum(write),
