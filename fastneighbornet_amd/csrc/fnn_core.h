@@ -130,6 +130,14 @@ struct State {
     int64_t bytes_plain;      // ... and to the plain fp64 scans (k_scan; always timed)
     int64_t n_ev_persistent;  // events completed inside the persistent event kernel
     int64_t n_su_exact;       // ... of which the sweep had to wait for the exact row sum of the new cluster
+    // deferred row sum of the newest cluster: k_update closes the event, the exact sequential sum is
+    // computed by a workgroup of the NEXT event's k_track (or by k_chain_flush before the host looks)
+    int32_t chain_pending, chain_m, chain_U, upart_n;
+    // an event launched WITHOUT scan kernels found that its window cannot serve it: this and the
+    // following such events do nothing until the host (which resyncs every batch) launches one with a scan
+    int32_t stall, pad_stall;
+    int64_t n_stalled;        // events skipped that way
+    int64_t n_sweep_waits;    // k_track: sweeps that had to wait for the exact row sum
     int64_t ev_ticks[8];      // k_events, workgroup 0: 100 MHz ticks spent in phases A, B, C, wait for the chain, D, barriers
     // ---- current event ----
     int32_t ev_active, ev_finish, need_rx;
@@ -839,6 +847,7 @@ FNN_HD bool pick_slots(const Dev& d, Cand best, int32_t z[4]) {
 // After the scan: turn the best candidate into Cx, Cy (NetMakerOriginal.java:376-380)
 FNN_HD void pick(const Dev& d, Cand best) {
     State& st = *d.st;
+    st.chain_pending = 0;  // (k_track's chain workgroup has delivered the previous event's u.Sx)
     st.ev_active = 0;
     if (st.done) return;
     if (st.m <= 3) { st.done = 1; return; }

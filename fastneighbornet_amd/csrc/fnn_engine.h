@@ -178,7 +178,7 @@ class Engine {
         hst.force_exact_rx = opts.force_exact_rx ? 1 : 0;
         // lookahead windows (fnn_core.h "Lookahead"): single rank with a screening copy
         {
-            int32_t K = opts.lookahead < 0 ? 0 : (opts.lookahead > 0 ? opts.lookahead : 64);
+            int32_t K = opts.lookahead < 0 ? 0 : (opts.lookahead > 0 ? opts.lookahead : 48);
             int32_t target = opts.lookahead_pairs > 0 ? opts.lookahead_pairs : 32768;
             if (const char* e = std::getenv("FNN_LA_K")) K = std::atoi(e);
             if (const char* e = std::getenv("FNN_LA_TARGET")) target = std::atoi(e);
@@ -235,7 +235,7 @@ class Engine {
     // after a state download: when will the open window have served its K events?
     void resync_schedule() {
         if (!dev.la) return;
-        sched_at = hst.la_valid ? ev_counter + (hst.la_K + 1 > hst.la_k ? hst.la_K + 1 - hst.la_k : 0) : ev_counter;
+        sched_at = (hst.la_valid && !hst.stall) ? ev_counter + (hst.la_K + 1 > hst.la_k ? hst.la_K + 1 - hst.la_k : 0) : ev_counter;
     }
     // A rank contributes nper candidate records (1 after a local reduction, or the scan's
     // GATHER_RECS per-workgroup records as they are).
@@ -285,6 +285,13 @@ class Engine {
             if (be.sync() != FNN_OK) return fail(FNN_EHIP, "fnn_step: sync failed (" + be.err() + ")");
             rc = pull_state();
             if (rc != FNN_OK) return rc;
+            if (hst.stall) {  // the event had no scan kernels and its window could not serve it: once more, with a scan
+                rc = enqueue_event(1);
+                if (rc != FNN_OK) return rc;
+                if (be.sync() != FNN_OK) return fail(FNN_EHIP, "fnn_step: sync failed (" + be.err() + ")");
+                rc = pull_state();
+                if (rc != FNN_OK) return rc;
+            }
         }
         m_bound = hst.m;
         resync_schedule();
@@ -306,7 +313,11 @@ class Engine {
     int32_t agglomerate() {
         if (!begun) return fail(FNN_ESTATE, "agglomerate: call fnn_begin first");
         double t0 = now_s();
+        if (const char* e = std::getenv("FNN_BATCH")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) batch = v; }
         while (!ended) {
+            // with lookahead windows on, k_update closes the events and the exact row sum of the new
+            // cluster is computed inside the next event's k_track (flushed before the host looks)
+            be.defer_chain = dev.la != 0 && !std::getenv("FNN_NO_DEFER");
             for (int i = 0; i < batch; i++) {
                 // the persistent kernel serves the open window; whatever event is left then needs a scan
                 const bool evm = use_events();
@@ -314,6 +325,8 @@ class Engine {
                 int32_t rce = enqueue_event(evm ? 1 : -1);
                 if (rce != FNN_OK) return rce;
             }
+            if (be.defer_chain && be.launch_chain_flush(dev) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
+            be.defer_chain = false;
             if (be.sync() != FNN_OK) return fail(FNN_EHIP, "fnn_run: sync failed (" + be.err() + ")");
             int32_t rc = pull_state();
             if (rc != FNN_OK) return rc;
@@ -371,7 +384,8 @@ class Engine {
         stats.n_window_fails = hst.n_la_fail;
         stats.window_pairs = hst.la_pairs_sum;
         stats.n_events_persistent = hst.n_ev_persistent;
-        stats.n_sweeps_exact = hst.n_su_exact;
+        stats.n_sweeps_exact = hst.n_su_exact + hst.n_sweep_waits;
+        stats.n_stalled_events = hst.n_stalled;
         be.collect_timing(stats);
         return rc;
     }

@@ -295,9 +295,9 @@ __device__ __forceinline__ void screen_tile_nonneg(const Dev& d, int rbase, int 
 
 // Emission pass of a lookahead window (fnn_core.h "Lookahead"), k_emit: k_screen has marked, per
 // unit (32 rows x 512 columns, one wave of a screening tile), the lanes whose 8 columns hold a
-// pair with a lower bound under the window's threshold.  A wave takes such a lane's 32 x 8 block,
-// one 2 x 2 micro-tile per lane, and appends every pair under the threshold, as the two
-// representatives' node ids, to the tracked list.
+// pair with a lower bound under the window's threshold.  Every such 32 x 8 block is walked again
+// and the pairs under the threshold are appended, as the two representatives' node ids, to the
+// tracked list.
 constexpr int EMIT_LDS = 2048;  // pairs a workgroup of k_emit collects before it reserves their place in the list
 __global__ __launch_bounds__(256) void k_emit(Dev d) {
     // (one device-scope atomic on a single address costs ~50 ns on this multi-XCD part: the pairs
@@ -319,34 +319,74 @@ __global__ __launch_bounds__(256) void k_emit(Dev d) {
         if (i < EMIT_LDS) lbuf[i] = make_int2(d.sid[rs], d.sid[cs]);
     };
     for (int ub = wave * 64; ub < nunits; ub += nwaves * 64) {
-        // 64 units per step: every lane fetches one unit's mask, the wave then serves the marked ones
+        // 64 units per step: every lane fetches one unit's mask; the marked 32 x 8 blocks of all 64
+        // units are then dealt out evenly, one block per lane and round (a node with an extreme row
+        // sum marks a whole row of blocks in ONE unit)
         const int myu = ub + lane;
         unsigned long long mymask = 0;
         if (myu < nunits && d.srec[myu] <= tp) mymask = d.shit[myu];
-        unsigned long long any = __ballot(mymask != 0);
-        while (any) {
-            const int src = __builtin_ctzll(any);
-            any &= any - 1;
-            const int u = ub + src;
-            unsigned long long mask = (unsigned long long)__shfl((long long)mymask, src, 64);
+        int incl = __builtin_popcountll(mymask);
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int T = __shfl(incl, 63, 64);
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            // owner = first lane whose inclusive prefix exceeds t (binary search over the lanes)
+            int lo = 0, hi = 63;
+#pragma unroll
+            for (int it = 0; it < 6; it++) {
+                const int mid = (lo + hi) >> 1;
+                const int pm = __shfl(incl, mid, 64);
+                if (pm > t) hi = mid; else lo = mid + 1;
+            }
+            const int owner = lo > 63 ? 63 : lo;
+            const int oincl = __shfl(incl, owner, 64);
+            unsigned long long omask = (unsigned long long)__shfl((long long)mymask, owner, 64);
+            if (t >= T) continue;
+            int k = t - (oincl - __builtin_popcountll(omask));  // index of the block among the owner's marked ones
+            while (k-- > 0) omask &= omask - 1;
+            const int l = __builtin_ctzll(omask);
+            const int u = ub + owner;
             int rt, ct;
             tri_tile_decode(u >> 2, SCR_R, rt, ct);
-            const int rbase = rt * SCR_TH, cunit = ct * SCR_TW + (u & 3) * SCR_UW;
-            while (mask) {
-                const int l = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                // lane i: row pair i / 4, column pair i % 4 of the marked lane's 32 x 8 block
-                const int r0 = rbase + 2 * (lane >> 2), c0 = cunit + 8 * l + 2 * (lane & 3);
-                if (r0 >= m || c0 >= m || c0 > r0) continue;
-                const unsigned a = *reinterpret_cast<const unsigned*>(d.H + (int64_t)r0 * d.ld + c0);
-                const unsigned b = *reinterpret_cast<const unsigned*>(d.H + (int64_t)(r0 + 1) * d.ld + c0);
-                const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + r0);
-                const double2 sxc = *reinterpret_cast<const double2*>(d.Sx + c0);
-                Brk dummy;
-                dummy.lb = __builtin_inff();
-                dummy.ub = __builtin_inff();
-                screen_micro_nn(r0, c0, m, twoP, k1, k2, bf_lo(a), bf_hi(a), bf_lo(b), bf_hi(b),
-                                (float)sxr.x, (float)sxr.y, (float)sxc.x, (float)sxc.y, dummy, emit);
+            const int rbase = rt * SCR_TH, c0 = ct * SCR_TW + (u & 3) * SCR_UW + 8 * l;
+            if (c0 >= m) continue;
+            float sxc[8];
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                const double2 sv = *reinterpret_cast<const double2*>(d.Sx + c0 + q);
+                sxc[q] = (float)sv.x;
+                sxc[q + 1] = (float)sv.y;
+            }
+            const uint16_t* colbase = d.H + c0;
+#pragma unroll 1
+            for (int part = 0; part < SCR_TH / 8; part++) {  // 4 row pairs (8 x 16-byte loads) in flight
+                const int rb = rbase + 8 * part;
+                if (rb >= m) break;
+                uint4 a[4], b[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    a[q] = ld16h<false>(colbase + (int64_t)(rb + 2 * q) * d.ld);
+                    b[q] = ld16h<false>(colbase + (int64_t)(rb + 2 * q + 1) * d.ld);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int r0 = rb + 2 * q;
+                    const double2 sxr = *reinterpret_cast<const double2*>(d.Sx + r0);
+                    const float s0 = (float)sxr.x, s1 = (float)sxr.y;
+                    const unsigned aw[4] = {a[q].x, a[q].y, a[q].z, a[q].w};
+                    const unsigned bw[4] = {b[q].x, b[q].y, b[q].z, b[q].w};
+                    Brk dummy;
+                    dummy.lb = __builtin_inff();
+                    dummy.ub = __builtin_inff();
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        screen_micro_nn(r0, c0 + 2 * j, m, twoP, k1, k2, bf_lo(aw[j]), bf_hi(aw[j]), bf_lo(bw[j]), bf_hi(bw[j]),
+                                        s0, s1, sxc[2 * j], sxc[2 * j + 1], dummy, emit);
+                }
             }
         }
     }
@@ -470,68 +510,6 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
             ubt[t] = __builtin_fminf(__builtin_fminf(shu[0], shu[1]), __builtin_fminf(shu[2], shu[3]));
         }
         __syncthreads();
-    }
-}
-
-// k_track: serve the event from the open lookahead window (fnn_core.h "Lookahead").  The work
-// items (tracked pairs, then the rows of the clusters created since the base scan) are spread over
-// the grid; the last workgroup to arrive reduces the per-workgroup minima and decides whether the
-// window certifies the minimum (la_hit: the scan kernels of this event return at once) or the
-// event has to scan.  force_base: the host's schedule asks for a new window at this event.
-constexpr int TRK_THREADS = 256;
-constexpr int TRK_GROUP = 16;  // arrival tickets in two levels: same-address device-scope atomics cost ~50 ns each
-__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed) {
-    __shared__ Cand sh[TRK_THREADS / 64];
-    __shared__ int lastflag;
-    State* st = d.st;
-    if (st->done) return;
-    if (force_base || !la_active(*st)) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            st->ev_timed = timed;
-            if (st->la_valid) st->la_prev_end = 0;  // the window ends on schedule
-            la_prepare_base(*st, d.lacnt);
-        }
-        return;
-    }
-    const TrackArgs ta = track_args(*st);
-    const int64_t items = track_item_count(ta);
-    Cand best;
-    best.q = inf_f64();
-    best.key = ~0ULL;
-    for (int64_t it = (int64_t)blockIdx.x * TRK_THREADS + threadIdx.x; it < items; it += (int64_t)gridDim.x * TRK_THREADS)
-        track_item(d, it, ta, best);
-    best = block_reduce<TRK_THREADS / 64>(best, sh);
-    if (threadIdx.x == 0) {
-        d.recs[blockIdx.x] = best;
-        __threadfence();
-        // last of its group of TRK_GROUP workgroups -> last of the groups (counters 128 bytes apart)
-        const unsigned g = blockIdx.x / TRK_GROUP, ngroups = (gridDim.x + TRK_GROUP - 1) / TRK_GROUP;
-        const unsigned gsize = g + 1 < ngroups ? (unsigned)TRK_GROUP : gridDim.x - g * TRK_GROUP;
-        int last = 0;
-        if (atomicAdd(d.ticket + 32 * (g + 1), 1u) == gsize - 1) {
-            d.ticket[32 * (g + 1)] = 0u;
-            __threadfence();
-            last = atomicAdd(d.ticket, 1u) == ngroups - 1 ? 1 : 0;
-        }
-        lastflag = last;
-    }
-    __syncthreads();
-    if (!lastflag) return;
-    __threadfence();
-    best.q = inf_f64();
-    best.key = ~0ULL;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += TRK_THREADS) {
-        Cand c;
-        c.q = __builtin_nontemporal_load(&d.recs[i].q);
-        c.key = __builtin_nontemporal_load(&d.recs[i].key);
-        if (cand_better(c, best)) best = c;
-    }
-    __syncthreads();
-    best = block_reduce<TRK_THREADS / 64>(best, sh);
-    if (threadIdx.x == 0) {
-        *d.ticket = 0u;
-        st->ev_timed = timed;
-        la_track_done(d, best, ta);
     }
 }
 
@@ -713,6 +691,7 @@ __global__ __launch_bounds__(256) void k_rx_fill(Dev d, const Cand* src, int nre
     __shared__ Cand shc[4];
     __shared__ int zsh[5];
     const State* st = d.st;
+    if (st->stall) return;  // (no scan kernels in this launch sequence and the window could not serve the event)
     // the event's best candidate: every workgroup reduces the records for itself (no cross-
     // workgroup hand-off); workgroup 0 also turns it into the event's control state
     Cand best;
@@ -938,6 +917,205 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
 }
 
 
+// ------------------------------------------------------------------ k_track
+// k_track: serve the event from the open lookahead window (fnn_core.h "Lookahead").  The work
+// items (tracked pairs, then the sweep of the newest cluster's rows) are spread over the track
+// workgroups; the last one to arrive reduces the per-workgroup minima and decides whether the
+// window certifies the minimum (la_hit: the scan kernels of this event return at once) or the
+// event has to scan.  force_base: the host's schedule asks for a new window at this event.
+//
+// Workgroup 0 is the CHAIN workgroup: when the previous event's k_update left the new cluster's
+// exact sequential row sum to be computed (chain_pending; ~20 us of one workgroup), it is computed
+// here, BESIDE the tracking.  Only the sweep of that cluster's own rows needs the sum: it runs on
+// the tree-ordered sum of k_update's partials, and its pairs compete in a separate record.  Both
+// summation orders are within eps of the exact sum, so if the best swept pair lies further than
+// the margin above the best other pair, the winner - an exactly evaluated pair - is certain.
+// Otherwise the last workgroup waits for the chain workgroup and sweeps again with the exact sum.
+constexpr int TRK_THREADS = 1024;
+constexpr int TRK_GROUP = 16;   // arrival tickets in two levels: same-address device-scope atomics cost ~50 ns each
+constexpr int TRK_FLAG = 32 * 65;  // word of d.ticket that carries "chain of event # done"
+
+__device__ __forceinline__ void chain_workgroup(const Dev& d, ChainLds<CH_EPT>& L) {
+    State* st = d.st;
+    if (!st->chain_pending) return;
+    const double usx = block_chain_sum<CH_EPT>(d.chain, st->chain_m, CH_GUARD_BITS, L, nullptr);
+    if (threadIdx.x == 0) {
+        d.Sx[st->chain_U] = usx;      // u.Sx and u.nbr.Sx (NetMakerOriginal.java:532, 535)
+        d.Sx[st->chain_U + 1] = usx;
+        __threadfence();
+        __hip_atomic_store(d.ticket + TRK_FLAG, (unsigned)st->n_events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// exact evaluation of the sweep items only, without inserting pairs (the approximate sweep did that)
+__device__ __forceinline__ void sweep_exact_item(const Dev& d, int64_t r, const TrackArgs& ta, Cand& bx) {
+    const int32_t half = (ta.m + 1) / 2;
+    const int32_t fi = ta.nf0 + (int32_t)(r / half), cp = (int32_t)(r % half);
+    if (fi >= ta.nf) return;
+    const int32_t id = d.fresh[2 * fi], stamp = d.fresh[2 * fi + 1];
+    const int32_t f0 = d.islot[id];
+    if (f0 < 0 || d.cstamp[id] != stamp) return;
+    const int32_t s2 = 2 * cp;
+    if (s2 >= ta.m || s2 == f0) return;
+    const double* F0 = d.D + (int64_t)f0 * d.ld + s2;
+    const double* F1 = F0 + d.ld;
+    const double a0 = F0[0], a1 = F0[1], b0 = F1[0], b1 = F1[1];
+    if (f0 > s2)
+        scan_micro(f0, s2, ta.m, ta.twoP, ta.cm2, a0, a1, b0, b1, d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1],
+                   d.Sx[s2], d.Sx[s2 + 1], d.spos[s2], d.spos[s2 + 1], bx);
+    else
+        scan_micro(s2, f0, ta.m, ta.twoP, ta.cm2, a0, b0, a1, b1, d.Sx[s2], d.Sx[s2 + 1], d.spos[s2], d.spos[s2 + 1],
+                   d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1], bx);
+}
+
+constexpr int TRK_REC_U = 1024;  // offset of the swept-pair records in d.recs
+
+__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed, int has_scan) {
+    __shared__ ChainLds<CH_EPT> L;
+    __shared__ Cand sh[TRK_THREADS / 64];
+    __shared__ int lastflag;
+    __shared__ double shs[2];
+    State* st = d.st;
+    if (blockIdx.x == 0) {  // the chain workgroup
+        chain_workgroup(d, L);
+        return;
+    }
+    const int wg = (int)blockIdx.x - 1, G = (int)gridDim.x - 1;
+    if (st->done) return;
+    if (!has_scan && st->stall) {  // (the launch sequence has no scan kernels and the window is gone: nothing to do)
+        if (wg == 0 && threadIdx.x == 0) st->n_stalled++;
+        return;
+    }
+    if (force_base || !la_active(*st)) {
+        if (wg == 0 && threadIdx.x == 0) {
+            st->ev_timed = timed;
+            if (st->la_valid) st->la_prev_end = 0;  // the window ends on schedule
+            la_prepare_base(*st, d.lacnt);
+            st->stall = has_scan ? 0 : 1;
+            if (!has_scan) st->n_stalled++;
+        }
+        return;
+    }
+    TrackArgs ta = track_args(*st);
+    const int64_t items = track_item_count(ta);
+    // the swept cluster's exact row sum is being computed by workgroup 0: tree-ordered sum first
+    double eps_u = 0.0;
+    const bool pending = st->chain_pending != 0 && ta.nf > ta.nf0;
+    if (pending) {
+        const bool simple = (ta.nf - ta.nf0 == 1) && d.islot[d.fresh[2 * (ta.nf - 1)]] == st->chain_U;
+        if (!simple) {
+            // (not expected: more than one unswept cluster) wait for the exact sum before sweeping
+            if (threadIdx.x == 0) {
+                const unsigned want = (unsigned)st->n_events;
+                long spins = 0;
+                while (__hip_atomic_load(d.ticket + TRK_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want && ++spins < 20000000) __builtin_amdgcn_s_sleep(2);
+                __threadfence();
+            }
+            __syncthreads();
+        } else {
+            if (threadIdx.x < 64) {
+                double su = 0.0, sa = 0.0;
+                const int np = st->upart_n;
+                for (int b = threadIdx.x; b < np; b += 64) { su += d.upart[2 * b]; sa += d.upart[2 * b + 1]; }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) { su += __shfl_down(su, off, 64); sa += __shfl_down(sa, off, 64); }
+                if (threadIdx.x == 0) { shs[0] = su; shs[1] = sa; }
+            }
+            __syncthreads();
+            ta.approx = 1;
+            ta.sxu = shs[0];
+            // both the sequential and the tree order are within gamma_m sum|terms| of the exact sum
+            eps_u = 4.0 * ((double)ta.m + 8.0) * 1.1102230246251565e-16 * shs[1];
+        }
+    }
+    Cand best, bestu;
+    best.q = inf_f64();
+    best.key = ~0ULL;
+    bestu = best;
+    for (int64_t it = (int64_t)wg * TRK_THREADS + threadIdx.x; it < items; it += (int64_t)G * TRK_THREADS)
+        track_item(d, it, ta, best, bestu);
+    best = block_reduce<TRK_THREADS / 64>(best, sh);
+    if (threadIdx.x == 0) d.recs[wg] = best;
+    if (ta.approx) {
+        __syncthreads();
+        bestu = block_reduce<TRK_THREADS / 64>(bestu, sh);
+        if (threadIdx.x == 0) d.recs[TRK_REC_U + wg] = bestu;
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        // last of its group of TRK_GROUP workgroups -> last of the groups (counters 128 bytes apart)
+        const unsigned g = (unsigned)wg / TRK_GROUP, ngroups = ((unsigned)G + TRK_GROUP - 1) / TRK_GROUP;
+        const unsigned gsize = g + 1 < ngroups ? (unsigned)TRK_GROUP : (unsigned)G - g * TRK_GROUP;
+        int last = 0;
+        if (atomicAdd(d.ticket + 32 * (g + 1), 1u) == gsize - 1) {
+            d.ticket[32 * (g + 1)] = 0u;
+            __threadfence();
+            last = atomicAdd(d.ticket, 1u) == ngroups - 1 ? 1 : 0;
+        }
+        lastflag = last;
+    }
+    __syncthreads();
+    if (!lastflag) return;
+    __threadfence();
+    auto reduce_recs = [&](const Cand* recs) {
+        Cand b;
+        b.q = inf_f64();
+        b.key = ~0ULL;
+        for (int i = threadIdx.x; i < G; i += TRK_THREADS) {
+            Cand c;
+            c.q = __builtin_nontemporal_load(&recs[i].q);
+            c.key = __builtin_nontemporal_load(&recs[i].key);
+            if (cand_better(c, b)) b = c;
+        }
+        __syncthreads();
+        b = block_reduce<TRK_THREADS / 64>(b, sh);
+        if (threadIdx.x == 0) sh[0] = b;
+        __syncthreads();
+        b = sh[0];
+        __syncthreads();
+        return b;
+    };
+    best = reduce_recs(d.recs);
+    if (ta.approx) {
+        bestu = reduce_recs(d.recs + TRK_REC_U);
+        // |Q~ - Q| <= eps_u + the roundings of (c-2) D - Sp - Sq, each <= 2^-53 of a term <= (c + 2n) Dmax
+        const double dmax = __builtin_bit_cast(double, st->dmax_bits);
+        const double margin = 2.0 * eps_u + 192.0 * 1.1102230246251565e-16 * ((double)st->n + 4.0) * dmax + 1e-300;
+        const bool certain = (bestu.q - margin > best.q) || (bestu.q == inf_f64());
+        if (!certain) {
+            // a swept pair may be the minimum: wait for the chain workgroup, sweep again with the exact sum
+            if (threadIdx.x == 0) {
+                const unsigned want = (unsigned)st->n_events;
+                long spins = 0;
+                while (__hip_atomic_load(d.ticket + TRK_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+                    if (++spins > 20000000) { st->error = 10; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __threadfence();
+                st->n_sweep_waits++;
+            }
+            __syncthreads();
+            Cand bx;
+            bx.q = inf_f64();
+            bx.key = ~0ULL;
+            for (int64_t r = threadIdx.x; r < items - ta.np; r += TRK_THREADS) sweep_exact_item(d, r, ta, bx);
+            bx = block_reduce<TRK_THREADS / 64>(bx, sh);
+            if (threadIdx.x == 0) sh[0] = bx;
+            __syncthreads();
+            bx = sh[0];
+            if (cand_better(bx, best)) best = bx;
+        }
+        // certain: every swept pair's exact Q lies strictly above best.q, so best wins as it stands
+    }
+    if (threadIdx.x == 0) {
+        *d.ticket = 0u;
+        st->ev_timed = timed;
+        la_track_done(d, best, ta);
+        st->stall = (!st->la_hit && !has_scan) ? 1 : 0;
+        if (st->stall) st->n_stalled++;
+    }
+}
+
 // ------------------------------------------------------------------ k_decide4
 // Candidate choice + merge plan (NetMakerOriginal.java:413-488), one workgroup.  Common case:
 // the choice among the <=4 candidates is certified from the tree-ordered partial sums of
@@ -974,7 +1152,7 @@ __device__ __forceinline__ void decide_on_lds_copy(const Dev& d, State& lst, con
 
 __device__ __forceinline__ void decide4_body(const Dev& d, int nparts, ChainLds<CH_EPT>& L, State& lst, double* red) {
     State* st = d.st;
-    if (!st->ev_active || st->ev_finish) return;
+    if (!st->ev_active || st->ev_finish || st->stall) return;
     const int need_rx = st->need_rx;
     double rxa[4] = {0.0, 0.0, 0.0, 0.0};
     int certified = 1;
@@ -1021,25 +1199,65 @@ __global__ __launch_bounds__(CH_T) void k_decide4(Dev d, int nparts) {
 // ------------------------------------------------------------------ k_update
 // subtract + every micro-op + add of one event in ONE launch (fnn_core.h: update_bulk /
 // update_special).  The last workgroup handles the <= 8 involved slots in phases.
-__global__ __launch_bounds__(256) void k_update(Dev d) {
-    const State* st = d.st;
-    if (!st->ev_active) return;
-    if (blockIdx.x == gridDim.x - 1) {
+__global__ __launch_bounds__(256) void k_update(Dev d, int defer) {
+    __shared__ double shp[4][2];
+    State* st = d.st;
+    if (!st->ev_active || st->stall) return;
+    double dsum = 0.0, dabs = 0.0;
+    const bool special = blockIdx.x == gridDim.x - 1;
+    if (special) {
         const int nph = update_special_phases(*st);
         for (int ph = 0; ph < nph; ph++) {
-            update_special(d, ph, (int)threadIdx.x);
+            const double v = update_special(d, ph, (int)threadIdx.x);
+            dsum += v;
+            dabs += v < 0.0 ? -v : v;
             __syncthreads();  // a phase's stores are visible to the next phase (same CU, same L1)
         }
-        return;
+    } else {
+        const double v = update_bulk(d, blockIdx.x * 256 + threadIdx.x);
+        dsum = v;
+        dabs = v < 0.0 ? -v : v;
     }
-    update_bulk(d, blockIdx.x * 256 + threadIdx.x);
+    if (!defer) return;  // k_finalize follows
+    // deferred row sum of the new cluster: tree-ordered partial sums for the next event's sweep, and
+    // the event is closed here; the exact sequential sum is computed beside the next event's tracking
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        dsum += __shfl_down(dsum, off, 64);
+        dabs += __shfl_down(dabs, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { shp[threadIdx.x >> 6][0] = dsum; shp[threadIdx.x >> 6][1] = dabs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d.upart[2 * blockIdx.x] = ((shp[0][0] + shp[1][0]) + shp[2][0]) + shp[3][0];
+        d.upart[2 * blockIdx.x + 1] = ((shp[0][1] + shp[1][1]) + shp[2][1]) + shp[3][1];
+        if (special) {
+            st->upart_n = (int)gridDim.x;
+            st->chain_m = st->m;
+            st->chain_U = st->U;
+            if (st->ev_finish) {  // special finish: u, v keep the default Sx (NetNode.java:15); nothing to sum
+                d.Sx[st->U] = 0.0;
+                d.Sx[st->U + 1] = 0.0;
+                st->chain_pending = 0;
+            } else st->chain_pending = 1;
+            close_event(d);
+        }
+    }
+}
+
+// the pending exact row sum, on its own (before the host looks at the state)
+__global__ __launch_bounds__(CH_T) void k_chain_flush(Dev d) {
+    __shared__ ChainLds<CH_EPT> L;
+    chain_workgroup(d, L);
+    __syncthreads();
+    if (threadIdx.x == 0) d.st->chain_pending = 0;
 }
 
 // ------------------------------------------------------------------ k_finalize
 __global__ __launch_bounds__(CH_T) void k_finalize(Dev d) {
     __shared__ ChainLds<CH_EPT> L;
     State* st = d.st;
-    if (!st->ev_active) return;
+    if (!st->ev_active || st->stall) return;
     double usx = 0.0;
     if (!st->ev_finish) usx = block_chain_sum<CH_EPT>(d.chain, st->m, CH_GUARD_BITS, L, nullptr);
     if (threadIdx.x == 0) finalize(d, usx);
@@ -1486,7 +1704,9 @@ struct HipBackend {
     int events_grid = 16;   // main workgroups of k_events (FNN_EVENTS_GRID); one more computes the chains
     bool persistent = false; // FNN_PERSISTENT=1: run window hits inside the persistent event kernel k_events (experimental:
                              // correct, but slower than one launch sequence per event)
-    int track_grid = 128;   // workgroups of k_track (FNN_TRACK_GRID)
+    int track_grid = 64;    // track workgroups of k_track (FNN_TRACK_GRID); one more computes the pending chain
+    bool skip_unsched_scans = true; // FNN_UNSCHED_SCANS=1: keep the (mostly idle) scan kernels in unscheduled events
+    bool defer_chain = false; // set by the engine: k_update closes the event, the exact u.Sx sum runs inside the next k_track
     bool scan_nt = true;    // non-temporal matrix loads in the scan (FNN_SCAN_NT)
 
     std::string err() const { return comm_err.empty() ? std::string(hipGetErrorString(last)) : comm_err; }
@@ -1538,6 +1758,7 @@ struct HipBackend {
         if (const char* e = std::getenv("FNN_SCAN_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) scan_grid = v; }
         if (const char* e = std::getenv("FNN_SCAN_NT")) scan_nt = std::atoi(e) != 0;
         if (const char* e = std::getenv("FNN_UNSCHED_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) unsched_grid = v; }
+        if (const char* e = std::getenv("FNN_UNSCHED_SCANS")) skip_unsched_scans = std::atoi(e) == 0;
         if (const char* e = std::getenv("FNN_EVENTS_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 63) events_grid = v; }
         if (const char* e = std::getenv("FNN_PERSISTENT")) persistent = std::atoi(e) != 0;
         if (const char* e = std::getenv("FNN_EMIT_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) emit_grid = v; }
@@ -1668,10 +1889,15 @@ struct HipBackend {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool screen = use_screen(d, m_bound);
         const bool timed = timing && (sched || !screen);
-        if (d.la) hipLaunchKernelGGL(k_track, dim3(track_grid), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0);
+        // (an unscheduled event is launched without scan kernels: if its window cannot serve it, the
+        //  device stalls - this and the following such events do nothing - until the host, which
+        //  looks at the state every batch, launches an event with a scan)
+        const bool has_scan = sched || !screen || !skip_unsched_scans;
+        if (d.la) hipLaunchKernelGGL(k_track, dim3(track_grid + 1), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0, has_scan ? 1 : 0);
         if (timed) { e0 = next_event(); e1 = next_event(); ev_kind.push_back(screen ? 1 : 0); }
         int nrecs;
-        if (screen) {
+        if (screen && !has_scan) nrecs = RES_BLOCKS;  // (k_rx_fill reads one record, the window's)
+        else if (screen) {
             int nt = (tri_tile_count(m_bound, SCR_TH, SCR_R) + d.world - 1) / d.world;
             const int want = sched ? scan_grid : unsched_grid;
             dim3 gs((unsigned)(nt < want ? (nt > 0 ? nt : 1) : want));
@@ -1703,8 +1929,8 @@ struct HipBackend {
         dim3 g1 = grid1(m_bound);
         hipLaunchKernelGGL(k_rx_fill, g1, dim3(256), 0, stream, d, src, nrecs);
         hipLaunchKernelGGL(k_decide4, dim3(1), dim3(CH_T), 0, stream, d, (int)g1.x);
-        hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d);
+        hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d, defer_chain ? 1 : 0);
+        if (!defer_chain) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d);
     }
     // single GPU: the whole event
     int32_t launch_event(const Dev& d, int32_t m_bound, bool sched) {
@@ -1713,8 +1939,14 @@ struct HipBackend {
         enqueue_rest(d, m_bound, (const Cand*)d.recs, nrecs);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
+    // a pending deferred row sum, before the host reads the state
+    int32_t launch_chain_flush(const Dev& d) {
+        hipLaunchKernelGGL(k_chain_flush, dim3(1), dim3(CH_T), 0, stream, d);
+        return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
+    }
     // persistent event kernel: serves up to max_events window hits in one launch (no-op otherwise)
     int32_t launch_events(const Dev& d, int32_t max_events) {
+        hipLaunchKernelGGL(k_chain_flush, dim3(1), dim3(CH_T), 0, stream, d);
         if (!HIPOK(hipMemsetAsync(d.evctl, 0, sizeof(EvCtl), stream))) return FNN_EHIP;
         hipLaunchKernelGGL(k_events, dim3(events_grid + 1), dim3(CH_T), 0, stream, d, (int)max_events);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;

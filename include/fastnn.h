@@ -58,7 +58,7 @@ typedef struct fnn_opts {
                               find, within a rigorous error bound, the few tile units that can hold
                               the minimum, and only those are rescanned in fp64 (same result) */
     int32_t lookahead;     /* events one screening pass may serve ("lookahead window"): 0 = default
-                              (64), < 0 = off (every event scans), > 0 = that many; same result either way */
+                              (48), < 0 = off (every event scans), > 0 = that many; same result either way */
     int32_t lookahead_pairs;/* wanted number of tracked pairs per window (0 = default 32768) */
     int32_t reserved[9];
 } fnn_opts;
@@ -103,7 +103,9 @@ typedef struct fnn_stats {
     double  t_plain_s;       /* sum of the durations of the plain fp64 scan launches (k_scan; m below the screening threshold) */
     int64_t plain_launches;  /* number of those launches */
     int64_t plain_bytes;     /* 8 * E_t summed over them */
-    int64_t reserved[2];
+    int64_t n_stalled_events;/* launch sequences without scan kernels that found their window gone (they do nothing; the
+                                host relaunches with a scan at its next look at the state) */
+    int64_t reserved[1];
 } fnn_stats;
 
 typedef struct fnn_handle fnn_handle;

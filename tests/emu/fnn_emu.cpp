@@ -45,6 +45,8 @@ struct EmuBackend {
     int32_t screen_min_n() const { return 8; }   // tiny on purpose: the CPU tests exercise screening
     int32_t screen_min_m = 8;
     bool persistent = false;  // (the persistent event kernel exists only on the GPU)
+    bool defer_chain = false; // (so does the deferred chain sum)
+    int32_t launch_chain_flush(const fnn::Dev&) { return FNN_OK; }
     int32_t launch_events(const fnn::Dev&, int32_t) { return FNN_OK; }
     std::string err() const { return "emu"; }
     int32_t open(int32_t) { return FNN_OK; }
