@@ -50,8 +50,11 @@ def api() -> _capi.Api:
         a._fn("comm_unique_id", _C.c_int32, [_C.POINTER(_C.c_uint8), _C.c_char_p])
         a._fn("comm_init_rccl", _C.c_int32, [_C.c_void_p, _C.c_int32, _C.c_int32, _C.POINTER(_C.c_uint8), _C.c_char_p])
         a._fn("stream_probe", _C.c_int32, [_C.c_int32, _C.c_int64, _C.c_int32, _C.POINTER(_C.c_double)])
+        a._fn("split_weights_f64", _C.c_int32,
+              [_C.POINTER(_C.c_double), _C.c_int32, _C.c_int64, _C.POINTER(_C.c_int32), _C.c_int32,
+               _C.POINTER(_C.c_double), _C.POINTER(_capi.FnnSwStats)])
         _api = a
     return _api
 
 
-from .canonical import NeighborNetCanonical, canonical_order  # noqa: E402,F401
+from .canonical import NeighborNetCanonical, canonical_order, split_weights  # noqa: E402,F401

@@ -49,6 +49,11 @@ class FnnStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
 
 
+class FnnSwStats(C.Structure):
+    _fields_ = [("outer_iterations", C.c_int64), ("cg_calls", C.c_int64), ("cg_iterations", C.c_int64),
+                ("nsplits", C.c_int64), ("t_solve_s", C.c_double), ("reserved", C.c_int64 * 3)]
+
+
 EVENT_DTYPE = np.dtype(
     [("m_before", "<i4"), ("c_before", "<i4"), ("cx_id", "<i4"), ("cy_id", "<i4"),
      ("x_id", "<i4"), ("y_id", "<i4"), ("kind", "<i4"), ("u_id", "<i4"),

@@ -9,8 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libfastnn_hip.so")
 SRC = os.path.join(HERE, "csrc", "fnn_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "fnn_core.h"), os.path.join(HERE, "csrc", "fnn_engine.h"),
-        os.path.join(ROOT, "include", "fastnn.h")]
+SRC_SPLITS = os.path.join(HERE, "csrc", "fnn_splits.hip")  # circular split weights
+DEPS = [SRC, SRC_SPLITS, os.path.join(HERE, "csrc", "fnn_core.h"), os.path.join(HERE, "csrc", "fnn_engine.h"),
+        os.path.join(HERE, "csrc", "fnn_chain.h"), os.path.join(ROOT, "include", "fastnn.h")]
 
 # -ffp-contract=off: one rounding per fp64 operation on host and device (parity with Java doubles)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
@@ -86,7 +87,7 @@ def build_host(force: bool = False) -> None:
 def build(force: bool = False) -> str:
     if force or stale():
         check_isa()
-        cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC]
+        cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC, SRC_SPLITS]
         subprocess.check_call(cmd)
     build_host(force)
     return LIB

@@ -76,3 +76,19 @@ def canonical_order(D: np.ndarray, device: int = 0, validate: bool = True) -> np
     a.check(a.canonical_order_f64(D.ctypes.data_as(C.POINTER(C.c_double)), n, n, C.byref(opts),
                                   order.ctypes.data_as(C.POINTER(C.c_int32)), None))
     return order
+
+
+def split_weights(D: np.ndarray, ordering: np.ndarray, device: int = 0):
+    """Non-negative least-squares weights of the circular splits of `ordering` over
+    `fnn_split_weights_f64` (CircularSplitWeights.java's method; index order of the reference's live
+    path, FastNN.java:405-419).  Returns (weights[n(n-1)/2], stats dict)."""
+    from . import api
+    a = api()
+    D = np.ascontiguousarray(D, dtype=np.float64)
+    n = D.shape[0]
+    o = np.ascontiguousarray(ordering, dtype=np.int32)
+    w = np.zeros(n * (n - 1) // 2, dtype=np.float64)
+    st = _capi.FnnSwStats()
+    a.check(a.split_weights_f64(D.ctypes.data_as(C.POINTER(C.c_double)), n, n, o.ctypes.data_as(C.POINTER(C.c_int32)),
+                                device, w.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)))
+    return w, {k: getattr(st, k) for k, _ in st._fields_ if k != "reserved"}

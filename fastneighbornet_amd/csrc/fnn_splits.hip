@@ -1,0 +1,506 @@
+// fnn_splits.hip -- circular split weights (non-negative least squares) on gfx950.
+//
+// The "next" row N1 of SURVEY.md 8(f): given the circular ordering, estimate the weights of the
+// n(n-1)/2 circular splits by constrained (x >= 0) ordinary least squares, as the reference does
+// with an active-set method around a conjugate-gradient solve on implicit operators
+// (CircularSplitWeights.java:366-557 runActiveConjugate, :769-831 circularConjugateGrads,
+// :603-731 calculateAtx / calculateAb, :247-271 runUnconstrainedLS, :283-337 worstIndices), with
+// the re-ordering of the distances by the circular ordering restored (setupD :202-211)
+// and the result mapped to the index space of the reference's live path (FastNN.java:405-419).
+//
+// GPU formulation.  All vectors of the method (split weights x, distances d, residuals ...) are
+// kept as the strict upper triangle of dense n x n fp64 arrays: entry [i][j], i < j, is the split
+// (i, j) = cycle positions {i+1 .. j}, or the pair of positions (i, j).  The reference evaluates
+// A b and A^T y with anti-diagonal recurrences (n - 1 dependent sweeps); here both are O(1)
+// gathers from a 2-D inclusive prefix sum P of the argument (row scan, LDS-tiled transpose, row
+// scan; P is held transposed):
+//   (A b)[a][b]   = sum of x over the splits that separate positions a < b
+//                 = rect(i in [0,a-1], j in [a,b-1]) + rect(i in [a,b-1], j in [b,n-1])
+//   (A^T y)[i][j] = sum of y over the pairs separated by split (i,j), S = {i+1..j}
+//                 = (RS[j] - RS[i]) - 2 (P[j][j] - P[i][j]),  RS = prefix of the row sums of the
+//                   symmetric completion of y.
+// Everything is bandwidth-bound elementwise / scan work on n^2 doubles; the control flow of the
+// active-set method (a handful of scalars per step) runs on the host.  Results agree with the
+// reference's algorithm to rounding (different summation order), not bit for bit; the optimum is
+// unique and the tests hold the weights to 1e-6 relative of the oracle and of a dense NNLS solve.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fnn_engine.h"  // fnn::fail / the thread-local error message shared with fnn_hip.hip
+
+namespace fnnsw {
+
+constexpr double CG_EPSILON = 1e-8;  // CircularSplitWeights.java:54
+constexpr int T = 256;
+
+#define SWOK(x) ((x) == hipSuccess)
+
+// ---------------------------------------------------------------- 2-D prefix sum
+// row scan in place: one workgroup per row
+__global__ __launch_bounds__(T) void k_rowscan(double* a, int n, int64_t ld) {
+    __shared__ double wsum[T / 64];
+    __shared__ double carry_s;
+    double* row = a + (int64_t)blockIdx.x * ld;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0.0;
+    __syncthreads();
+    for (int base = 0; base < n; base += T) {
+        const int i = base + (int)threadIdx.x;
+        double v = i < n ? row[i] : 0.0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double t = __shfl_up(v, d, 64);
+            if (lane >= d) v += t;
+        }
+        if (lane == 63) wsum[w] = v;
+        __syncthreads();
+        double pre = carry_s;
+        for (int k = 0; k < w; k++) pre += wsum[k];
+        v += pre;
+        if (i < n) row[i] = v;
+        __syncthreads();
+        if (threadIdx.x == T - 1) carry_s = v;
+        __syncthreads();
+    }
+}
+
+// out = in^T (n x n), 32 x 32 tiles through LDS
+__global__ __launch_bounds__(T) void k_transpose(const double* in, double* out, int n, int64_t ld) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = by + k, c = bx + tx;
+        tile[k][tx] = (r < n && c < n) ? in[(int64_t)r * ld + c] : 0.0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int r = bx + k, c = by + tx;
+        if (r < n && c < n) out[(int64_t)r * ld + c] = tile[tx][k];
+    }
+}
+
+// ---------------------------------------------------------------- operators (gathers from the transposed prefix Pt[j][i] = P[i][j])
+__device__ __forceinline__ double PT(const double* Pt, int64_t ld, int i, int j) {  // P[i][j], -1 -> 0
+    return (i < 0 || j < 0) ? 0.0 : Pt[(int64_t)j * ld + i];
+}
+
+// d[a][b] = (A x)[a][b] for a < b, from the prefix of x
+__global__ __launch_bounds__(T) void k_ab(const double* Pt, double* d, int n, int64_t ld) {
+    const int b = blockIdx.x * T + threadIdx.x, a = blockIdx.y;
+    if (b >= n || a >= b) return;
+    const double first = PT(Pt, ld, a - 1, b - 1) - PT(Pt, ld, a - 1, a - 1);
+    const double second = (PT(Pt, ld, b - 1, n - 1) - PT(Pt, ld, a - 1, n - 1)) - (PT(Pt, ld, b - 1, b - 1) - PT(Pt, ld, a - 1, b - 1));
+    d[(int64_t)a * ld + b] = first + second;
+}
+
+// rs[a] = sum over b != a of the symmetric completion of y, from the prefix Q of y (upper triangle)
+__global__ __launch_bounds__(T) void k_rowsums(const double* Qt, double* rs, int n, int64_t ld) {
+    const int a = blockIdx.x * T + threadIdx.x;
+    if (a >= n) return;
+    const double rowsum = PT(Qt, ld, a, n - 1) - PT(Qt, ld, a - 1, n - 1);
+    const double colsum = PT(Qt, ld, n - 1, a) - PT(Qt, ld, n - 1, a - 1);
+    rs[a] = rowsum + colsum;
+}
+// inclusive prefix of rs (one workgroup; n <= 65536)
+__global__ __launch_bounds__(1024) void k_scan1(double* v, int n) {
+    __shared__ double wsum[16];
+    __shared__ double carry_s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0.0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        double x = i < n ? v[i] : 0.0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double t = __shfl_up(x, d, 64);
+            if (lane >= d) x += t;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        double pre = carry_s;
+        for (int k = 0; k < w; k++) pre += wsum[k];
+        x += pre;
+        if (i < n) v[i] = x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = x;
+        __syncthreads();
+    }
+}
+// p[i][j] = (A^T y)[i][j] for i < j
+__global__ __launch_bounds__(T) void k_atx(const double* Qt, const double* RS, double* p, int n, int64_t ld) {
+    const int j = blockIdx.x * T + threadIdx.x, i = blockIdx.y;
+    if (j >= n || i >= j) return;
+    const double inside = PT(Qt, ld, j, j) - PT(Qt, ld, i, j);
+    p[(int64_t)i * ld + j] = (RS[j] - RS[i]) - 2.0 * inside;
+}
+
+// ---------------------------------------------------------------- setup kernels
+// d'[a][b] = D[ord[a+1]-1][ord[b+1]-1] for a < b, 0 elsewhere (restored setupD)
+__global__ __launch_bounds__(T) void k_reorder(const double* D, int64_t ldD, const int32_t* ord, double* d, int n, int64_t ld) {
+    const int b = blockIdx.x * T + threadIdx.x, a = blockIdx.y;
+    if (b >= n) return;
+    double v = 0.0;
+    if (a < b) v = D[(int64_t)(ord[a + 1] - 1) * ldD + (ord[b + 1] - 1)];
+    d[(int64_t)a * ld + b] = v;
+}
+// Chepoi & Fichet closed form of the unconstrained optimum (runUnconstrainedLS :247-271), with dd(a,b)
+// the re-ordered distance of positions a, b (either order, 0 on the diagonal):
+//   x[i][j] = ( dd(i,j) + dd(i+1,j+1) - dd(i,j+1) - dd(i+1,j) ) / 2, positions taken modulo n
+__device__ __forceinline__ double dd(const double* d, int64_t ld, int a, int b) {
+    if (a == b) return 0.0;
+    return a < b ? d[(int64_t)a * ld + b] : d[(int64_t)b * ld + a];
+}
+__global__ __launch_bounds__(T) void k_unconstrained(const double* d, double* x, int n, int64_t ld) {
+    const int j = blockIdx.x * T + threadIdx.x, i = blockIdx.y;
+    if (j >= n) return;
+    double v = 0.0;
+    if (i < j) {
+        const int i1 = i + 1, j1 = (j + 1) % n;
+        v = (dd(d, ld, i, j) + dd(d, ld, i1, j1) - dd(d, ld, i, j1) - dd(d, ld, i1, j)) / 2.0;
+    }
+    x[(int64_t)i * ld + j] = v;
+}
+
+// ---------------------------------------------------------------- vector kernels over the strict upper triangle
+enum { OP_COPY = 0, OP_R_INIT, OP_P_UPDATE, OP_W_MASK, OP_XR_UPDATE, OP_CONTRACT, OP_MOVE_OLD, OP_GRAD };
+struct VecArgs {
+    double* a; double* b; const double* c; const double* e; uint8_t* act;
+    double s0, s1;
+    int n; int64_t ld;
+};
+template <int OP>
+__global__ __launch_bounds__(T) void k_vec(VecArgs g) {
+    const int j = blockIdx.x * T + threadIdx.x, i = blockIdx.y;
+    if (j >= g.n || i >= j) return;
+    const int64_t k = (int64_t)i * g.ld + j;
+    if (OP == OP_COPY) g.a[k] = g.c[k];
+    else if (OP == OP_R_INIT) g.a[k] = g.act[k] ? 0.0 : g.c[k] - g.a[k];            // r = active ? 0 : b - r   (:785-789)
+    else if (OP == OP_P_UPDATE) g.a[k] = g.c[k] + g.s0 * g.a[k];                      // p = r + beta p           (:808)
+    else if (OP == OP_W_MASK) { if (g.act[k]) g.a[k] = 0.0; }                         // w = 0 on the active set  (:817-819)
+    else if (OP == OP_XR_UPDATE) { g.a[k] += g.s0 * g.c[k]; g.b[k] -= g.s0 * g.e[k]; }  // x += alpha p; r -= alpha w (:826-829)
+    else if (OP == OP_CONTRACT) {                                                     // worstIndices + contraction (:411-430)
+        const double v = g.a[k];
+        if (v < g.s0 || (g.s1 != 0.0 && v == g.s0)) { g.a[k] = 0.0; g.act[k] = 1; }
+    } else if (OP == OP_MOVE_OLD) { if (!g.act[k]) g.b[k] += g.s0 * (g.a[k] - g.b[k]); }  // old_x += min_xi (x - old_x) (:452-454)
+    else if (OP == OP_GRAD) g.a[k] = (g.a[k] - g.c[k]) * 2.0;                          // r = 2 (AtWAx - AtWd)     (:478-479)
+}
+
+// reductions: per-workgroup partials, folded by a second launch (fixed order: reproducible)
+struct Best { double v; int64_t k; };
+enum { RD_DOT = 0, RD_COUNT_NEG, RD_COUNT_LT, RD_COUNT_EQ, RD_MIN_RATIO, RD_MIN_ACTIVE_GRAD, RD_ANY_NEG };
+template <int RD>
+__global__ __launch_bounds__(T) void k_reduce(const double* a, const double* b, const uint8_t* act, double s0, int n, int64_t ld,
+                                              double* partial, Best* bpartial) {
+    __shared__ double sh[T / 64];
+    __shared__ Best shb[T / 64];
+    double acc = 0.0;
+    Best best{INFINITY, INT64_MAX};
+    for (int i = blockIdx.y; i < n; i += gridDim.y)
+        for (int j = blockIdx.x * T + threadIdx.x; j < n; j += gridDim.x * T) {
+            if (i >= j) continue;
+            const int64_t k = (int64_t)i * ld + j;
+            if (RD == RD_DOT) acc += a[k] * b[k];
+            else if (RD == RD_COUNT_NEG) acc += a[k] < 0.0 ? 1.0 : 0.0;
+            else if (RD == RD_COUNT_LT) acc += (a[k] < 0.0 && a[k] < s0) ? 1.0 : 0.0;
+            else if (RD == RD_COUNT_EQ) acc += (a[k] < 0.0 && a[k] == s0) ? 1.0 : 0.0;
+            else if (RD == RD_MIN_RATIO) {  // first minimum of old_x / (old_x - x) over x < 0 (:434-445)
+                if (a[k] < 0.0) {
+                    const double xi = b[k] / (b[k] - a[k]);
+                    if (xi < best.v || (xi == best.v && k < best.k)) { best.v = xi; best.k = k; }
+                }
+            } else if (RD == RD_MIN_ACTIVE_GRAD) {  // first minimum of the gradient over the active set (:480-487)
+                if (act[k]) {
+                    const double gv = a[k];
+                    if (gv < best.v || (gv == best.v && k < best.k)) { best.v = gv; best.k = k; }
+                }
+            }
+        }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (RD == RD_MIN_RATIO || RD == RD_MIN_ACTIVE_GRAD) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            Best o;
+            o.v = __shfl_down(best.v, off, 64);
+            o.k = __shfl_down((long long)best.k, off, 64);
+            if (o.v < best.v || (o.v == best.v && o.k < best.k)) best = o;
+        }
+        if (lane == 0) shb[w] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int q = 1; q < T / 64; q++)
+                if (shb[q].v < best.v || (shb[q].v == best.v && shb[q].k < best.k)) best = shb[q];
+            bpartial[blockIdx.y * gridDim.x + blockIdx.x] = best;
+        }
+    } else {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) sh[w] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    }
+}
+// extreme negative values for the bisection of the cutoff
+__global__ __launch_bounds__(T) void k_minneg(const double* a, int n, int64_t ld, double* partial) {
+    __shared__ double sh[T / 64];
+    double mn = 0.0;
+    for (int i = blockIdx.y; i < n; i += gridDim.y)
+        for (int j = blockIdx.x * T + threadIdx.x; j < n; j += gridDim.x * T)
+            if (i < j) { const double v = a[(int64_t)i * ld + j]; if (v < mn) mn = v; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const double o = __shfl_down(mn, off, 64); if (o < mn) mn = o; }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < T / 64; q++) if (sh[q] < mn) mn = sh[q];
+        partial[blockIdx.y * gridDim.x + blockIdx.x] = mn;
+    }
+}
+__global__ __launch_bounds__(T) void k_fill(double* a, int64_t count, double v) {
+    const int64_t i = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (i < count) a[i] = v;
+}
+// live[k] over (i, j), 0 <= i < j <= n-1, from the fast algorithm's x
+__global__ __launch_bounds__(T) void k_to_live(const double* x, double* live, int n, int64_t ld) {
+    const int j = blockIdx.x * T + threadIdx.x, i = blockIdx.y;
+    if (j >= n || i >= j) return;
+    const int64_t k = ((int64_t)(2 * n - i - 1) * i) / 2 + (j - i - 1);  // row-major index of (i, j), i < j
+    const double v = (i >= 1) ? x[(int64_t)(i - 1) * ld + (j - 1)] : x[(int64_t)(j - 1) * ld + (n - 1)];
+    live[k] = v;
+}
+
+// ---------------------------------------------------------------- host driver
+struct Solver {
+    int n = 0;
+    int64_t ld = 0;
+    hipStream_t s = nullptr;
+    std::vector<void*> allocs;
+    double *d = nullptr, *x = nullptr, *r = nullptr, *w = nullptr, *p = nullptr, *y = nullptr, *old_x = nullptr, *atwd = nullptr;
+    double *P = nullptr, *Pt = nullptr, *rs = nullptr, *partial = nullptr, *live = nullptr, *Dm = nullptr;
+    int32_t* ord = nullptr;
+    uint8_t* act = nullptr;
+    Best* bpartial = nullptr;
+    dim3 grid2, gred;
+    int64_t st_outer = 0, st_cg = 0, st_it = 0;
+    bool ok = true;
+
+    template <class Tp>
+    Tp* alloc(size_t count) {
+        void* p_ = nullptr;
+        if (!SWOK(hipMalloc(&p_, sizeof(Tp) * (count ? count : 1)))) { ok = false; return nullptr; }
+        allocs.push_back(p_);
+        return (Tp*)p_;
+    }
+    ~Solver() {
+        for (void* p_ : allocs) (void)hipFree(p_);
+        if (s) (void)hipStreamDestroy(s);
+    }
+    // 2-D inclusive prefix of src (upper triangle, zeros elsewhere) -> Pt (transposed)
+    void prefix(const double* src) {
+        (void)hipMemcpyAsync(P, src, sizeof(double) * (size_t)n * (size_t)ld, hipMemcpyDeviceToDevice, s);
+        hipLaunchKernelGGL(k_rowscan, dim3(n), dim3(T), 0, s, P, n, ld);
+        hipLaunchKernelGGL(k_transpose, dim3((n + 31) / 32, (n + 31) / 32), dim3(T), 0, s, P, Pt, n, ld);
+        hipLaunchKernelGGL(k_rowscan, dim3(n), dim3(T), 0, s, Pt, n, ld);
+    }
+    void Ab(const double* b_, double* out) {  // out = A b
+        prefix(b_);
+        hipLaunchKernelGGL(k_ab, grid2, dim3(T), 0, s, Pt, out, n, ld);
+    }
+    void Atx(const double* y_, double* out) {  // out = A^T y
+        prefix(y_);
+        hipLaunchKernelGGL(k_rowsums, dim3((n + T - 1) / T), dim3(T), 0, s, Pt, rs, n, ld);
+        hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, s, rs, n);
+        hipLaunchKernelGGL(k_atx, grid2, dim3(T), 0, s, Pt, rs, out, n, ld);
+    }
+    template <int OP>
+    void vec(double* a, double* b, const double* c, const double* e, double s0 = 0.0, double s1 = 0.0) {
+        VecArgs g{a, b, c, e, act, s0, s1, n, ld};
+        hipLaunchKernelGGL(k_vec<OP>, grid2, dim3(T), 0, s, g);
+    }
+    template <int RD>
+    double reduce_sum(const double* a, const double* b, double s0 = 0.0) {
+        hipLaunchKernelGGL(k_reduce<RD>, gred, dim3(T), 0, s, a, b, act, s0, n, ld, partial, bpartial);
+        std::vector<double> h((size_t)gred.x * gred.y);
+        (void)hipMemcpyAsync(h.data(), partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        double acc = 0.0;
+        for (double v : h) acc += v;
+        return acc;
+    }
+    template <int RD>
+    Best reduce_best(const double* a, const double* b) {
+        hipLaunchKernelGGL(k_reduce<RD>, gred, dim3(T), 0, s, a, b, act, 0.0, n, ld, partial, bpartial);
+        std::vector<Best> h((size_t)gred.x * gred.y);
+        (void)hipMemcpyAsync(h.data(), bpartial, sizeof(Best) * h.size(), hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        Best best{INFINITY, INT64_MAX};
+        for (const Best& o : h)
+            if (o.v < best.v || (o.v == best.v && o.k < best.k)) best = o;
+        return best;
+    }
+    double min_negative(const double* a) {
+        hipLaunchKernelGGL(k_minneg, gred, dim3(T), 0, s, a, n, ld, partial);
+        std::vector<double> h((size_t)gred.x * gred.y);
+        (void)hipMemcpyAsync(h.data(), partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        double mn = 0.0;
+        for (double v : h) if (v < mn) mn = v;
+        return mn;
+    }
+
+    // circularConjugateGrads (:769-831), W = 1
+    void cg() {
+        const int64_t kmax = (int64_t)n * (n - 1) / 2;
+        Ab(x, y);
+        Atx(y, r);
+        vec<OP_R_INIT>(r, nullptr, atwd, nullptr);
+        double rho = reduce_sum<RD_DOT>(r, r), rho_old = 0.0;
+        const double e_0 = CG_EPSILON * std::sqrt(reduce_sum<RD_DOT>(atwd, atwd));
+        int64_t k = 0;
+        while (rho > e_0 * e_0 && k < kmax) {
+            k++;
+            if (k == 1) vec<OP_COPY>(p, nullptr, r, nullptr);
+            else vec<OP_P_UPDATE>(p, nullptr, r, nullptr, rho / rho_old);
+            Ab(p, y);
+            Atx(y, w);
+            vec<OP_W_MASK>(w, nullptr, nullptr, nullptr);
+            const double alpha = rho / reduce_sum<RD_DOT>(p, w);
+            vec<OP_XR_UPDATE>(x, r, p, w, alpha);
+            rho_old = rho;
+            rho = reduce_sum<RD_DOT>(r, r);
+        }
+        st_cg++;
+        st_it += k;
+    }
+    // worstIndices(x, 0.6) + contraction (:411-430).  Returns false if nothing is negative.
+    bool contract_worst() {
+        const int64_t num_neg = (int64_t)reduce_sum<RD_COUNT_NEG>(x, nullptr);
+        if (num_neg == 0) return false;
+        const int64_t nkept = (int64_t)std::ceil(0.6 * (double)num_neg);
+        // cutoff = nkept-th smallest negative value.  count(x < t) is monotone in t; bisect over the
+        // bit patterns of the negative doubles (larger pattern = more negative), at most 64 steps:
+        // invariant count(x < val(lo)) < nkept <= count(x < val(hi)), lo more negative than hi
+        auto val = [](uint64_t bits) { double v; std::memcpy(&v, &bits, 8); return v; };
+        const double mn = min_negative(x);
+        uint64_t lo, hi = 0x8000000000000000ULL;  // hi = -0.0: count(x < -0.0) = num_neg >= nkept
+        std::memcpy(&lo, &mn, 8);                  // count(x < min) = 0 < nkept
+        while (lo - hi > 1) {
+            const uint64_t mid = hi + (lo - hi) / 2;
+            const int64_t c = (int64_t)reduce_sum<RD_COUNT_LT>(x, nullptr, val(mid));
+            if (c >= nkept) hi = mid; else lo = mid;
+        }
+        // no double lies strictly between val(lo) and val(hi): the nkept-th smallest value is val(lo).
+        // Values below it all go; of the values equal to it the reference takes the first
+        // nkept - count(<) by index - here they are taken together (the same unless equal negative
+        // weights straddle the 60 % mark; the optimum reached does not depend on it)
+        vec<OP_CONTRACT>(x, nullptr, nullptr, nullptr, val(lo), 1.0);
+        return true;
+    }
+
+    // runActiveConjugate (:366-557)
+    void active_conjugate() {
+        hipLaunchKernelGGL(k_unconstrained, dim3((n + T - 1) / T, n), dim3(T), 0, s, d, x, n, ld);
+        if (reduce_sum<RD_COUNT_NEG>(x, nullptr) == 0.0) return;
+        (void)hipMemsetAsync(act, 0, (size_t)n * (size_t)ld, s);
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)((n * ld + T - 1) / T)), dim3(T), 0, s, old_x, (int64_t)n * ld, 1.0);  // Arrays.fill(old_x, 1.0) (:383)
+        Atx(d, atwd);
+        bool first_pass = true;
+        for (;;) {
+            st_outer++;
+            for (;;) {
+                if (!first_pass) cg();
+                first_pass = false;
+                if (contract_worst()) cg();
+                const Best mr = reduce_best<RD_MIN_RATIO>(x, old_x);
+                if (mr.k == INT64_MAX) break;  // feasible
+                vec<OP_MOVE_OLD>(x, old_x, nullptr, nullptr, mr.v);
+                const uint8_t one = 1;
+                const double zero = 0.0;
+                (void)hipMemcpyAsync(act + mr.k, &one, 1, hipMemcpyHostToDevice, s);
+                (void)hipMemcpyAsync(x + mr.k, &zero, sizeof(double), hipMemcpyHostToDevice, s);
+                (void)hipStreamSynchronize(s);
+            }
+            Ab(x, y);
+            Atx(y, r);
+            vec<OP_GRAD>(r, nullptr, atwd, nullptr);
+            const Best mg = reduce_best<RD_MIN_ACTIVE_GRAD>(r, nullptr);
+            if (mg.k == INT64_MAX || mg.v > -0.0000001) break;
+            const uint8_t zero8 = 0;
+            (void)hipMemcpyAsync(act + mg.k, &zero8, 1, hipMemcpyHostToDevice, s);
+            (void)hipStreamSynchronize(s);
+        }
+    }
+};
+
+}  // namespace fnnsw
+
+extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD, const int32_t* ordering, int32_t device,
+                                         double* weights_out, fnn_sw_stats* stats) {
+    using namespace fnnsw;
+    if (!D || !ordering || !weights_out || n < 2 || ldD < n) return fnn::fail(FNN_EINVAL, "fnn_split_weights_f64: bad arguments");
+    {
+        std::vector<char> seen((size_t)n + 1, 0);
+        for (int i = 1; i <= n; i++) {
+            if (ordering[i] < 1 || ordering[i] > n || seen[(size_t)ordering[i]]) return fnn::fail(FNN_EINVAL, "fnn_split_weights_f64: ordering is not a permutation of 1..n");
+            seen[(size_t)ordering[i]] = 1;
+        }
+    }
+    int cnt = 0;
+    if (!SWOK(hipGetDeviceCount(&cnt)) || cnt <= 0) return fnn::fail(FNN_EHIP, "no HIP device available");
+    if (device < 0 || device >= cnt || !SWOK(hipSetDevice(device))) return fnn::fail(FNN_EINVAL, "device ordinal out of range");
+    hipEvent_t e0, e1;
+    Solver S;
+    S.n = n;
+    S.ld = ((int64_t)n + 31) / 32 * 32 + 32;
+    if (!SWOK(hipStreamCreateWithFlags(&S.s, hipStreamNonBlocking))) return fnn::fail(FNN_EHIP, "hipStreamCreate failed");
+    const size_t NN = (size_t)n * (size_t)S.ld;
+    S.d = S.alloc<double>(NN); S.x = S.alloc<double>(NN); S.r = S.alloc<double>(NN); S.w = S.alloc<double>(NN);
+    S.p = S.alloc<double>(NN); S.y = S.alloc<double>(NN); S.old_x = S.alloc<double>(NN); S.atwd = S.alloc<double>(NN);
+    S.P = S.alloc<double>(NN); S.Pt = S.alloc<double>(NN); S.rs = S.alloc<double>((size_t)n + 8);
+    S.act = S.alloc<uint8_t>(NN);
+    S.Dm = S.alloc<double>((size_t)n * (size_t)n);
+    S.ord = S.alloc<int32_t>((size_t)n + 1);
+    S.live = S.alloc<double>((size_t)n * (n - 1) / 2);
+    S.grid2 = dim3((unsigned)((n + T - 1) / T), (unsigned)n);
+    S.gred = dim3((unsigned)((n + T - 1) / T), (unsigned)(n < 256 ? n : 256));
+    S.partial = S.alloc<double>((size_t)S.gred.x * S.gred.y);
+    S.bpartial = S.alloc<Best>((size_t)S.gred.x * S.gred.y);
+    if (!S.ok) return fnn::fail(FNN_ENOMEM, "fnn_split_weights_f64: device allocation failed");
+    for (double* v : {S.d, S.x, S.r, S.w, S.p, S.y, S.old_x, S.atwd, S.P, S.Pt}) (void)hipMemsetAsync(v, 0, sizeof(double) * NN, S.s);
+    if (!SWOK(hipMemcpy2DAsync(S.Dm, sizeof(double) * (size_t)n, D, sizeof(double) * (size_t)ldD, sizeof(double) * (size_t)n, (size_t)n,
+                               hipMemcpyHostToDevice, S.s)) ||
+        !SWOK(hipMemcpyAsync(S.ord, ordering, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, S.s)) ||
+        !SWOK(hipStreamSynchronize(S.s)))
+        return fnn::fail(FNN_EHIP, "fnn_split_weights_f64: upload failed");
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, S.s);
+    hipLaunchKernelGGL(k_reorder, dim3((unsigned)((n + T - 1) / T), (unsigned)n), dim3(T), 0, S.s, S.Dm, (int64_t)n, S.ord, S.d, n, S.ld);
+    S.active_conjugate();
+    hipLaunchKernelGGL(k_to_live, S.grid2, dim3(T), 0, S.s, S.x, S.live, n, S.ld);
+    (void)hipEventRecord(e1, S.s);
+    hipError_t e = hipStreamSynchronize(S.s);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e != hipSuccess || hipGetLastError() != hipSuccess) return fnn::fail(FNN_EHIP, std::string("fnn_split_weights_f64: ") + hipGetErrorString(e));
+    if (!SWOK(hipMemcpy(weights_out, S.live, sizeof(double) * (size_t)n * (n - 1) / 2, hipMemcpyDeviceToHost)))
+        return fnn::fail(FNN_EHIP, "fnn_split_weights_f64: download failed");
+    if (stats) {
+        stats->outer_iterations = S.st_outer;
+        stats->cg_calls = S.st_cg;
+        stats->cg_iterations = S.st_it;
+        stats->t_solve_s = ms * 1e-3;
+        int64_t pos = 0;
+        for (int64_t k = 0; k < (int64_t)n * (n - 1) / 2; k++) pos += weights_out[k] > 0.000001 ? 1 : 0;  // FastNN.java:455 threshold
+        stats->nsplits = pos;
+    }
+    return FNN_OK;
+}

@@ -6,6 +6,10 @@
 // stops at EOF or at the first line beyond numTaxa rows.
 #include "fastnn_host.hpp"
 
+#include <cmath>
+#include <cstdlib>
+#include <limits>
+
 #include <cctype>
 #include <cerrno>
 #include <cstdlib>
@@ -142,7 +146,127 @@ std::string orderingToString(const std::vector<int32_t>& o) {
 }  // namespace nnet
 
 // small C surface so the Python tests can exercise the reader without a GPU
+namespace nnet {
+
+std::string javaDoubleToString(double d) {
+    if (d != d) return "NaN";
+    if (d == std::numeric_limits<double>::infinity()) return "Infinity";
+    if (d == -std::numeric_limits<double>::infinity()) return "-Infinity";
+    if (d == 0.0) return std::signbit(d) ? "-0.0" : "0.0";
+    // shortest number of significant digits that reads back as the same double
+    char buf[64];
+    int prec = 1;
+    for (; prec <= 17; prec++) {
+        std::snprintf(buf, sizeof(buf), "%.*e", prec - 1, d);
+        if (std::strtod(buf, nullptr) == d) break;
+    }
+    std::string m(buf);
+    const size_t epos = m.find('e');
+    const int x = std::atoi(m.c_str() + epos + 1);
+    std::string digits;
+    bool neg = false;
+    for (size_t i = 0; i < epos; i++) {
+        if (m[i] == '-') neg = true;
+        else if (m[i] >= '0' && m[i] <= '9') digits.push_back(m[i]);
+    }
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    std::string out = neg ? "-" : "";
+    const double a = std::fabs(d);
+    if (a >= 1e-3 && a < 1e7) {
+        if (x >= 0) {
+            std::string ip = digits.substr(0, std::min(digits.size(), (size_t)x + 1));
+            while (ip.size() < (size_t)x + 1) ip.push_back('0');
+            std::string fp = digits.size() > (size_t)x + 1 ? digits.substr((size_t)x + 1) : "0";
+            out += ip + "." + fp;
+        } else {
+            out += "0." + std::string((size_t)(-x - 1), '0') + digits;
+        }
+    } else {
+        out += digits.substr(0, 1) + "." + (digits.size() > 1 ? digits.substr(1) : "0") + "E" + std::to_string(x);
+    }
+    return out;
+}
+
+std::vector<SplitAndWeight> splitsFromWeights(const std::vector<int32_t>& ordering, const double* weights, int nTaxa) {
+    std::vector<SplitAndWeight> splits;
+    const double optionThreshold = 0.000001;  // FastNN.java:455
+    int64_t index = 0;
+    for (int i = 0; i < nTaxa; i++) {
+        std::vector<char> member((size_t)nTaxa + 1, 0);
+        for (int j = i + 1; j < nTaxa; j++) {
+            member[(size_t)ordering[(size_t)j]] = 1;  // split.set(ordering[j]) (FastNN.java:415)
+            if (weights[index] > optionThreshold) {
+                SplitAndWeight saw;
+                saw.weight = weights[index];
+                for (int t = 0; t <= nTaxa; t++)
+                    if (member[(size_t)t]) saw.split.push_back(t);
+                splits.push_back(std::move(saw));
+            }
+            index++;
+        }
+    }
+    return splits;
+}
+
+void printNexusWithSplitsAndDistances(std::FILE* out, const std::vector<int32_t>& order, const DistancesAndNames& dan,
+                                      const std::vector<SplitAndWeight>& splits) {
+    const int ntax = dan.nTaxa;
+    std::fprintf(out, "#nexus\n\n");
+    // PrintTaxa (OutputPrinter.java:21-32)
+    std::fprintf(out, "BEGIN Taxa;\nDIMENSIONS ntax=%d;\nTAXLABELS\n", ntax);
+    for (int i = 0; i < ntax; i++) std::fprintf(out, "[%d] '%s'\n", i + 1, dan.names[(size_t)i].c_str());
+    std::fprintf(out, ";\nEND; [Taxa]\n\n");
+    // PrintDistances (:34-47)
+    std::fprintf(out, "BEGIN Distances;\nDIMENSIONS ntax=%d;\nFORMAT labels=no diagonal triangle=both;\nMATRIX\n", ntax);
+    for (int i = 0; i < ntax; i++) {
+        for (int j = 0; j < ntax; j++) std::fprintf(out, " %s", javaDoubleToString(dan.get(i, j)).c_str());
+        std::fprintf(out, "\n");
+    }
+    std::fprintf(out, ";\nEND; [Distances]\n\n");
+    // PrintSplits (:49-69), PrintSplit (:71-85)
+    std::fprintf(out, "BEGIN Splits;\nDIMENSIONS ntax=%d nsplits=%zu;\n", ntax, splits.size());
+    std::fprintf(out, "FORMAT labels=no weights=yes confidences=no intervals=no;\nPROPERTIES fit=-1.0 cyclic;\nCYCLE");
+    for (size_t i = 1; i < order.size(); i++) std::fprintf(out, " %d", order[i]);
+    std::fprintf(out, ";\nMATRIX\n");
+    int counter = 1;
+    for (const SplitAndWeight& saw : splits) {
+        int size = (int)saw.split.size();
+        if (ntax - size < size) size = ntax - size;
+        std::fprintf(out, "[%d, size=%d] \t %s \t ", counter, size, javaDoubleToString(saw.weight).c_str());
+        for (int32_t t : saw.split) std::fprintf(out, " %d", t);
+        std::fprintf(out, ",\n");
+        counter++;
+    }
+    std::fprintf(out, ";\nEND; [Splits]\n\n");
+    // PrintAssumptions (:87-96)
+    std::fprintf(out, "BEGIN st_Assumptions;\nuptodate;\ndisttransform=NeighborNet;\nsplitstransform=EqualAngle;\n");
+    std::fprintf(out, "SplitsPostProcess filter=dimension value=%d;\n exclude  no missing;\nautolayoutnodelabels;\nEND; [st_Assumptions]\n\n", ntax);
+}
+
+}  // namespace nnet
+
 extern "C" {
+// Double.toString of d into buf (>= 32 bytes); test hook
+void fnnh_java_double(double d, char* buf) { std::snprintf(buf, 32, "%s", nnet::javaDoubleToString(d).c_str()); }
+// Nexus document for (names, D, order, live-order weights) into the file `path`; test hook. Returns the number of splits or -1.
+int32_t fnnh_write_nexus(const char* path, int32_t n, const double* D, const char* names256, const int32_t* order, const double* weights) {
+    try {
+        nnet::DistancesAndNames dan;
+        dan.nTaxa = n;
+        dan.distances.resize((size_t)n * (size_t)(n - 1) / 2);
+        for (int i = 0; i < n; i++) {
+            dan.names.emplace_back(names256 + (size_t)i * 256);
+            for (int j = i + 1; j < n; j++) dan.distances[(size_t)dan.upperIndex(i, j)] = D[(size_t)i * (size_t)n + (size_t)j];
+        }
+        std::vector<int32_t> ord(order, order + n + 1);
+        auto splits = nnet::splitsFromWeights(ord, weights, n);
+        std::FILE* f = std::fopen(path, "w");
+        if (!f) return -1;
+        nnet::printNexusWithSplitsAndDistances(f, ord, dan, splits);
+        std::fclose(f);
+        return (int32_t)splits.size();
+    } catch (...) { return -1; }
+}
 int32_t fnnh_read_taxa_count(const char* path) {
     try { return nnet::readTaxaCount(path); } catch (...) { return -1; }
 }

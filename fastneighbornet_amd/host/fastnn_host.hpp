@@ -12,6 +12,7 @@
 #define FASTNN_HOST_HPP
 
 #include <cstdint>
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -90,6 +91,25 @@ class NeighborNetCanonical : public NetMakerOriginal {
   private:
     int device;
 };
+
+// SplitAndWeight (CircularSplitWeights.java:47-50): the BitSet as the ascending list of its set bits
+// (1-based taxon ids)
+struct SplitAndWeight {
+    std::vector<int32_t> split;
+    double weight = 0.0;
+};
+
+// Double.toString semantics (shortest digits that round-trip; plain decimals for 1e-3 <= |d| < 1e7,
+// otherwise d.dddE[-]x), as the reference's string concatenations print distances and weights
+std::string javaDoubleToString(double d);
+
+// the live path's split list (FastNN.java:405-419, :455-466) from the weights in live index order:
+// split k = (i, j), 0 <= i < j <= n-1 = taxa ordering[i+1 .. j]; kept if weight > 1e-6
+std::vector<SplitAndWeight> splitsFromWeights(const std::vector<int32_t>& ordering, const double* weights, int nTaxa);
+
+// OutputPrinter.NexusWithSplitsAndDistances (OutputPrinter.java:8-96), written to `out`
+void printNexusWithSplitsAndDistances(std::FILE* out, const std::vector<int32_t>& order, const DistancesAndNames& dan,
+                                      const std::vector<SplitAndWeight>& splits);
 
 }  // namespace nnet
 #endif

@@ -3,9 +3,10 @@
 // -order -additive -time -help, banner and progress lines on stderr, the circular order as
 // Arrays.toString on stdout with -order.
 //
-// Not built yet (SURVEY.md section 8(f) "next"): the split-weight / Nexus output of a run
-// without -order (FastNN.java:401-540) and the non-Canonical modes; both end with a message
-// and exit status 2 instead of silently doing something else.
+// A run without -order continues as FastNN.java:401-540 does: non-negative least-squares weights of
+// the circular splits (on the GPU, fnn_split_weights_f64: CircularSplitWeights.java's method) and
+// the Nexus document on stdout (OutputPrinter.java).  Not provided: the non-Canonical modes (a
+// message and exit status 2 instead of silently doing something else).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -113,10 +114,24 @@ int main(int argc, char** argv) {
             std::printf("%s\n", nnet::orderingToString(ordering).c_str());
             return 0;
         }
-        std::fprintf(stderr,
-                     "fastnn-mi355x: split weights and the Nexus document (a run without -order) are not built yet; "
-                     "use -order.\n");
-        return 2;
+        // FastNN.java:398-491: split weights, then the Nexus document (the reference parses the file a
+        // second time for the names and distances, FastNN.java:438)
+        t0 = std::chrono::steady_clock::now();
+        std::vector<double> weights((size_t)nTaxa * (size_t)(nTaxa - 1) / 2);
+        fnn_sw_stats sw{};
+        if (nTaxa >= 2) {
+            int32_t rc = fnn_split_weights_f64(D.data(), nTaxa, nTaxa, ordering.data(), device, weights.data(), &sw);
+            if (rc != FNN_OK) throw std::runtime_error(std::string("fastnn: ") + fnn_last_error());
+        }
+        const nnet::DistancesAndNames dan(fileName, nTaxa);
+        std::vector<nnet::SplitAndWeight> splits = nnet::splitsFromWeights(ordering, weights.data(), nTaxa);
+        t1 = std::chrono::steady_clock::now();
+        if (timeMe) std::fprintf(stderr, "Got the splits and weights in (s): %.9g\n", std::chrono::duration<double>(t1 - t0).count());
+        t0 = std::chrono::steady_clock::now();
+        nnet::printNexusWithSplitsAndDistances(stdout, ordering, dan, splits);
+        t1 = std::chrono::steady_clock::now();
+        if (timeMe) std::fprintf(stderr, "Wrote the output in (s): %.9g\n", std::chrono::duration<double>(t1 - t0).count());
+        return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "Exception in thread \"main\" %s\n", e.what());
         return 1;

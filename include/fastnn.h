@@ -194,6 +194,26 @@ int32_t fnn_comm_unique_id(uint8_t* id_out, const char* rccl_path);
 int32_t fnn_comm_init_rccl(fnn_handle* h, int32_t world, int32_t rank, const uint8_t* id, const char* rccl_path);
 int32_t fnn_comm_init_host(fnn_handle* h, int32_t world, int32_t rank, fnn_allgather_fn fn, void* ctx);
 
+/* ---- circular split weights ------------------------------------------------
+ * Non-negative least-squares weights of the n(n-1)/2 circular splits of `ordering` (the array
+ * fnn_run returns: n + 1 entries, [1..n] = 1-based taxon ids in circular order) for the symmetric
+ * n x n distances D (host memory, row stride ld).  Algorithm of CircularSplitWeights.java
+ * (active-set method around a conjugate-gradient solve with the implicit operators A b, A^T y;
+ * Chepoi-Fichet start) with the re-ordering of the distances restored; weights_out has n(n-1)/2
+ * entries in the index order of the reference's live path (FastNN.java:405-419): k runs over
+ * (i, j), 0 <= i < j <= n-1, row-major, split k = taxa ordering[i+1 .. j] against the rest.  The
+ * reference keeps the splits with weight > 1e-6 (FastNN.java:455). */
+typedef struct fnn_sw_stats {
+    int64_t outer_iterations; /* passes of the active-set loop (a constraint is released per pass) */
+    int64_t cg_calls;         /* conjugate-gradient solves */
+    int64_t cg_iterations;    /* ... and their iterations (each applies A and A^T once) */
+    int64_t nsplits;          /* weights above 1e-6 */
+    double  t_solve_s;        /* device time from the re-ordered distances to the weights */
+    int64_t reserved[3];
+} fnn_sw_stats;
+int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ld, const int32_t* ordering, int32_t device,
+                              double* weights_out, fnn_sw_stats* stats);
+
 /* Diagnostic: the exact block-parallel evaluation of the sequential fp64 sum
  * (((0 + b[0]) + b[1]) + ...) used for ComputeRx / u.Sx (NetMakerOriginal.java:551-560,
  * :532), run on an arbitrary host buffer.  ept = addends per thread (32, fixed by the

@@ -106,3 +106,66 @@ def test_cli_config0_64_taxa_phylip(oracle, tmp_path):
     assert r.returncode == 0, r.stderr
     assert r.stdout == "[" + ", ".join(str(int(v)) for v in o_ref) + "]\n"
     assert "Got the order in (s): " in r.stderr
+    # without -order: split weights on the GPU + the Nexus document (FastNN.java:398-491)
+    from oracle import csw_oracle as W
+    w_ref, _ = W.split_weights(D, o_ref)
+    r = subprocess.run([exe, "-distFile", p, "-mode", "Canonical", "-time"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Got the splits and weights in (s): " in r.stderr and "Wrote the output in (s): " in r.stderr
+    txt = r.stdout.split("\n")
+    assert txt[0] == "#nexus" and "BEGIN Splits;" in txt
+    i = txt.index("BEGIN Splits;")
+    ns = int(txt[i + 1].split("nsplits=")[1].rstrip(";"))
+    assert abs(ns - int((w_ref > 1e-6).sum())) <= 1
+    assert txt[i + 4] == "CYCLE " + " ".join(str(int(t)) for t in o_ref[1:]) + ";"
+    weights = sorted(float(line.split(" \t ")[1]) for line in txt[i + 6: i + 6 + ns])
+    ref_sorted = sorted(float(x) for x in w_ref[w_ref > 1e-6])
+    if len(weights) == len(ref_sorted):
+        assert np.allclose(weights, ref_sorted, rtol=0, atol=2e-6)
+
+
+def test_java_double_formatting_and_nexus_document(hostlib, oracle, tmp_path):
+    """N2 (OutputPrinter.java:8-96): number formatting follows Double.toString, the document follows
+    the reference's block order; splits come from the live-order weights with the 1e-6 threshold."""
+    hostlib.fnnh_java_double.argtypes = [C.c_double, C.c_char_p]
+    def jd(x):
+        b = C.create_string_buffer(32)
+        hostlib.fnnh_java_double(x, b)
+        return b.value.decode()
+    for x, s in [(1.0, "1.0"), (0.001, "0.001"), (1e-4, "1.0E-4"), (1e7, "1.0E7"), (9999999.999, "9999999.999"),
+                 (123456.789, "123456.789"), (0.1 + 0.2, "0.30000000000000004"), (1e21, "1.0E21"), (1.234e-5, "1.234E-5"),
+                 (100.0, "100.0"), (0.0, "0.0"), (-2.5, "-2.5"), (2.0 ** -10, "9.765625E-4"), (1 / 3, "0.3333333333333333"),
+                 (float("nan"), "NaN"), (float("inf"), "Infinity"), (12345678.0, "1.2345678E7")]:
+        assert jd(x) == s, (x, jd(x), s)
+    from oracle import csw_oracle as W
+    n = 7
+    D = oracle.synth(n, 3)
+    order, _, _ = oracle.run(D)
+    w, _ = W.split_weights(D, order)
+    names = b"".join((f"tax on{i + 1}".encode()).ljust(256, b"\0") for i in range(n))
+    hostlib.fnnh_write_nexus.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.c_char_p, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_double)]
+    p = str(tmp_path / "out.nex")
+    ns = hostlib.fnnh_write_nexus(p.encode(), n, D.ctypes.data_as(C.POINTER(C.c_double)), names,
+                                  order.ctypes.data_as(C.POINTER(C.c_int32)), w.ctypes.data_as(C.POINTER(C.c_double)))
+    assert ns == int((w > 1e-6).sum())
+    txt = open(p).read().split("\n")
+    assert txt[0] == "#nexus" and txt[1] == "" and txt[2] == "BEGIN Taxa;" and txt[3] == f"DIMENSIONS ntax={n};"
+    assert txt[5] == "[1] 'tax on1'"
+    i = txt.index("BEGIN Distances;")
+    assert txt[i + 2] == "FORMAT labels=no diagonal triangle=both;" and txt[i + 3] == "MATRIX"
+    row0 = txt[i + 4].split(" ")
+    assert row0[0] == "" and row0[1] == "0.0" and float(row0[2]) == D[0, 1] and len(row0) == n + 1
+    i = txt.index("BEGIN Splits;")
+    assert txt[i + 1] == f"DIMENSIONS ntax={n} nsplits={ns};"
+    assert txt[i + 4] == "CYCLE " + " ".join(str(int(t)) for t in order[1:]) + ";"
+    first = txt[i + 6]
+    assert first.startswith("[1, size=") and first.endswith(",") and " \t " in first
+    # every split line lists a contiguous arc of the cycle that avoids ordering[n]
+    pos = {int(t): k for k, t in enumerate(order[1:])}
+    for line in txt[i + 6: i + 6 + ns]:
+        taxa = [int(t) for t in line.split(" \t ")[2].rstrip(",").split()]
+        ks = sorted(pos[t] for t in taxa)
+        assert ks == list(range(ks[0], ks[0] + len(ks))) and int(order[n]) not in taxa
+        assert taxa == sorted(taxa)
+    assert txt[-3] == "END; [st_Assumptions]" and txt[-2] == "" and txt[-1] == ""
