@@ -91,7 +91,7 @@ class Engine {
             !(dev.cstamp = (int32_t*)be.alloc(sizeof(int32_t) * (3 * nn + 8))) ||
             !(dev.tpairs = (int32_t*)be.alloc(sizeof(int32_t) * 4 * LA_PCAP)) ||
             !(dev.fresh = (int32_t*)be.alloc(sizeof(int32_t) * 2 * LA_KMAX)) ||
-            !(dev.ticket = (uint32_t*)be.alloc(sizeof(uint32_t) * 32 * 66)) ||
+            !(dev.ticket = (uint32_t*)be.alloc(sizeof(uint32_t) * 32 * 72)) ||
             !(dev.lacnt = (int32_t*)be.alloc(256)) ||
             !(dev.lalog = (double*)be.alloc(sizeof(double) * 5 * LA_LOGCAP)) ||
             !(dev.upart = (double*)be.alloc(sizeof(double) * 2 * 64)) ||
@@ -199,7 +199,7 @@ class Engine {
             return fail(FNN_EHIP, "fnn_begin: state upload failed (" + be.err() + ")");
         if (be.memset(dev.islot, 0xFF, sizeof(int32_t) * (3 * (size_t)(n > 0 ? n : 1) + 8)) != FNN_OK ||
             be.memset(dev.cstamp, 0, sizeof(int32_t) * (3 * (size_t)(n > 0 ? n : 1) + 8)) != FNN_OK ||
-            be.memset(dev.ticket, 0, sizeof(uint32_t) * 32 * 66) != FNN_OK || be.memset(dev.lacnt, 0, 256) != FNN_OK)
+            be.memset(dev.ticket, 0, sizeof(uint32_t) * 32 * 72) != FNN_OK || be.memset(dev.lacnt, 0, 256) != FNN_OK)
             return fail(FNN_EHIP, "fnn_begin: memset failed (" + be.err() + ")");
         if (n > 3) {
             if (dev.H && be.launch_prep_screen(dev, nrows) != FNN_OK)
