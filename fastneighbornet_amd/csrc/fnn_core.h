@@ -529,7 +529,7 @@ FNN_HD void la_close_base(State& st, double* lalog, const int32_t* lacnt) {
     st.la_prev_end = 0;
     if (cnt > st.la_pcap) {  // too many pairs under the threshold: narrower next time, and back off
         st.n_la_overflow++;
-        st.la_W *= 0.6;
+        st.la_W *= 0.85;
         st.la_backoff = st.la_backoff < 1 ? 1 : (st.la_backoff >= 512 ? 1024 : 2 * st.la_backoff);
         st.la_skip = st.la_backoff;
         return;
@@ -545,10 +545,12 @@ FNN_HD void la_close_base(State& st, double* lalog, const int32_t* lacnt) {
     st.la_coef = (double)st.c - 2.0 - (double)st.la_K;
     if (st.la_coef < 0.0) st.la_coef = 0.0;
     st.la_pairs_sum += cnt;
-    // width for the next window: wide enough to last its K events, narrow enough for the list
-    if (prev_end == 2) st.la_W *= 0.7;
-    else if (prev_end == 1 && cnt < st.la_pcap / 2) st.la_W *= 1.25;
-    else if (cnt > st.la_target) st.la_W *= 0.9;
+    // width for the next window: wide enough to last its K events, narrow enough for the list.  The
+    // number of pairs under the threshold grows very steeply with the width (x 30 for + 25 %), so
+    // the steps are small
+    if (prev_end == 2) st.la_W *= 0.85;
+    else if (prev_end == 1 && cnt < st.la_pcap / 2) st.la_W *= 1.1;
+    else if (cnt > st.la_target) st.la_W *= 0.95;
     const double wmin = 1e-6 * dmax + 1e-300, wmax = 1e12 * dmax + 1e-300;
     if (!(st.la_W >= wmin)) st.la_W = wmin;
     if (st.la_W > wmax) st.la_W = wmax;

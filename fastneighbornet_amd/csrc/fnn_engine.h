@@ -178,7 +178,11 @@ class Engine {
         hst.force_exact_rx = opts.force_exact_rx ? 1 : 0;
         // lookahead windows (fnn_core.h "Lookahead"): single rank with a screening copy
         {
-            int32_t K = opts.lookahead < 0 ? 0 : (opts.lookahead > 0 ? opts.lookahead : 48);
+            // default window length: 16 + n / 1024 events (48 at n = 32768; shorter windows for smaller problems, whose
+            // minima move faster relative to the spread of Q - measured optimum at 8192 / 16384 / 32768 taxa)
+            int32_t Kdef = 16 + n / 1024;
+            if (Kdef > 64) Kdef = 64;
+            int32_t K = opts.lookahead < 0 ? 0 : (opts.lookahead > 0 ? opts.lookahead : Kdef);
             int32_t target = opts.lookahead_pairs > 0 ? opts.lookahead_pairs : 32768;
             if (const char* e = std::getenv("FNN_LA_K")) K = std::atoi(e);
             if (const char* e = std::getenv("FNN_LA_TARGET")) target = std::atoi(e);

@@ -1677,7 +1677,7 @@ struct HipBackend {
     static constexpr int64_t kColPad = SCR_TW;   // whole screening tiles (and scan tiles) stay in bounds
     // below this many taxa the fp32 copy is not even allocated (FNN_SCREEN_MIN_N, tests)
     int32_t screen_min_n() const { if (const char* e = std::getenv("FNN_SCREEN_MIN_N")) { int v = std::atoi(e); if (v >= 8) return v; } return 8192; }
-    int screen_min_m = 8192;                     // events with fewer live nodes use the plain scan (FNN_SCREEN_MIN_M)
+    int screen_min_m = 4096;                     // events with fewer live nodes use the plain scan (FNN_SCREEN_MIN_M)
     hipError_t last = hipSuccess;
     hipStream_t stream = nullptr;
     int device = 0;

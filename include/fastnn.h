@@ -58,7 +58,7 @@ typedef struct fnn_opts {
                               find, within a rigorous error bound, the few tile units that can hold
                               the minimum, and only those are rescanned in fp64 (same result) */
     int32_t lookahead;     /* events one screening pass may serve ("lookahead window"): 0 = default
-                              (48), < 0 = off (every event scans), > 0 = that many; same result either way */
+                              (16 + n / 1024, at most 64), < 0 = off (every event scans), > 0 = that many; same result either way */
     int32_t lookahead_pairs;/* wanted number of tracked pairs per window (0 = default 32768) */
     int32_t reserved[9];
 } fnn_opts;
