@@ -103,7 +103,8 @@ struct State {
     int32_t ev_screened, pad_scr2;
     // ---- lookahead window (see "Lookahead" below) ----
     int32_t la_on;          // configured: windows enabled (single rank, screening copy present)
-    int32_t la_K;           // events one window may serve
+    int32_t la_K;           // events one window may serve (upper limit)
+    int32_t la_Kcur;        // ... the open / opening window: min(la_K, 16 + m / 1024) at its base scan
     int32_t la_target;      // wanted number of tracked pairs per window
     int32_t la_min_m;       // windows only while m >= la_min_m (the screened regime)
     int32_t la_valid;       // a window is open
@@ -345,7 +346,7 @@ FNN_HD float screen_cm2k(const State& st) { return (float)(((double)st.c - 2.0) 
 // windows on, the lower bound uses (c - 2 - K) instead of (c - 2): it then also bounds the pair's
 // Q in each of the next K events (see "Lookahead" below); it is merely a little looser now.
 FNN_HD float screen_k1(const State& st) {
-    double cc = (double)st.c - 2.0 - (st.la_on ? (double)st.la_K : 0.0);
+    double cc = (double)st.c - 2.0 - (st.la_on ? (double)st.la_Kcur : 0.0);
     if (cc < 0.0) cc = 0.0;
     return (float)((cc * (1.0 - (double)SCR_KAPPA * 1.000001)) * (1.0 - 2e-7));
 }
@@ -492,7 +493,7 @@ FNN_HD double la_delta(const State& st) {
 
 // does k_track serve this event from the open window?
 FNN_HD bool la_active(const State& st) {
-    return st.la_on && st.la_valid && !st.done && st.la_k <= st.la_K && st.la_nf <= LA_KMAX && st.m >= st.la_min_m &&
+    return st.la_on && st.la_valid && !st.done && st.la_k <= st.la_Kcur && st.la_nf <= LA_KMAX && st.m >= st.la_min_m &&
            st.m > 4;
 }
 
@@ -502,6 +503,7 @@ FNN_HD void la_prepare_base(State& st, int32_t* lacnt) {
     if (st.la_valid) st.la_k_prev = st.la_k;
     st.la_valid = 0;
     st.la_emit = 0;
+    st.la_Kcur = 16 + st.m / 1024 < st.la_K ? 16 + st.m / 1024 : st.la_K;  // shorter windows as the problem shrinks
     *lacnt = 0;
     if (st.la_on && st.nonneg && st.screen_ok && !st.done && st.m >= st.la_min_m) {
         if (st.la_skip > 0) st.la_skip--;
@@ -542,7 +544,7 @@ FNN_HD void la_close_base(State& st, double* lalog, const int32_t* lacnt) {
     st.la_nf_done = 0;
     st.la_base_stamp = (int32_t)st.n_events;
     st.la_theta_eff = (double)st.la_theta_pred - la_delta(st);
-    st.la_coef = (double)st.c - 2.0 - (double)st.la_K;
+    st.la_coef = (double)st.c - 2.0 - (double)st.la_Kcur;
     if (st.la_coef < 0.0) st.la_coef = 0.0;
     st.la_pairs_sum += cnt;
     // width for the next window: wide enough to last its K events, narrow enough for the list.  The

@@ -182,6 +182,7 @@ class Engine {
             // minima move faster relative to the spread of Q - measured optimum at 8192 / 16384 / 32768 taxa)
             int32_t Kdef = 16 + n / 1024;
             if (Kdef > 64) Kdef = 64;
+            hst.la_Kcur = 0;
             int32_t K = opts.lookahead < 0 ? 0 : (opts.lookahead > 0 ? opts.lookahead : Kdef);
             int32_t target = opts.lookahead_pairs > 0 ? opts.lookahead_pairs : 32768;
             if (const char* e = std::getenv("FNN_LA_K")) K = std::atoi(e);
@@ -239,7 +240,7 @@ class Engine {
     // after a state download: when will the open window have served its K events?
     void resync_schedule() {
         if (!dev.la) return;
-        sched_at = (hst.la_valid && !hst.stall) ? ev_counter + (hst.la_K + 1 > hst.la_k ? hst.la_K + 1 - hst.la_k : 0) : ev_counter;
+        sched_at = (hst.la_valid && !hst.stall) ? ev_counter + (hst.la_Kcur + 1 > hst.la_k ? hst.la_Kcur + 1 - hst.la_k : 0) : ev_counter;
     }
     // A rank contributes nper candidate records (1 after a local reduction, or the scan's
     // GATHER_RECS per-workgroup records as they are).
@@ -251,7 +252,7 @@ class Engine {
         const int64_t cnt = ev_counter++;
         bool sched = !dev.la || cnt <= 1 || cnt >= sched_at;
         if (force_sched >= 0) sched = force_sched != 0;
-        if (sched) sched_at = cnt + hst.la_K + 1;
+        if (sched) sched_at = cnt + (hst.la_Kcur > 0 ? hst.la_Kcur : hst.la_K) + 1;
         if (comm_mode == 0) return be.launch_event(dev, m_bound, sched) == FNN_OK ? FNN_OK : fail(FNN_EHIP, "launch failed (" + be.err() + ")");
         int32_t nper = 1;
         if (be.launch_event_scan(dev, m_bound, &nper) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
