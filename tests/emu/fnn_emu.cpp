@@ -242,7 +242,35 @@ struct EmuBackend {
         }
         return best;
     }
-    int32_t launch_event(const fnn::Dev& d, int32_t m_bound, bool sched) { return event_rest(d, m_bound, scan_local(d, sched)); }
+    // Same launch-sequence semantics as the GPU backend: an unscheduled event of the screened regime
+    // carries no scan kernels; if its window cannot serve it, it stalls (this and the following such
+    // sequences do nothing) until the host launches an event with a scan.
+    int32_t launch_event(const fnn::Dev& d, int32_t m_bound, bool sched) {
+        fnn::State& st = *d.st;
+        const bool screen = d.H && m_bound >= screen_min_m;
+        const bool has_scan = sched || !screen;
+        if (has_scan) {
+            if (!st.done) st.stall = 0;
+            return event_rest(d, m_bound, scan_local(d, sched));
+        }
+        if (st.done) return FNN_OK;
+        if (st.stall) { st.n_stalled++; return FNN_OK; }
+        if (fnn::la_active(st)) {
+            fnn::Cand tb;
+            tb.q = fnn::inf_f64();
+            tb.key = ~0ULL;
+            const fnn::TrackArgs ta = fnn::track_args(st);
+            for (int32_t it : thread_order((int32_t)fnn::track_item_count(ta))) fnn::track_item(d, it, ta, tb);
+            fnn::la_track_done(d, tb, ta);
+            if (st.la_hit) return event_rest(d, m_bound, d.recs[0]);
+        } else {
+            if (st.la_valid) st.la_prev_end = 0;
+            fnn::la_prepare_base(st, d.lacnt);
+        }
+        st.stall = 1;
+        st.n_stalled++;
+        return FNN_OK;
+    }
     int32_t launch_event_scan(const fnn::Dev& d, int32_t, int32_t* nper) {
         // contribute 3 records (the real one plus two "none") to exercise the multi-record exchange
         fnn::Cand none;

@@ -133,7 +133,7 @@ def test_lookahead_windows_keep_the_exact_result(emu_api, oracle, monkeypatch):
     cases = [(oracle.synth(n, seed, dist), every) for n, seed, dist, every in
              [(9, 1, "uniform53", 1), (33, 2, "dec4", 1), (64, 3, "uniform53", 1), (131, 4, "uniform53", 3),
               (200, 5, "dec4", 7), (330, 6, "uniform53", 17)]] + [(two, 3), (neg, 3), (np.ones((40, 40)) - np.eye(40), 1)]
-    total_hits = total_fails = 0
+    total_hits = total_fails = total_stalled = 0
     for K, target, pcap, mode in [(1, 8192, 0, 0), (3, 4, 0, 2), (8, 64, 0, 4), (64, 8192, 0, 8), (64, 1, 0, 1),
                                   (512, 8192, 0, 5), (16, 8192, 7, 2), (64, 65536, 300, 6)]:
         if pcap:
@@ -156,7 +156,10 @@ def test_lookahead_windows_keep_the_exact_result(emu_api, oracle, monkeypatch):
         assert st.n_events - 8 <= st.n_base_scans + st.n_window_hits <= st.n_events
         total_hits += st.n_window_hits
         total_fails += st.n_window_fails
-    assert total_hits > 500 and total_fails > 0
+        total_stalled += st.n_stalled_events
+    # windows were used, some could not certify their event, and launch sequences without scan kernels
+    # that found their window gone stalled until the host relaunched with a scan
+    assert total_hits > 500 and total_fails > 0 and total_stalled > 0
     # negative entries: the monotonicity argument does not hold, windows stay closed
     with Handle(emu_api, 60) as h:
         h.set_matrix(neg)
