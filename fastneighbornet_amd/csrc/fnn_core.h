@@ -1,7 +1,7 @@
 // fnn_core.h -- per-thread bodies of the Canonical Neighbor-Net engine.
 //
 // Everything here is a __host__ __device__ function over plain pointers: the HIP
-// kernels in fnn_kernels.hip are thin wrappers that map (block, thread) to the
+// kernels in fnn_hip.hip are thin wrappers that map (block, thread) to the
 // arguments of these bodies, and tests/emu/fnn_emu.cpp drives the SAME bodies in
 // loops on the CPU so that the slot bookkeeping can be checked against the oracle
 // without a GPU.  The emulation driver is test infrastructure; the product path

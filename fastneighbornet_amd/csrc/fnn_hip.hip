@@ -4,23 +4,28 @@
 // (-ffp-contract=off on host AND device: every fp64 operation of the path is
 // rounded once, in the reference's source order; no FMA anywhere).
 //
-// Kernel inventory (one agglomeration event = the fixed launch sequence of
-// HipBackend::launch_event; all control state lives in device memory so the host
-// never has to wait for a decision):
+// Kernel inventory (one agglomeration event = a fixed launch sequence of HipBackend::launch_event;
+// all control state lives in device memory so the host never has to wait for a decision):
+//   k_track     lookahead windows (fnn_core.h "Lookahead"): the event's minimum from the tracked pairs
+//               + one sweep of the newest cluster's rows, exact fp64, when the open window can certify
+//               it (no scan then); workgroup 0 computes the previous event's exact u.Sx beside it
 //   k_scan      all-pairs Q-criterion argmin over the lower triangle of the live
 //               m x m block (NeighborNetCanonical.java:151-178).  HBM-bound: reads
 //               each live matrix entry once, 16 B per lane, 1 KiB per wave-load.
-//   k_screen    events with >= 8192 live nodes: the same scan as a bracketing pass over the bf16
-//               copy of the matrix (2 B per entry); k_resolve: exact fp64 rescan of the few
-//               32 x 512 units that can hold the minimum
+//   k_screen    events with >= 4096 live nodes that scan: the same scan as a bracketing pass over the
+//               bf16 copy of the matrix (2 B per entry); k_emit: the pairs a new window tracks;
+//               k_resolve: exact fp64 rescan of the few 32 x 512 units that can hold the minimum
 //   k_rx_fill   reduce the per-block records, form Cx/Cy (NetMakerOriginal.java:376-380); ComputeRx
 //               terms in reference position order (:549-561) + tree partial sums
 //   k_decide4   candidate choice (:413-452) certified from the partial sums, else from the <=4
 //               exact sequential Rx sums; merge plan (:462-488)
 //   k_update    fused: subtractClusterDistance x2 per node (:455-461, 681-696), the net effect of
 //               the plan's micro-ops (agg3way row/column rewrite :653-656, slot swaps / moves)
-//               and updateClusterDistances' per-node part (:520-531)
-//   k_finalize  exact sequential u.Sx sum (:532), event log, loop condition (:339)
+//               and updateClusterDistances' per-node part (:520-531); closes the event when the
+//               exact u.Sx sum is deferred to the next k_track
+//   k_finalize  exact sequential u.Sx sum (:532), event log, loop condition (:339) - stepping API and
+//               configurations without windows; k_chain_flush: a deferred sum before the host looks
+//   k_events    experimental persistent kernel for window events (off by default)
 // Several GPUs: every rank scans 1/world of the tiles; the candidate records are all-gathered
 // (k_reduce_local + ncclAllGather) between the scan and k_rx_fill.
 #include <hip/hip_runtime.h>
