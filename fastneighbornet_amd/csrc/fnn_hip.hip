@@ -883,10 +883,12 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
                     const int e = __builtin_ctzll(endmask);
                     endmask &= endmask - 1;
                     const int fe = readlane_i32(rf, e);
+                    if (stop_after == 4) { s += (double)fe; prev_end = e; continue; }  // diagnostic: loop structure only
                     if (fe & 1) {
                         Mono mr;
                         mr.i0 = u2f(readlane_u64(rs0, e));
                         mr.i1 = u2f(readlane_u64(rs1, e));
+                        if (stop_after == 5) { s += mr.i0; prev_end = e; continue; }  // diagnostic: no mono_apply, no mixed adds
                         if (mono_apply(s, readlane_i32(rE, e), mr)) cs.runs++;
                         else {
                             cs.run_fail++;
@@ -902,11 +904,14 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
                         }
                     } else {
                         cs.mixed++;
+                        if (stop_after == 5) { prev_end = e; continue; }
                         const int sl = readlane_i32(rslot, e);
                         if (sl >= 0) {
-                            const uint64_t v = f2u(lane < EPT ? L.vals[sl][lane] : 0.0);
+                            // (every lane adds the same parked addends in order: LDS broadcast reads, which
+                            //  pipeline under the dependent additions - no cross-lane traffic)
+                            const double* pv = L.vals[sl];
 #pragma unroll
-                            for (int j = 0; j < EPT; j++) s += u2f(readlane_u64(v, j));
+                            for (int j = 0; j < EPT; j++) s += pv[j];
                         } else chain_serial_global(s, buf, first + e * EPT, EPT, m);
                     }
                     prev_end = e;

@@ -9,7 +9,7 @@ os.environ["FNN_CHAIN_TIME"] = "1"
 rng = np.random.default_rng(1)
 for m in (4096, 16384, 32768):
     v = rng.random(m) + 2.0**-10
-    for stop in (1, 2, 3, 0):
+    for stop in (1, 2, 3, 4, 5, 0):
         os.environ["FNN_CHAIN_STOP"] = str(stop)
         out = C.c_double(); st = (C.c_int32 * 4)()
         print(f"m={m} stop_after={stop}:", flush=True)
