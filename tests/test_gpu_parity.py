@@ -273,3 +273,21 @@ def test_screened_run_against_the_oracle(hip_api, oracle):
     for f in ("m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id", "entries"):
         assert (ev[f] == ev_ref[f]).all(), f
     assert (bits(ev["best"]) == bits(ev_ref["best"])).all()
+
+
+@pytest.mark.parametrize("n,seed,dist", [(8448, 22, "dec4")])
+def test_window_runs_against_the_oracle(hip_api, oracle, n, seed, dist):
+    """Lookahead windows at sizes where they serve most events (and, with the 4-decimal input, under
+    exact ties of Q): the whole trajectory must equal the oracle's."""
+    D = oracle.synth(n, seed, dist)
+    o_ref, ev_ref, se = oracle.run(D, threads=16)
+    with Handle(hip_api, n, record_events=True) as h:
+        h.set_matrix(D, chunk_rows=2048)
+        order, st = h.run()
+        ev = h.events()
+    assert (order == o_ref).all()
+    assert st.sum_entries == se and st.n_events == len(ev_ref)
+    for f in ("m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id", "entries"):
+        assert (ev[f] == ev_ref[f]).all(), f
+    assert (bits(ev["best"]) == bits(ev_ref["best"])).all()
+    assert st.n_window_hits + st.n_base_scans >= st.n_events - 4096 - 8
