@@ -1167,18 +1167,22 @@ __device__ __forceinline__ void decide4_body(const Dev& d, int nparts, ChainLds<
     double rxa[4] = {0.0, 0.0, 0.0, 0.0};
     int certified = 1;
     if (need_rx) {
-        if (threadIdx.x < 64) {  // sum the partials of k_rx_fill (<= 128 x 8 doubles)
-            double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int b = threadIdx.x; b < nparts; b += 64)
-#pragma unroll
-                for (int k = 0; k < 8; k++) v[k] += d.rxpart[(size_t)b * 8 + k];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1)
-#pragma unroll
-                for (int k = 0; k < 8; k++) v[k] += __shfl_down(v[k], off, 64);
-            if (threadIdx.x == 0) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) red[k] = v[k];
+        {   // sum the partials of k_rx_fill ([workgroup][8] doubles): one load per thread, all in flight
+            // at once (any summation order will do: the sums are only certified, not used as exact)
+            __shared__ double wred[CH_T / 64][8];
+            double v = 0.0;
+            for (int idx = threadIdx.x; idx < nparts * 8; idx += CH_T) v += d.rxpart[idx];
+            // lanes l, l + 8, l + 16, ... of a wave hold the same component k = l & 7
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int lane_ = threadIdx.x & 63, w_ = threadIdx.x >> 6;
+            if (lane_ < 8) wred[w_][lane_] = v;
+            __syncthreads();
+            if (threadIdx.x < 8) {
+                double acc = 0.0;
+                for (int q = 0; q < CH_T / 64; q++) acc += wred[q][threadIdx.x];
+                red[threadIdx.x] = acc;
             }
         }
         __syncthreads();
