@@ -52,3 +52,31 @@ def check_order(order, n):
     if n >= 1:
         assert order[1] == 1
     assert sorted(order[1:].tolist()) == list(range(1, n + 1))
+
+
+def tree_metric(n, seed):
+    """Additive tree metric with dyadic branch lengths (path sums exact -> exact ties of the Q criterion)."""
+    r = np.random.default_rng(seed)
+    parent = [-1]; blen = [0.0]
+    leaves = [0]
+    while len(leaves) < n:                      # split a random leaf into two
+        v = leaves.pop(int(r.integers(len(leaves))))
+        for _ in range(2):
+            parent.append(v); blen.append(float(r.integers(1, 64)) / 64.0); leaves.append(len(parent) - 1)
+    def path(v):
+        out = []
+        while v >= 0:
+            out.append(v); v = parent[v]
+        return out
+    P = [path(v) for v in leaves]
+    D = np.zeros((n, n))
+    for i in range(n):
+        si = set(P[i]); di = {v: sum(blen[u] for u in P[i][:k]) for k, v in enumerate(P[i])}
+        for j in range(i + 1, n):
+            dj = 0.0
+            for v in P[j]:
+                if v in si:
+                    D[i, j] = D[j, i] = di[v] + dj
+                    break
+                dj += blen[v]
+    return D

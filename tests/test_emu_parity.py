@@ -5,7 +5,7 @@ shuffled order exposes order dependence (= races on the GPU)."""
 import numpy as np
 import pytest
 
-from common import check_order, compare_trajectory
+from common import check_order, compare_trajectory, tree_metric
 from fastneighbornet_amd._capi import Handle
 
 
@@ -132,7 +132,7 @@ def test_lookahead_windows_keep_the_exact_result(emu_api, oracle, monkeypatch):
     np.fill_diagonal(neg, 0.0)
     cases = [(oracle.synth(n, seed, dist), every) for n, seed, dist, every in
              [(9, 1, "uniform53", 1), (33, 2, "dec4", 1), (64, 3, "uniform53", 1), (131, 4, "uniform53", 3),
-              (200, 5, "dec4", 7), (330, 6, "uniform53", 17)]] + [(two, 3), (neg, 3), (np.ones((40, 40)) - np.eye(40), 1)]
+              (200, 5, "dec4", 7), (330, 6, "uniform53", 17)]] + [(two, 3), (neg, 3), (np.ones((40, 40)) - np.eye(40), 1), (tree_metric(90, 4), 3)]
     total_hits = total_fails = total_stalled = 0
     for K, target, pcap, mode in [(1, 8192, 0, 0), (3, 4, 0, 2), (8, 64, 0, 4), (64, 8192, 0, 8), (64, 1, 0, 1),
                                   (512, 8192, 0, 5), (16, 8192, 7, 2), (64, 65536, 300, 6)]:

@@ -169,7 +169,7 @@ import numpy as np
 import fastneighbornet_amd as fa
 from fastneighbornet_amd._capi import Handle
 from oracle import nnet_oracle as O
-from common import compare_trajectory
+from common import compare_trajectory, tree_metric
 a = fa.api()
 for n, seed, dist in [(40, 1, "uniform53"), (300, 2, "dec4"), (1100, 3, "uniform53"), (2100, 4, "uniform53")]:
     compare_trajectory(a, O, O.synth(n, seed, dist), deep=(n < 1000), deep_every=11)
@@ -213,6 +213,10 @@ A = rng.integers(1, 3, size=(400, 400)).astype(np.float64); A = np.triu(A, 1); A
 with Handle(a, 400) as h:
     h.set_matrix(A); o1, _ = h.run()
 assert (o1 == O.run(A)[0]).all()
+# additive tree metrics with dyadic branch lengths: path sums are exact, so the Q criterion has
+# exact ties between cherries - windows, certified decisions and tie-breaks under stress
+for n, seed in [(60, 1), (257, 2), (600, 3)]:
+    compare_trajectory(a, O, tree_metric(n, seed), deep=(n < 100), deep_every=5)
 rng = np.random.default_rng(3)
 n = 300
 A = rng.integers(1, 3, size=(n, n)).astype(np.float64); A = np.triu(A, 1); A = A + A.T
