@@ -1267,8 +1267,16 @@ FNN_HD void init_thread(const Dev& d, int32_t k) {
     if (k >= d.n) return;
     const double* D = d.D; const int64_t ld = d.ld;
     double s = 0.0;
-    for (int32_t j = 0; j < d.n; j++)
-        if (j != k) s += D[j * ld + k];  // == D[k][j] (symmetric input); column walk coalesces across k
+    // == D[k][j] (symmetric input); the column walk coalesces across k.  Eight loads in flight, added in
+    // the reference's order (the sum is sequential, the loads are not)
+    for (int32_t j0 = 0; j0 < d.n; j0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (j0 + u < d.n) ? D[(int64_t)(j0 + u) * ld + k] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (j0 + u < d.n && j0 + u != k) s += v[u];
+    }
     d.Sx[k] = s;
     d.sid[k] = k + 1;
     d.spos[k] = k;
