@@ -445,9 +445,12 @@ FNN_HD void tri_tile_decode(int32_t t, int32_t R, int32_t& rt, int32_t& ct) {
 FNN_HD int32_t screen_unit_count(int32_t m) { return 4 * tri_tile_count(m, SCR_TH, SCR_TW / SCR_TH); }
 
 // every store into the matrix keeps the bf16 copy in step
-FNN_HD void store_d(const Dev& d, int64_t idx, double v) {
+// (only the lower triangle of the copy, diagonal included, is ever read: the screening pass and the
+//  emission pass look at 2 x 2 blocks at or below the diagonal and use no entry above it)
+FNN_HD void store_d(const Dev& d, int64_t r, int64_t c, double v) {
+    const int64_t idx = r * d.ld + c;
     d.D[idx] = v;
-    if (d.H) d.H[idx] = bf16_from_double(v);
+    if (d.H && c <= r) d.H[idx] = bf16_from_double(v);
 }
 
 // ---------------------------------------------------------------------------
@@ -1082,17 +1085,17 @@ FNN_HD void op_thread(const Dev& d, const Op& op, int32_t k) {
             double t = d.Sx[a]; d.Sx[a] = d.Sx[b]; d.Sx[b] = t;
         } else if (k != b) {
             double ta = D[a * ld + k], tb = D[b * ld + k];
-            store_d(d, a * ld + k, tb); store_d(d, k * ld + a, tb);
-            store_d(d, b * ld + k, ta); store_d(d, k * ld + b, ta);
+            store_d(d, a, k, tb); store_d(d, k, a, tb);
+            store_d(d, b, k, ta); store_d(d, k, b, ta);
         }
     } else if (op.kind == OP_MOVE) {
         int32_t src = op.a, dst = op.b;
         if (k == src) {
-            store_d(d, dst * ld + dst, 0.0);
+            store_d(d, dst, dst, 0.0);
             d.Sx[dst] = d.Sx[src];
         } else if (k != dst) {
             double t = D[src * ld + k];
-            store_d(d, dst * ld + k, t); store_d(d, k * ld + dst, t);
+            store_d(d, dst, k, t); store_d(d, k, dst, t);
         }
     } else if (op.kind == OP_AGG3) {
         int32_t X = op.a, Y = op.b, Z = op.c, U = op.d, V = op.e;
@@ -1104,14 +1107,14 @@ FNN_HD void op_thread(const Dev& d, const Op& op, int32_t k) {
             double uv;
             if (op.flag) uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + dyx / 3.0) + dyz / 3.0;
             else uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + dyz / 3.0) + dyx / 3.0;
-            store_d(d, U * ld + U, 0.0); store_d(d, V * ld + V, 0.0);
-            store_d(d, U * ld + V, uv); store_d(d, V * ld + U, uv);
+            store_d(d, U, U, 0.0); store_d(d, V, V, 0.0);
+            store_d(d, U, V, uv); store_d(d, V, U, uv);
         } else if (k != Y && k != Z) {
             double dx = D[X * ld + k], dy = D[Y * ld + k], dz = D[Z * ld + k];
             double nu = (2.0 / 3.0) * dx + dy / 3.0;
             double nv = (2.0 / 3.0) * dz + dy / 3.0;
-            store_d(d, U * ld + k, nu); store_d(d, k * ld + U, nu);
-            store_d(d, V * ld + k, nv); store_d(d, k * ld + V, nv);
+            store_d(d, U, k, nu); store_d(d, k, U, nu);
+            store_d(d, V, k, nv); store_d(d, k, V, nv);
         }
     }
 }
@@ -1197,11 +1200,11 @@ FNN_HD double update_bulk(const Dev& d, int32_t k) {
     for (int t = 0; t < MAX_TGT; t++) {
         if (t < st.ntgt) {
             const int32_t dst = st.tgt[t].dst;
-            store_d(d, dst * ld + k, tv[t][0]);
-            store_d(d, k * ld + dst, tv[t][0]);
+            store_d(d, dst, k, tv[t][0]);
+            store_d(d, k, dst, tv[t][0]);
             if (paired) {
-                store_d(d, dst * ld + k + 1, tv[t][1]);
-                store_d(d, (k + 1) * ld + dst, tv[t][1]);
+                store_d(d, dst, k + 1, tv[t][1]);
+                store_d(d, k + 1, dst, tv[t][1]);
             }
         }
     }
