@@ -892,16 +892,19 @@ FNN_HD void pick(const Dev& d, Cand best) {
 // ComputeRx term for slot s (NetMakerOriginal.java:555-558), written to the chain
 // buffer at the node's reference position; the terms are also returned (0 where absent)
 // so that the kernel can form tree-ordered partial sums for the certified decision.
-FNN_HD void rx_fill_thread(const Dev& d, int32_t s, int32_t m, int32_t twoP, const int32_t z[4], double term[4]) {
+// write_chain: also store the terms in the chain buffers (only the exact sequential sums read them, and
+// those are needed only when the certified decision fails: the GPU writes them then, not before)
+FNN_HD void rx_fill_thread(const Dev& d, int32_t s, int32_t m, int32_t twoP, const int32_t z[4], double term[4],
+                           bool write_chain = true) {
     term[0] = term[1] = term[2] = term[3] = 0.0;
     if (s >= m) return;
     bool full = (s == z[0] || s == z[1] || s == z[2] || s == z[3] || s >= twoP);
-    int32_t pos = d.spos[s];
+    int32_t pos = write_chain ? d.spos[s] : 0;
     for (int k = 0; k < 4; k++) {
         if (z[k] < 0) continue;
         double v = d.D[(int64_t)z[k] * d.ld + s];
         term[k] = full ? v : v / 2.0;
-        d.chain[(int64_t)k * d.cstride + chain_addr(pos)] = term[k];
+        if (write_chain) d.chain[(int64_t)k * d.cstride + chain_addr(pos)] = term[k];
     }
 }
 

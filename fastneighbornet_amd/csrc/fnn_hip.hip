@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256) void k_rx_fill(Dev d, const Cand* src, int nre
     if (blockIdx.x == 0 && threadIdx.x == 0) pick(d, best);
     if (!need) return;
     double term[4];
-    rx_fill_thread(d, blockIdx.x * 256 + threadIdx.x, m, twoP, z, term);
+    rx_fill_thread(d, blockIdx.x * 256 + threadIdx.x, m, twoP, z, term, false);
     double v[8];
 #pragma unroll
     for (int k = 0; k < 4; k++) { v[k] = term[k]; v[4 + k] = term[k] < 0.0 ? -term[k] : term[k]; }
@@ -1191,9 +1191,20 @@ __device__ __forceinline__ void decide4_body(const Dev& d, int nparts, ChainLds<
         for (int k = 0; k < 4; k++) { rxa[k] = red[k]; rxs[k] = red[4 + k]; }
         certified = rx_certify(d, rxa, rxs) ? 1 : 0;
         if (!certified) {
-            // rare: the <=4 sums exactly, one after the other in this workgroup
+            // rare: the <=4 sums exactly, one after the other in this workgroup; their addends go to the
+            // chain buffers first (the rx phase only formed the tree sums)
             const int z[4] = {st->sa, st->sap, st->sb, st->sbp};
             const int m_old = st->m_old;
+            {
+                const int32_t zz[4] = {z[0], z[1], z[2], z[3]};
+                const int32_t twoP_old = 2 * st->P_old;
+                for (int32_t sl = threadIdx.x; sl < m_old; sl += blockDim.x) {
+                    double term[4];
+                    rx_fill_thread(d, sl, m_old, twoP_old, zz, term, true);
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
             for (int b = 0; b < 4; b++) {
                 rxa[b] = 0.0;
                 if (z[b] >= 0) rxa[b] = block_chain_sum<CH_EPT>(d.chain + (size_t)b * d.cstride, m_old, CH_GUARD_BITS, L, nullptr);
@@ -1518,7 +1529,7 @@ __global__ __launch_bounds__(CH_T) void k_events(Dev d, int max_events) {
             if (need) {
                 for (int32_t sl = w * CH_T + tid; sl < m; sl += nmain * CH_T) {
                     double term[4];
-                    rx_fill_thread(d, sl, m, twoP, z, term);
+                    rx_fill_thread(d, sl, m, twoP, z, term, false);
 #pragma unroll
                     for (int k = 0; k < 4; k++) { v[k] += term[k]; v[4 + k] += term[k] < 0.0 ? -term[k] : term[k]; }
                 }
