@@ -209,6 +209,9 @@ def main():
             },
             "hbm_gbps_whole_run": round(float(st.bytes_total) / sec / 1e9, 1),
             "hbm_frac_whole_run": round(float(st.bytes_total) / sec / 1e9 / HBM_PEAK_GBPS, 4),
+            # SURVEY.md 8(d)'s second figure, B_scan / t_order with B_scan = 8 B x sum_t E_t (what a scan of the fp64
+            # matrix in every event would read).  NOT physical traffic: the windows avoid reading most of it.
+            "b_scan_over_t_order_gbps": round(float(fp64_equiv) / sec / 1e9, 1),
             "rx_decisions": {"certified_from_tree_sums": int(st.n_rx_certified), "exact_sequential_sums": int(st.n_rx_exact)},
             "phases_s": {"init": round(st.t_init_s, 4), "agglomerate": round(st.t_agglom_s, 4),
                          "expand": round(st.t_expand_s, 4), "screen_kernel_sum": round(st.t_scan_s, 4),

@@ -83,6 +83,7 @@ class Api:
         f("create", C.c_int32, [C.c_int32, C.POINTER(FnnOpts), C.POINTER(C.c_void_p)])
         f("destroy", C.c_int32, [C.c_void_p])
         f("set_rows", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, _dp, C.c_int64])
+        f("set_packed_upper", C.c_int32, [C.c_void_p, _dp])
         f("synth", C.c_int32, [C.c_void_p, C.c_uint64, C.c_int32])
         f("run", C.c_int32, [C.c_void_p, _ip, C.POINTER(FnnStats)])
         f("begin", C.c_int32, [C.c_void_p])
@@ -178,6 +179,13 @@ class Handle:
         for r0 in range(0, self.n, step):
             cnt = min(step, self.n - r0)
             self.api.check(self.api.set_rows(self._h, r0, cnt, D[r0:].ctypes.data_as(_dp), self.n))
+
+    def set_packed_upper(self, packed: np.ndarray):
+        """DistancesAndNames.distances: the strict upper triangle, row-major (DistancesAndNames.java:24-38)."""
+        packed = np.ascontiguousarray(packed, dtype=np.float64)
+        if packed.shape != (self.n * (self.n - 1) // 2,):
+            raise ValueError(f"packed triangle must have {self.n * (self.n - 1) // 2} entries")
+        self.api.check(self.api.set_packed_upper(self._h, packed.ctypes.data_as(_dp)))
 
     def synth(self, seed: int, dist: str = "uniform53"):
         self.api.check(self.api.synth(self._h, seed, {"uniform53": 0, "dec4": 1}[dist]))

@@ -1304,6 +1304,10 @@ FNN_HD uint64_t splitmix64_at(uint64_t seed, uint64_t k) {
     return z ^ (z >> 31);
 }
 
+// packed strict upper triangle (DistancesAndNames.java:24-38): entry (a, b), a < b, sits at
+// packed_row_base(n, a) + b
+FNN_HD int64_t packed_row_base(int64_t n, int64_t a) { return a * (n - 1) - a * (a - 1) / 2 - (a + 1); }
+
 // synthetic entry (i < j) of the generator; index k = i*n - i(i+1)/2 + (j-i-1)
 FNN_HD double synth_entry(int64_t n, int64_t i, int64_t j, uint64_t seed, int32_t dist) {
     uint64_t k = (uint64_t)(i * n - i * (i + 1) / 2 + (j - i - 1));

@@ -131,6 +131,29 @@ class Engine {
         return FNN_OK;
     }
 
+    // DistancesAndNames' packed strict upper triangle -> both triangles on the device
+    // (FastNN.java:307-312 does this expansion on the host)
+    int32_t set_packed_upper(const double* packed) {
+        if (!packed && n > 1) return fail(FNN_EINVAL, "fnn_set_packed_upper: bad arguments");
+        const int64_t cap = (int64_t)16 << 20;  // entries per staged chunk (128 MiB); a row has < 2^15.. entries
+        for (int64_t row0 = 0; row0 + 1 < n;) {
+            int64_t cnt = 0, entries = 0;
+            while (row0 + cnt + 1 < n && (cnt == 0 || entries + (n - 1 - (row0 + cnt)) <= cap)) {
+                entries += n - 1 - (row0 + cnt);
+                cnt++;
+            }
+            const int64_t p0 = packed_row_base(n, row0) + row0 + 1;
+            if (be.unpack_rows(dev, packed + p0, p0, entries, (int32_t)row0, (int32_t)cnt) != FNN_OK)
+                return fail(FNN_EHIP, "fnn_set_packed_upper: copy failed (" + be.err() + ")");
+            row0 += cnt;
+        }
+        if (n > 0 && be.launch_mirror(dev) != FNN_OK)
+            return fail(FNN_EHIP, "fnn_set_packed_upper: launch failed (" + be.err() + ")");
+        have_matrix = true;
+        begun = ended = false;
+        return FNN_OK;
+    }
+
     int32_t set_matrix_device(const double* dmat, int64_t ld_in) {
         if (!dmat || ld_in < n) return fail(FNN_EINVAL, "fnn_set_matrix_device: bad arguments");
         if (n > 0 && be.d2d_2d(dev.D, ld, dmat, ld_in, n, n) != FNN_OK)

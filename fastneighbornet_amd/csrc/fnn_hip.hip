@@ -1657,6 +1657,32 @@ __global__ __launch_bounds__(256) void k_synth(Dev d, uint64_t seed, int dist) {
     d.D[r * d.ld + c] = v;
 }
 
+// rows [row0, row0 + gridDim.y) of the packed strict upper triangle (staged chunk starting at packed
+// index p0) -> the upper triangle of D
+__global__ __launch_bounds__(256) void k_unpack(Dev d, const double* __restrict__ stage, int64_t p0, int32_t row0) {
+    const int64_t r = row0 + (int64_t)blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c <= r || c >= d.n) return;
+    d.D[r * d.ld + c] = __builtin_nontemporal_load(stage + (packed_row_base(d.n, r) + c - p0));
+}
+
+// lower triangle := transpose of the upper one, diagonal := 0 (32x32 tiles through LDS)
+__global__ __launch_bounds__(256) void k_mirror(Dev d) {
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x, by = blockIdx.y;  // tile row by, tile column bx
+    if (bx < by) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int64_t r = (int64_t)by * 32 + k, c = (int64_t)bx * 32 + tx;
+        tile[k][tx] = (r < d.n && c < d.n && r < c) ? d.D[r * d.ld + c] : 0.0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int64_t r = (int64_t)bx * 32 + k, c = (int64_t)by * 32 + tx;  // the transposed tile
+        if (r < d.n && c < d.n && c <= r) d.D[r * d.ld + c] = (c == r) ? 0.0 : tile[tx][k];
+    }
+}
+
 // symmetric (bitwise), finite, zero diagonal: 32x32 tiles, transposed partner through LDS
 __global__ __launch_bounds__(256) void k_validate(Dev d, int* bad) {
     __shared__ uint64_t tile[32][33];
@@ -1715,6 +1741,8 @@ struct HipBackend {
     double scan_ms = 0.0, plain_ms = 0.0;       // k_screen launches / k_scan launches
     int64_t scan_launches = 0, plain_launches = 0;
     int* d_bad = nullptr;
+    double* d_stage = nullptr;  // staging for fnn_set_packed_upper
+    int64_t stage_cap = 0;
     // RCCL (dlopen'ed: the process may already hold PyTorch's copy of the library)
     void* rccl_lib = nullptr;
     void* rccl_comm = nullptr;
@@ -1801,6 +1829,9 @@ struct HipBackend {
         ev_pool.clear();
         if (d_bad) (void)hipFree(d_bad);
         d_bad = nullptr;
+        if (d_stage) (void)hipFree(d_stage);
+        d_stage = nullptr;
+        stage_cap = 0;
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
         opened = false;
@@ -1875,6 +1906,27 @@ struct HipBackend {
     int32_t launch_synth(const Dev& d, uint64_t seed, int32_t dist) {
         dim3 g((unsigned)((d.n + 255) / 256), (unsigned)d.n);
         hipLaunchKernelGGL(k_synth, g, dim3(256), 0, stream, d, seed, dist);
+        return HIPOK(hipGetLastError()) && HIPOK(hipStreamSynchronize(stream)) ? FNN_OK : FNN_EHIP;
+    }
+    int32_t unpack_rows(const Dev& d, const double* src, int64_t p0, int64_t entries, int32_t row0, int32_t cnt) {
+        if (entries > stage_cap) {
+            if (d_stage) (void)hipFree(d_stage);
+            d_stage = nullptr;
+            stage_cap = 0;
+            if (!HIPOK(hipMalloc((void**)&d_stage, sizeof(double) * (size_t)entries))) return FNN_EHIP;
+            stage_cap = entries;
+        }
+        if (!HIPOK(hipMemcpyAsync(d_stage, src, sizeof(double) * (size_t)entries, hipMemcpyHostToDevice, stream))) return FNN_EHIP;
+        dim3 g((unsigned)((d.n + 255) / 256), (unsigned)cnt);
+        hipLaunchKernelGGL(k_unpack, g, dim3(256), 0, stream, d, (const double*)d_stage, p0, row0);
+        return HIPOK(hipGetLastError()) && HIPOK(hipStreamSynchronize(stream)) ? FNN_OK : FNN_EHIP;
+    }
+    int32_t launch_mirror(const Dev& d) {
+        if (d_stage) (void)hipFree(d_stage);
+        d_stage = nullptr;
+        stage_cap = 0;
+        unsigned t = (unsigned)((d.n + 31) / 32);
+        hipLaunchKernelGGL(k_mirror, dim3(t, t), dim3(256), 0, stream, d);
         return HIPOK(hipGetLastError()) && HIPOK(hipStreamSynchronize(stream)) ? FNN_OK : FNN_EHIP;
     }
     int32_t launch_validate(const Dev& d, int32_t* bad) {
@@ -2049,6 +2101,10 @@ int32_t fnn_destroy(fnn_handle* h) {
 int32_t fnn_set_rows(fnn_handle* h, int32_t row0, int32_t nrows, const double* rows, int64_t ld_in) {
     FNN_NEED(h);
     FNN_TRY(return h->eng.set_rows(row0, nrows, rows, ld_in);)
+}
+int32_t fnn_set_packed_upper(fnn_handle* h, const double* packed) {
+    if (!h) return fnn::fail(FNN_EINVAL, "fnn_set_packed_upper: null handle");
+    FNN_TRY(return h->eng.set_packed_upper(packed);)
 }
 int32_t fnn_set_matrix_device(fnn_handle* h, const double* d_matrix, int64_t ld_in) {
     FNN_NEED(h);

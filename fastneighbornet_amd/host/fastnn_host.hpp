@@ -77,12 +77,30 @@ class NeighborNetCanonical : public NetMakerOriginal {
   public:
     NeighborNetCanonical(const double* d, int numTaxa, int numThreads = 1, void* pool = nullptr, int device = 0)
         : NetMakerOriginal(d, numTaxa, numThreads, pool), device(device) {}
+    // from the reader's own container: the packed triangle goes to the device as it is
+    // (fnn_set_packed_upper) instead of through the dense copy of FastNN.java:307-312
+    explicit NeighborNetCanonical(const DistancesAndNames& dan, int numThreads = 1, void* pool = nullptr, int device = 0)
+        : NetMakerOriginal(nullptr, dan.nTaxa, numThreads, pool), device(device), packed(&dan.distances) {}
     std::vector<int32_t> runNeighborNet() override {
         ordering.assign((size_t)ntax + 1, 0);
         fnn_opts o{};
         o.device = device;
         o.validate = 1;
-        int32_t rc = fnn_canonical_order_f64(D, ntax, ntax, &o, ordering.data(), &stats);
+        int32_t rc;
+        if (!packed) {
+            rc = fnn_canonical_order_f64(D, ntax, ntax, &o, ordering.data(), &stats);
+        } else if (ntax <= 3) {  // NetMakerOriginal.java:133-140
+            for (int i = 0; i <= ntax; i++) ordering[(size_t)i] = i;
+            rc = FNN_OK;
+        } else {
+            fnn_handle* h = nullptr;
+            rc = fnn_create(ntax, &o, &h);
+            if (rc == FNN_OK) rc = fnn_set_packed_upper(h, packed->data());
+            if (rc == FNN_OK) rc = fnn_run(h, ordering.data(), &stats);
+            const std::string why = rc == FNN_OK ? "" : fnn_last_error();
+            if (h) fnn_destroy(h);
+            if (rc != FNN_OK) throw std::runtime_error("fastnn: " + why);
+        }
         if (rc != FNN_OK) throw std::runtime_error(std::string("fastnn: ") + fnn_last_error());
         return ordering;
     }
@@ -90,6 +108,7 @@ class NeighborNetCanonical : public NetMakerOriginal {
 
   private:
     int device;
+    const std::vector<double>* packed = nullptr;
 };
 
 // SplitAndWeight (CircularSplitWeights.java:47-50): the BitSet as the ascending list of its set bits

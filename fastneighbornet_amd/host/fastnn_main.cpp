@@ -103,8 +103,7 @@ int main(int argc, char** argv) {
     }
     try {
         nnet::DistancesAndNames danOrg(fileName, nTaxa);
-        std::vector<double> D = danOrg.toMatrix();
-        nnet::NeighborNetCanonical myNMO(D.data(), nTaxa, nThreads, nullptr, device);
+        nnet::NeighborNetCanonical myNMO(danOrg, nThreads, nullptr, device);
         std::fprintf(stderr, "Using the canonical implementation.\n");
         auto t0 = std::chrono::steady_clock::now();
         std::vector<int32_t> ordering = myNMO.runNeighborNet();
@@ -119,6 +118,7 @@ int main(int argc, char** argv) {
         t0 = std::chrono::steady_clock::now();
         std::vector<double> weights((size_t)nTaxa * (size_t)(nTaxa - 1) / 2);
         fnn_sw_stats sw{};
+        std::vector<double> D = danOrg.toMatrix();
         if (nTaxa >= 2) {
             int32_t rc = fnn_split_weights_f64(D.data(), nTaxa, nTaxa, ordering.data(), device, weights.data(), &sw);
             if (rc != FNN_OK) throw std::runtime_error(std::string("fastnn: ") + fnn_last_error());

@@ -124,6 +124,11 @@ int32_t fnn_destroy(fnn_handle* h);
  * constructor argument; the caller's buffer is never written (the reference
  * destroys its argument in place, NetMakerOriginal.java:653-656). */
 int32_t fnn_set_rows(fnn_handle* h, int32_t row0, int32_t nrows, const double* rows, int64_t ld_in);
+/* The same matrix from the reference's own container: the packed strict upper triangle of
+ * DistancesAndNames (`double[] distances`, n(n-1)/2 entries, row-major: entry (a, b), a < b, at
+ * a(n-1) - a(a-1)/2 + b - (a+1), DistancesAndNames.java:24-38).  Replaces the dense expansion of
+ * FastNN.java:307-312: half the bytes cross the bus, the device mirrors the triangle itself. */
+int32_t fnn_set_packed_upper(fnn_handle* h, const double* packed);
 /* Same from DEVICE memory (whole matrix, row stride ld_in doubles). */
 int32_t fnn_set_matrix_device(fnn_handle* h, const double* d_matrix, int64_t ld_in);
 /* Fill the device matrix with the synthetic generator of SURVEY.md 8(d)

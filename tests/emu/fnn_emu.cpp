@@ -67,6 +67,18 @@ struct EmuBackend {
     int32_t d2h_2d(double* d, int64_t ldd, const double* s, int64_t lds, int64_t w, int64_t h) {
         return h2d_2d(d, ldd, s, lds, w, h);
     }
+    int32_t unpack_rows(const fnn::Dev& d, const double* src, int64_t p0, int64_t, int32_t row0, int32_t cnt) {
+        for (int64_t r = row0; r < (int64_t)row0 + cnt; r++)
+            for (int64_t c = r + 1; c < d.n; c++) d.D[r * d.ld + c] = src[fnn::packed_row_base(d.n, r) + c - p0];
+        return FNN_OK;
+    }
+    int32_t launch_mirror(const fnn::Dev& d) {
+        for (int64_t r = 0; r < d.n; r++) {
+            d.D[r * d.ld + r] = 0.0;
+            for (int64_t c = 0; c < r; c++) d.D[r * d.ld + c] = d.D[c * d.ld + r];
+        }
+        return FNN_OK;
+    }
     int32_t sync() { return FNN_OK; }
     void collect_timing(fnn_stats&) {}
 
@@ -457,6 +469,7 @@ int32_t emu_destroy(void* h) { auto* e = (EmuEngine*)h; e->destroy(); delete e; 
 int32_t emu_set_rows(void* h, int32_t row0, int32_t nrows, const double* rows, int64_t ld) {
     return ((EmuEngine*)h)->set_rows(row0, nrows, rows, ld);
 }
+int32_t emu_set_packed_upper(void* h, const double* packed) { return ((EmuEngine*)h)->set_packed_upper(packed); }
 int32_t emu_synth(void* h, uint64_t seed, int32_t dist) { return ((EmuEngine*)h)->synth(seed, dist); }
 int32_t emu_run(void* h, int32_t* order, fnn_stats* st) { return ((EmuEngine*)h)->run(order, st); }
 int32_t emu_begin(void* h) { return ((EmuEngine*)h)->begin(); }

@@ -54,6 +54,25 @@ def test_run_matches_stepping(emu_api, oracle):
     assert (ev["best"].view(np.int64) == ev_ref["best"].view(np.int64)).all()
 
 
+def test_packed_upper_upload(emu_api, oracle):
+    """N3: DistancesAndNames' packed strict upper triangle (DistancesAndNames.java:24-38) uploaded
+    as such gives the matrix FastNN.java:307-312 builds, and the same order."""
+    emu_api.set_order_mode(0)
+    for n in (1, 2, 3, 4, 5, 37, 150):
+        D = oracle.synth(n, 3) if n > 1 else np.zeros((1, 1))
+        with Handle(emu_api, n) as h:
+            h.set_packed_upper(D[np.triu_indices(n, 1)])
+            if n > 3:
+                h.begin()
+                assert (h.live_matrix().view(np.int64) == D.view(np.int64)).all()
+                while h.step() is not None:
+                    pass
+                order = h.finish()
+            else:
+                order, _ = h.run()
+        assert (order == oracle.run(D)[0]).all() if n > 3 else order.tolist() == list(range(n + 1))
+
+
 def test_validate_rejects_bad_matrix(emu_api, oracle):
     from fastneighbornet_amd._capi import FnnError
     D = oracle.synth(8, 1)

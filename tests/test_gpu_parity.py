@@ -67,6 +67,24 @@ def test_device_synth_is_bit_identical(hip_api, oracle):
             assert (h.finish() == o_ref).all()
 
 
+def test_packed_upper_upload(hip_api, oracle):
+    """N3: the packed strict upper triangle of DistancesAndNames (DistancesAndNames.java:24-38) is
+    mirrored on the device; n = 6000 needs two staged chunks."""
+    for n in (2, 4, 5, 100, 777, 6000):
+        D = oracle.synth(n, 4)
+        with Handle(hip_api, n) as h:
+            h.set_packed_upper(D[np.triu_indices(n, 1)])
+            if n < 4:
+                assert h.run()[0].tolist() == list(range(n + 1))
+                continue
+            h.begin()
+            assert (bits(h.live_matrix()) == bits(D)).all()
+            if n <= 777:
+                while h.step() is not None:
+                    pass
+                assert (h.finish() == oracle.run(D, threads=8)[0]).all()
+
+
 def test_one_call_and_host_mirror(hip_api, oracle):
     import fastneighbornet_amd as fa
     n = 300
