@@ -149,6 +149,67 @@ FNN_HD bool mono_apply(double& s, int32_t E, Mono mo) {
     return true;
 }
 
+// The automaton of a whole chunk of N addends relative to one binade, with the addends handled
+// independently of each other (no dependency from one addend to the next: the per-addend work
+// pipelines).  Without a tie every addend's automaton is the constant q + r, and constants compose
+// by addition; the increments are integer-valued doubles, so their sum is exact in ANY order while
+// it stays below 2^53, and a sum that leaves that range can only come out >= 2^53 (each partial sum
+// is either exact or the rounding of an exact value >= 2^53), which mono_apply rejects.  False: some
+// addend needs the ordinary addition, or there is a tie (an addend ending exactly half an ulp above a
+// multiple of the ulp; with k bits of the addend below the ulp of the sum that has probability 2^-k,
+// so it happens in the first chunks of a sum, which cross binades anyway, and ~1/j-th of the time in
+// chunk j): the chunk's addends are then added one by one.
+template <int N>
+FNN_HD bool chain_chunk(const double (&a)[N], double invu, Mono& mt) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};  // four independent accumulators
+    double tmin = 0.0;
+    bool tie = false;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const double t = a[i] * invu;                 // a in ulps; exact (see header); -0.0 counts as 0
+        const double c = __builtin_rint(t);           // q + r unless there is a tie (round to nearest even)
+        const double e = t - c;                       // exact, |e| <= 0.5
+        tie = tie || (__builtin_fabs(e) == 0.5);
+        acc[i & 3] += c;
+        tmin = __builtin_fmin(tmin, t);               // (fmin drops a NaN: caught by the sum below)
+    }
+    const double c = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    // NaN addend -> c is NaN; negative addend -> tmin < 0; an addend >= 2^(E+1) (or inf) makes the sum
+    // >= 2^53, which no run accepts
+    if (!(c < CH_TWO53) || tmin < 0.0 || tie) return false;
+    mt.i0 = c;
+    mt.i1 = c;
+    return true;
+}
+
+// Increment of an automaton as an integer for mono_apply_bits; anything outside the exact range
+// becomes 2^53, which mono_apply_bits always rejects.
+FNN_HD uint64_t mono_inc_bits(double inc) {
+    return (inc >= 0.0 && inc < CH_TWO53) ? (uint64_t)inc : (1ULL << 53);
+}
+
+// mono_apply on the bit pattern of s: with s in binade E, S = s / ulp is 2^52 + mantissa, so its
+// parity is bit 0 of the pattern, S + increment is an integer addition on the pattern, and the sum
+// stays below 2^53 exactly when no carry reaches the exponent field.  Same accept / reject decisions
+// and the same result as mono_apply; a handful of integer operations instead of a chain of dependent
+// fp64 ones.
+FNN_HD bool mono_apply_pattern(uint64_t& sb, int32_t E, uint64_t i0, uint64_t i1) {
+    if (E < CH_E_MIN || E > CH_E_MAX) return false;
+    if ((int64_t)(sb >> 52) != (int64_t)E) return false;       // positive and in binade E
+    const uint64_t inc = (sb & 1ULL) ? i1 : i0;
+    if (inc > (1ULL << 52)) return false;
+    const uint64_t nb = sb + inc;
+    if ((int64_t)(nb >> 52) != (int64_t)E) return false;       // S + increment >= 2^53
+    sb = nb;
+    return true;
+}
+FNN_HD bool mono_apply_bits(double& s, int32_t E, uint64_t i0, uint64_t i1) {
+    uint64_t sb = f2u(s);
+    if (!mono_apply_pattern(sb, E, i0, i1)) return false;
+    s = u2f(sb);
+    return true;
+}
+
 // Counters of the walker (diagnostics / tests)
 struct ChainStats {
     int32_t runs;         // composed runs applied

@@ -181,6 +181,7 @@ struct Dev {
     int32_t* tpairs; // lookahead: tracked pairs {id a, id b, cstamp a, cstamp b} (LA_PCAP records)
     int32_t* fresh;  // lookahead: per fresh cluster {representative id, stamp} (LA_KMAX entries)
     uint32_t* ticket; // lookahead: arrival counter of k_track's workgroups
+    uint64_t* chrec;  // records of a chain sum between its data-parallel part (k_track) and its walk (k_decide4): CHREC_WORDS
     int32_t* lacnt;  // lookahead: append counter of the tracked list (its own word: the control block may be
                      // cached in LDS by the persistent event kernel while every thread appends)
     double* upart;   // persistent event kernel: per main workgroup {sum, sum of magnitudes} of the new cluster's row-sum addends
@@ -204,6 +205,12 @@ struct Dev {
 constexpr int CH_T = 1024;               // threads of the chain workgroup
 constexpr int CH_EPT = 32;               // addends per thread
 constexpr int CH_SC = CH_T * CH_EPT;     // addends per super-chunk
+constexpr int CH_NSLOT = 48;             // parked ("mixed") chunks per super-chunk
+// layout of Dev::chrec in 8-byte words: increments own[CH_T], sc[CH_T]; then E, flags, slot (CH_T int32 each);
+// then the parked addends
+constexpr int CHREC_OWN = 0, CHREC_SC = CH_T, CHREC_E = 2 * CH_T, CHREC_FLAGS = CHREC_E + CH_T / 2,
+              CHREC_SLOT = CHREC_FLAGS + CH_T / 2, CHREC_VALS = CHREC_SLOT + CH_T / 2,
+              CHREC_WORDS = CHREC_VALS + CH_NSLOT * CH_EPT;
 FNN_HD int64_t chain_addr(int32_t e) {
     const int32_t sc = e / CH_SC, r = e % CH_SC;
     const int32_t t = r / CH_EPT, j = r % CH_EPT;
@@ -630,6 +637,7 @@ struct TrackArgs {
     // persistent event kernel: the swept cluster's exact row sum may still be on its way; the sweep
     // then runs with the tree-ordered sum `sxu` and its pairs compete in a separate record
     int32_t approx;
+    int32_t usl;  // slot of the cluster whose sum sxu is (-2: not checked)
     double sxu;
 };
 FNN_HD TrackArgs track_args(const State& st) {
@@ -643,31 +651,39 @@ FNN_HD TrackArgs track_args(const State& st) {
     a.coef = st.la_coef;
     a.th = (double)st.la_theta_pred;
     a.approx = 0;
+    a.usl = -2;
     a.sxu = 0.0;
     return a;
 }
 FNN_HD int64_t track_item_count(const TrackArgs& a) { return (int64_t)a.np + (int64_t)(a.nf - a.nf0) * ((a.m + 1) / 2); }
-// `bestu` receives the swept pairs when the sweep runs on an approximate row sum (a.approx)
-FNN_HD void track_item(const Dev& d, int64_t item, const TrackArgs& a, Cand& best, Cand& bestu) {
-    if (item < a.np) {
-        const int32_t* t = d.tpairs + 4 * item;
-        const int32_t ia = t[0], ib = t[1];
-        const int32_t sa = d.islot[ia], sb = d.islot[ib];
-        if (sa < 0 || sb < 0 || d.cstamp[ia] != t[2] || d.cstamp[ib] != t[3]) return;  // a cluster is gone or was re-formed
-        pair_eval(d, sa, sb, a.m, a.twoP, a.cm2, best);
-        return;
-    }
-    const int64_t r = item - a.np;
+// a tracked pair: evaluated exactly if both clusters still exist unchanged
+FNN_HD void track_pair_item(const Dev& d, int64_t item, const TrackArgs& a, Cand& best) {
+    const int32_t* t = d.tpairs + 4 * item;
+    const int32_t ia = t[0], ib = t[1];
+    const int32_t sa = d.islot[ia], sb = d.islot[ib];
+    if (sa < 0 || sb < 0 || d.cstamp[ia] != t[2] || d.cstamp[ib] != t[3]) return;  // a cluster is gone or was re-formed
+    pair_eval(d, sa, sb, a.m, a.twoP, a.cm2, best);
+}
+// item r of the sweep of the new clusters' rows.  `bestu` receives the swept pairs when the sweep runs
+// on an approximate row sum (a.approx); false: the swept cluster is not the one whose sum a.sxu is.
+FNN_HD bool track_sweep_item(const Dev& d, int64_t r, const TrackArgs& a, Cand& best, Cand& bestu) {
     const int32_t half = (a.m + 1) / 2;
     const int32_t fi = a.nf0 + (int32_t)(r / half), cp = (int32_t)(r % half);
-    if (fi >= a.nf) return;
+    if (fi >= a.nf) return true;
     const int32_t id = d.fresh[2 * fi], stamp = d.fresh[2 * fi + 1];
     const int32_t f0 = d.islot[id];
-    if (f0 < 0 || d.cstamp[id] != stamp) return;  // already consumed by a later event
+    if (f0 < 0 || d.cstamp[id] != stamp) return true;  // already consumed by a later event
     // (insertion with the approximate sum: its error, ~1e-16 m n Dmax, is far inside the gap la_delta ~ 1e-6 n Dmax
     //  between the insertion threshold theta_pred and the acceptance threshold theta_eff)
-    if (a.approx) fresh_eval(d, f0, 2 * cp, a.m, a.twoP, a.cm2, a.coef, a.th, a.sxu, a.sxu, bestu);
-    else fresh_eval(d, f0, 2 * cp, a.m, a.twoP, a.cm2, a.coef, a.th, d.Sx[f0], d.Sx[f0 + 1], best);
+    if (a.approx) {
+        if (a.usl != -2 && f0 != a.usl) return false;
+        fresh_eval(d, f0, 2 * cp, a.m, a.twoP, a.cm2, a.coef, a.th, a.sxu, a.sxu, bestu);
+    } else fresh_eval(d, f0, 2 * cp, a.m, a.twoP, a.cm2, a.coef, a.th, d.Sx[f0], d.Sx[f0 + 1], best);
+    return true;
+}
+FNN_HD void track_item(const Dev& d, int64_t item, const TrackArgs& a, Cand& best, Cand& bestu) {
+    if (item < a.np) track_pair_item(d, item, a, best);
+    else (void)track_sweep_item(d, item - a.np, a, best, bestu);
 }
 FNN_HD void track_item(const Dev& d, int64_t item, const TrackArgs& a, Cand& best) { track_item(d, item, a, best, best); }
 

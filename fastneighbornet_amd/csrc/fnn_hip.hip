@@ -323,13 +323,16 @@ __global__ __launch_bounds__(256) void k_emit(Dev d) {
         const int i = atomicAdd(&lcount, 1);
         if (i < EMIT_LDS) lbuf[i] = make_int2(d.sid[rs], d.sid[cs]);
     };
-    for (int ub = wave * 64; ub < nunits; ub += nwaves * 64) {
-        // 64 units per step: every lane fetches one unit's mask; the marked 32 x 8 blocks of all 64
-        // units are then dealt out evenly, one block per lane and round (a node with an extreme row
-        // sum marks a whole row of blocks in ONE unit)
+    // `per` units per wave and step (a power of two, 4..64: few enough that all waves of the grid get
+    // some when the live matrix is small): lane l < per fetches one unit's mask; the marked 32 x 8
+    // blocks of these units are then dealt out evenly, one block per lane and round (a node with an
+    // extreme row sum marks a whole row of blocks in ONE unit)
+    int per = 4;
+    while (per < 64 && per * nwaves < nunits) per <<= 1;
+    for (int ub = wave * per; ub < nunits; ub += nwaves * per) {
         const int myu = ub + lane;
         unsigned long long mymask = 0;
-        if (myu < nunits && d.srec[myu] <= tp) mymask = d.shit[myu];
+        if (lane < per && myu < nunits && d.srec[myu] <= tp) mymask = d.shit[myu];
         int incl = __builtin_popcountll(mymask);
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -754,7 +757,6 @@ __global__ __launch_bounds__(256) void k_rx_fill(Dev d, const Cand* src, int nre
 //   3. a segmented scan over the lanes of each wave composes runs of chunks of equal binade;
 //   4. wave 0 walks over the runs: one exact O(1) update per run, ordinary additions for mixed
 //      chunks, and retries at finer granularity where the binade assumption is refuted.
-constexpr int CH_NSLOT = 48;
 
 template <int EPT>
 struct ChainLds {
@@ -764,7 +766,8 @@ struct ChainLds {
     int32_t E[CH_T];
     int32_t flags[CH_T];  // bit0 pure, bit1 last chunk of its run
     int32_t slot[CH_T];
-    double own0[CH_T], own1[CH_T], sc0[CH_T], sc1[CH_T];
+    uint64_t own[CH_T], sc[CH_T];  // increments of a chunk / of the run up to the chunk, as integers (mono_inc_bits);
+                                   // chunks with a tie are "mixed", so an automaton here is one constant
     double vals[CH_NSLOT][EPT];
 };
 
@@ -778,6 +781,12 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+__device__ __forceinline__ uint64_t readfirstlane_u64(uint64_t v) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ void chain_serial_global(double& s, const double* buf, int start, int cnt, int m) {
     for (int i = 0; i < cnt; i++)
         if (start + i < m) s += buf[chain_addr(start + i)];
@@ -785,8 +794,10 @@ __device__ __forceinline__ void chain_serial_global(double& s, const double* buf
 
 __device__ int g_chain_stop_after = 0;  // diagnostic: 1 loads+prefix, 2 +automata, 3 +segmented scan (0 = full)
 
-template <int EPT>
-__device__ double block_chain_sum(const double* __restrict__ buf, int m, int guard_bits, ChainLds<EPT>& L,
+// MODE 0: the whole sum.  MODE 1: steps 1-3 only (the records stay in L; m <= CH_T * EPT).  MODE 2:
+// step 4 only, on records that are in L already (m <= CH_T * EPT).
+template <int EPT, int MODE = 0>
+__device__ __forceinline__ double block_chain_sum(const double* __restrict__ buf, int m, int guard_bits, ChainLds<EPT>& L,
                                   ChainStats* stats) {
     const int stop_after = stats ? g_chain_stop_after : 0;
     static_assert(EPT % 2 == 0 && EPT <= 64, "EPT");
@@ -794,6 +805,8 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
     ChainStats cs{0, 0, 0, 0};
     if (tid == 0) L.s = 0.0;
     for (int base = 0; base < m; base += CH_T * EPT) {
+        double s_in = 0.0;
+        if (MODE != 2) {
         if (tid == 0) L.slot_count = 0;
         // 1. addends of this thread: chunk-interleaved buffer (fnn_core.h chain_addr), so the j-th
         //    16-byte load of all lanes of a wave is one contiguous 1 KiB segment
@@ -821,20 +834,15 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
         __syncthreads();
         double wpre = 0.0;
         for (int k = 0; k < w; k++) wpre += L.wtot[k];
-        const double s_in = L.s;
+        s_in = L.s;
         double A = s_in + (wpre + (inc - loc));  // predicted partial sum in front of this chunk
         if (stop_after == 1) { if (tid == 0) L.s = A; __syncthreads(); continue; }
         // 2. automaton of the chunk: the binade is predicted once per chunk (partial sums are
         //    monotone over non-negative addends; a negative addend makes the chunk "mixed")
         int32_t E = -1;
         bool pure = chain_predict(A, A + loc, guard_bits != 0, E);
-        Mono mt = mono_identity();
-        if (pure) {
-            const double invu = inv_ulp(E);
-#pragma unroll
-            for (int i = 0; i < EPT; i++) pure = pure && chain_accumulate(a[i], invu, mt);
-        }
-        if (stop_after == 2) { if (tid == 0) L.s = mt.i0 + (double)E + (pure ? 1.0 : 0.0); __syncthreads(); continue; }
+        // a chunk that is not predicted to stay in one binade is "mixed": its addends are parked now,
+        // while they are still in registers (nothing of a[] stays live across the automata)
         int slot = -1;
         if (!pure && idx0 < m) {
             slot = atomicAdd(&L.slot_count, 1);
@@ -843,39 +851,63 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
                 for (int i = 0; i < EPT; i++) L.vals[slot][i] = a[i];
             } else slot = -1;
         }
+        Mono mt = mono_identity();
+        if (pure) {
+            pure = chain_chunk<EPT>(a, inv_ulp(E), mt);
+            if (!pure) {  // rare (negative / non-finite addend, tie): parked from memory
+                slot = atomicAdd(&L.slot_count, 1);
+                if (slot < CH_NSLOT) {
+#pragma unroll 1
+                    for (int i = 0; i < EPT; i++) L.vals[slot][i] = (idx0 + i < m) ? buf[chain_addr(idx0 + i)] : 0.0;
+                } else slot = -1;
+            }
+        }
+        if (stop_after == 2) { if (tid == 0) L.s = mt.i0 + (double)E + (pure ? 1.0 : 0.0); __syncthreads(); continue; }
         // 3. runs inside the wave: segmented inclusive scan of the chunk automata
         const int pure_prev = __shfl_up((int)pure, 1, 64);
         const int E_prev = __shfl_up(E, 1, 64);
         const bool head = (lane == 0) || !pure || !pure_prev || (E != E_prev);
-        Mono sc = mt;
+        double sc = mt.i0;  // (== mt.i1: constant automata compose by addition)
         int f = head ? 1 : 0;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            Mono o;
-            o.i0 = __shfl_up(sc.i0, d, 64);
-            o.i1 = __shfl_up(sc.i1, d, 64);
+            const double o = __shfl_up(sc, d, 64);
             const int fo = __shfl_up(f, d, 64);
-            if (lane >= d && !f) { sc = mono_compose(o, sc); f = fo; }
+            if (lane >= d && !f) { sc = o + sc; f = fo; }
         }
         const int head_next = __shfl_down((int)head, 1, 64);
         const bool endf = (lane == 63) || head_next || (idx0 + EPT >= m);
         L.E[tid] = E;
         L.flags[tid] = (pure ? 1 : 0) | (endf ? 2 : 0);
         L.slot[tid] = slot;
-        L.own0[tid] = mt.i0; L.own1[tid] = mt.i1;
-        L.sc0[tid] = sc.i0; L.sc1[tid] = sc.i1;
+        L.own[tid] = mono_inc_bits(mt.i0);
+        L.sc[tid] = mono_inc_bits(sc);
         __syncthreads();
-        if (stop_after == 3) { if (tid == 0) L.s = sc.i0; __syncthreads(); continue; }
+        if (stop_after == 3) { if (tid == 0) L.s = sc; __syncthreads(); continue; }
+        if (MODE == 1) return 0.0;
+        } else {
+            __syncthreads();
+            s_in = L.s;
+        }
         // 4. the walk (every lane of wave 0 carries the same s)
         if (w == 0) {
-            double s = s_in;
+            // the running sum lives as its bit pattern in scalar registers: a run is applied by a few
+            // scalar integer operations (mono_apply_pattern) instead of a chain of dependent fp64 ones
+            uint64_t sb = readfirstlane_u64(f2u(s_in));
+            // (the records of the next 64 chunks are fetched from LDS while the current ones are walked)
+            int nE = L.E[lane], nf = L.flags[lane], nslot = L.slot[lane];
+            uint64_t no = L.own[lane], ns = L.sc[lane];
             for (int ww = 0; ww < CH_T / 64; ww++) {
                 const int first = base + ww * 64 * EPT;
                 if (first >= m) break;
                 const int nvalid = min(64, (m - first + EPT - 1) / EPT);
-                const int id = ww * 64 + lane;
-                const int rE = L.E[id], rf = L.flags[id], rslot = L.slot[id];
-                const uint64_t ro0 = f2u(L.own0[id]), ro1 = f2u(L.own1[id]), rs0 = f2u(L.sc0[id]), rs1 = f2u(L.sc1[id]);
+                const int rE = nE, rf = nf, rslot = nslot;
+                const uint64_t ro = no, rs = ns;
+                if (ww + 1 < CH_T / 64) {
+                    const int id = (ww + 1) * 64 + lane;
+                    nE = L.E[id]; nf = L.flags[id]; nslot = L.slot[id];
+                    no = L.own[id]; ns = L.sc[id];
+                }
                 uint64_t endmask = __ballot((rf & 2) != 0);
                 if (nvalid < 64) endmask &= (1ULL << nvalid) - 1;
                 int prev_end = -1;
@@ -883,22 +915,20 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
                     const int e = __builtin_ctzll(endmask);
                     endmask &= endmask - 1;
                     const int fe = readlane_i32(rf, e);
-                    if (stop_after == 4) { s += (double)fe; prev_end = e; continue; }  // diagnostic: loop structure only
+                    if (stop_after == 4) { sb += (uint64_t)fe; prev_end = e; continue; }  // diagnostic: loop structure only
                     if (fe & 1) {
-                        Mono mr;
-                        mr.i0 = u2f(readlane_u64(rs0, e));
-                        mr.i1 = u2f(readlane_u64(rs1, e));
-                        if (stop_after == 5) { s += mr.i0; prev_end = e; continue; }  // diagnostic: no mono_apply, no mixed adds
-                        if (mono_apply(s, readlane_i32(rE, e), mr)) cs.runs++;
+                        const uint64_t m0 = readlane_u64(rs, e);
+                        if (stop_after == 5) { sb += m0; prev_end = e; continue; }  // diagnostic: no apply, no mixed adds
+                        if (mono_apply_pattern(sb, readlane_i32(rE, e), m0, m0)) cs.runs++;
                         else {
                             cs.run_fail++;
                             for (int j = prev_end + 1; j <= e; j++) {
-                                Mono mj;
-                                mj.i0 = u2f(readlane_u64(ro0, j));
-                                mj.i1 = u2f(readlane_u64(ro1, j));
-                                if (!mono_apply(s, readlane_i32(rE, j), mj)) {
+                                const uint64_t mj = readlane_u64(ro, j);
+                                if (!mono_apply_pattern(sb, readlane_i32(rE, j), mj, mj)) {
                                     cs.thread_fail++;
-                                    chain_serial_global(s, buf, first + j * EPT, EPT, m);
+                                    double sv = u2f(sb);
+                                    chain_serial_global(sv, buf, first + j * EPT, EPT, m);
+                                    sb = readfirstlane_u64(f2u(sv));
                                 }
                             }
                         }
@@ -906,18 +936,20 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
                         cs.mixed++;
                         if (stop_after == 5) { prev_end = e; continue; }
                         const int sl = readlane_i32(rslot, e);
+                        double sv = u2f(sb);
                         if (sl >= 0) {
                             // (every lane adds the same parked addends in order: LDS broadcast reads, which
                             //  pipeline under the dependent additions - no cross-lane traffic)
                             const double* pv = L.vals[sl];
 #pragma unroll
-                            for (int j = 0; j < EPT; j++) s += pv[j];
-                        } else chain_serial_global(s, buf, first + e * EPT, EPT, m);
+                            for (int j = 0; j < EPT; j++) sv += pv[j];
+                        } else chain_serial_global(sv, buf, first + e * EPT, EPT, m);
+                        sb = readfirstlane_u64(f2u(sv));
                     }
                     prev_end = e;
                 }
             }
-            if (lane == 0) L.s = s;
+            if (lane == 0) L.s = u2f(sb);
         }
         __syncthreads();
     }
@@ -944,16 +976,78 @@ __device__ double block_chain_sum(const double* __restrict__ buf, int m, int gua
 constexpr int TRK_THREADS = 1024;
 constexpr int TRK_GROUP = 16;   // arrival tickets in two levels: same-address device-scope atomics cost ~50 ns each
 constexpr int TRK_FLAG = 32 * 65;  // word of d.ticket that carries "chain of event # done"
+constexpr int TRK_BAD = 32 * 67;   // word of d.ticket: a sweep item did not find the cluster it expected
 
-__device__ __forceinline__ void chain_workgroup(const Dev& d, ChainLds<CH_EPT>& L) {
+constexpr int CH_SPLIT_FLAG = 32 * 66;  // word of d.ticket: "records of a split chain sum are waiting in d.chrec"
+
+// The chain sum in two launches: its data-parallel steps beside the tracking (k_track), its walk beside
+// the candidate choice (k_decide4) - the sum is due only before k_update touches the row sums again.
+// Only for launch sequences without scan kernels (a scan needs every row sum) and one super-chunk.
+// has_scan bit 1 = "do not split" (FNN_CHAIN_SPLIT=0).
+__device__ __forceinline__ bool chain_split_mode(const State* st, int has_scan) {
+    return has_scan == 0 && st->chain_m <= CH_SC;
+}
+
+__device__ __forceinline__ void chain_records_store(const ChainLds<CH_EPT>& L, uint64_t* rec) {
+    const int tid = threadIdx.x;
+    rec[CHREC_OWN + tid] = L.own[tid];
+    rec[CHREC_SC + tid] = L.sc[tid];
+    reinterpret_cast<int32_t*>(rec + CHREC_E)[tid] = L.E[tid];
+    reinterpret_cast<int32_t*>(rec + CHREC_FLAGS)[tid] = L.flags[tid];
+    reinterpret_cast<int32_t*>(rec + CHREC_SLOT)[tid] = L.slot[tid];
+    const int nv = min(L.slot_count, CH_NSLOT) * CH_EPT;
+    const double* v = &L.vals[0][0];
+    for (int i = tid; i < nv; i += CH_T) rec[CHREC_VALS + i] = f2u(v[i]);
+}
+__device__ __forceinline__ void chain_records_load(ChainLds<CH_EPT>& L, const uint64_t* rec) {
+    const int tid = threadIdx.x;
+    L.own[tid] = rec[CHREC_OWN + tid];
+    L.sc[tid] = rec[CHREC_SC + tid];
+    L.E[tid] = reinterpret_cast<const int32_t*>(rec + CHREC_E)[tid];
+    L.flags[tid] = reinterpret_cast<const int32_t*>(rec + CHREC_FLAGS)[tid];
+    L.slot[tid] = reinterpret_cast<const int32_t*>(rec + CHREC_SLOT)[tid];
+    double* v = &L.vals[0][0];
+    for (int i = tid; i < CH_NSLOT * CH_EPT; i += CH_T) v[i] = u2f(rec[CHREC_VALS + i]);
+    if (tid == 0) L.s = 0.0;
+}
+
+__device__ __forceinline__ void chain_deliver(const Dev& d, double usx) {
+    State* st = d.st;
+    d.Sx[st->chain_U] = usx;      // u.Sx and u.nbr.Sx (NetMakerOriginal.java:532, 535)
+    d.Sx[st->chain_U + 1] = usx;
+}
+
+__device__ __forceinline__ void chain_workgroup(const Dev& d, ChainLds<CH_EPT>& L, bool split = false) {
     State* st = d.st;
     if (!st->chain_pending) return;
+    if (split) {
+        block_chain_sum<CH_EPT, 1>(d.chain, st->chain_m, CH_GUARD_BITS, L, nullptr);
+        chain_records_store(L, d.chrec);
+        __syncthreads();
+        if (threadIdx.x == 0) { __threadfence(); d.ticket[CH_SPLIT_FLAG] = 1u; }
+        return;
+    }
     const double usx = block_chain_sum<CH_EPT>(d.chain, st->chain_m, CH_GUARD_BITS, L, nullptr);
     if (threadIdx.x == 0) {
-        d.Sx[st->chain_U] = usx;      // u.Sx and u.nbr.Sx (NetMakerOriginal.java:532, 535)
-        d.Sx[st->chain_U + 1] = usx;
+        chain_deliver(d, usx);
+        d.ticket[CH_SPLIT_FLAG] = 0u;
         __threadfence();
         __hip_atomic_store(d.ticket + TRK_FLAG, (unsigned)st->n_events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// second half of a split chain sum (k_decide4's second workgroup)
+__device__ __forceinline__ void chain_walk_workgroup(const Dev& d, ChainLds<CH_EPT>& L) {
+    if (d.ticket[CH_SPLIT_FLAG] != 1u) return;
+    const State* st = d.st;
+    chain_records_load(L, d.chrec);
+    const double usx = block_chain_sum<CH_EPT, 2>(d.chain, st->chain_m, CH_GUARD_BITS, L, nullptr);
+    if (threadIdx.x == 0) {
+        chain_deliver(d, usx);
+        d.ticket[CH_SPLIT_FLAG] = 0u;
+        // (workgroup 0 copies the whole control block in and out, except when it has nothing to do:
+        //  only then may this workgroup write to it)
+        if (!st->ev_active || st->ev_finish || st->stall) d.st->chain_pending = 0;
     }
 }
 
@@ -982,12 +1076,14 @@ constexpr int TRK_REC_U = 1024;  // offset of the swept-pair records in d.recs
 
 __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed, int has_scan) {
     __shared__ ChainLds<CH_EPT> L;
-    __shared__ Cand sh[TRK_THREADS / 64];
+    __shared__ Cand sh[TRK_THREADS / 64], shu[TRK_THREADS / 64];
     __shared__ int lastflag;
     __shared__ double shs[2];
     State* st = d.st;
+    const bool split = chain_split_mode(st, has_scan);
+    has_scan &= 1;
     if (blockIdx.x == 0) {  // the chain workgroup
-        chain_workgroup(d, L);
+        chain_workgroup(d, L, split);
         return;
     }
     const int wg = (int)blockIdx.x - 1, G = (int)gridDim.x - 1;
@@ -1008,48 +1104,62 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     }
     TrackArgs ta = track_args(*st);
     const int64_t items = track_item_count(ta);
-    // the swept cluster's exact row sum is being computed by workgroup 0: tree-ordered sum first
+    // The swept cluster's exact row sum is being computed by workgroup 0: the sweep runs on the tree-ordered
+    // sum of k_update's partials, which are fetched now and summed after the tracked pairs (their loads
+    // overlap).  (More than one unswept cluster is not expected: the window ends.)
     double eps_u = 0.0;
+    bool giveup = false;  // the window cannot serve this event: it ends here (as after a failed certification)
     const bool pending = st->chain_pending != 0 && ta.nf > ta.nf0;
-    if (pending) {
-        const bool simple = (ta.nf - ta.nf0 == 1) && d.islot[d.fresh[2 * (ta.nf - 1)]] == st->chain_U;
-        if (!simple) {
-            // (not expected: more than one unswept cluster) wait for the exact sum before sweeping
-            if (threadIdx.x == 0) {
-                const unsigned want = (unsigned)st->n_events;
-                long spins = 0;
-                while (__hip_atomic_load(d.ticket + TRK_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want && ++spins < 20000000) __builtin_amdgcn_s_sleep(2);
-                __threadfence();
-            }
-            __syncthreads();
-        } else {
-            if (threadIdx.x < 64) {
-                double su = 0.0, sa = 0.0;
-                const int np = st->upart_n;
-                for (int b = threadIdx.x; b < np; b += 64) { su += d.upart[2 * b]; sa += d.upart[2 * b + 1]; }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) { su += __shfl_down(su, off, 64); sa += __shfl_down(sa, off, 64); }
-                if (threadIdx.x == 0) { shs[0] = su; shs[1] = sa; }
-            }
-            __syncthreads();
-            ta.approx = 1;
-            ta.sxu = shs[0];
-            // both the sequential and the tree order are within gamma_m sum|terms| of the exact sum
-            eps_u = 4.0 * ((double)ta.m + 8.0) * 1.1102230246251565e-16 * shs[1];
-        }
+    if (pending && ta.nf - ta.nf0 != 1) giveup = true;
+    const bool approx = pending && !giveup;
+    double2 up0 = make_double2(0.0, 0.0), up1 = up0, up2 = up0;
+    const int npart = approx ? st->upart_n : 0;
+    if (threadIdx.x < 64) {
+        const double2* up = reinterpret_cast<const double2*>(d.upart);
+        if ((int)threadIdx.x < npart) up0 = up[threadIdx.x];
+        if ((int)threadIdx.x + 64 < npart) up1 = up[threadIdx.x + 64];
+        if ((int)threadIdx.x + 128 < npart) up2 = up[threadIdx.x + 128];
     }
     Cand best, bestu;
     best.q = inf_f64();
     best.key = ~0ULL;
     bestu = best;
-    for (int64_t it = (int64_t)wg * TRK_THREADS + threadIdx.x; it < items; it += (int64_t)G * TRK_THREADS)
-        track_item(d, it, ta, best, bestu);
-    best = block_reduce<TRK_THREADS / 64>(best, sh);
-    if (threadIdx.x == 0) d.recs[wg] = best;
-    if (ta.approx) {
+    const int64_t stride = (int64_t)G * TRK_THREADS, start = (int64_t)wg * TRK_THREADS + threadIdx.x;
+    for (int64_t it = start; it < ta.np; it += stride) track_pair_item(d, it, ta, best);
+    if (approx) {
+        if (threadIdx.x < 64) {
+            double su = (up0.x + up1.x) + up2.x, sa = (up0.y + up1.y) + up2.y;
+            for (int b = threadIdx.x + 192; b < npart; b += 64) { su += d.upart[2 * b]; sa += d.upart[2 * b + 1]; }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { su += __shfl_down(su, off, 64); sa += __shfl_down(sa, off, 64); }
+            if (threadIdx.x == 0) { shs[0] = su; shs[1] = sa; }
+        }
         __syncthreads();
-        bestu = block_reduce<TRK_THREADS / 64>(bestu, sh);
-        if (threadIdx.x == 0) d.recs[TRK_REC_U + wg] = bestu;
+        ta.approx = 1;
+        ta.usl = st->chain_U;
+        ta.sxu = shs[0];
+        // both the sequential and the tree order are within gamma_m sum|terms| of the exact sum
+        eps_u = 4.0 * ((double)ta.m + 8.0) * 1.1102230246251565e-16 * shs[1];
+    }
+    bool swept_ok = true;
+    if (!giveup)
+        for (int64_t r = start; r < items - ta.np; r += stride) swept_ok = track_sweep_item(d, r, ta, best, bestu) && swept_ok;
+    if (!swept_ok) atomicOr(d.ticket + TRK_BAD, 1u);  // (not expected: the swept cluster is not the chain's)
+    // both minima in one pass: wave reduction, one barrier, thread 0 folds the waves
+    {
+        best = wave_reduce(best);
+        if (ta.approx) bestu = wave_reduce(bestu);
+        const int lane_ = threadIdx.x & 63, w_ = threadIdx.x >> 6;
+        if (lane_ == 0) { sh[w_] = best; shu[w_] = bestu; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < TRK_THREADS / 64; k++) {
+                if (cand_better(sh[k], best)) best = sh[k];
+                if (ta.approx && cand_better(shu[k], bestu)) bestu = shu[k];
+            }
+            d.recs[wg] = best;
+            if (ta.approx) d.recs[TRK_REC_U + wg] = bestu;
+        }
     }
     if (threadIdx.x == 0) {
         __threadfence();
@@ -1067,32 +1177,46 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     __syncthreads();
     if (!lastflag) return;
     __threadfence();
-    auto reduce_recs = [&](const Cand* recs) {
-        Cand b;
+    // the records of all workgroups, both sets at once, by the first wave
+    if (threadIdx.x < 64) {
+        Cand b, bu;
         b.q = inf_f64();
         b.key = ~0ULL;
-        for (int i = threadIdx.x; i < G; i += TRK_THREADS) {
+        bu = b;
+        for (int i = threadIdx.x; i < G; i += 64) {
             Cand c;
-            c.q = __builtin_nontemporal_load(&recs[i].q);
-            c.key = __builtin_nontemporal_load(&recs[i].key);
+            c.q = __builtin_nontemporal_load(&d.recs[i].q);
+            c.key = __builtin_nontemporal_load(&d.recs[i].key);
             if (cand_better(c, b)) b = c;
+            if (ta.approx) {
+                c.q = __builtin_nontemporal_load(&d.recs[TRK_REC_U + i].q);
+                c.key = __builtin_nontemporal_load(&d.recs[TRK_REC_U + i].key);
+                if (cand_better(c, bu)) bu = c;
+            }
         }
-        __syncthreads();
-        b = block_reduce<TRK_THREADS / 64>(b, sh);
-        if (threadIdx.x == 0) sh[0] = b;
-        __syncthreads();
-        b = sh[0];
-        __syncthreads();
-        return b;
-    };
-    best = reduce_recs(d.recs);
-    if (ta.approx) {
-        bestu = reduce_recs(d.recs + TRK_REC_U);
+        b = wave_reduce(b);
+        if (ta.approx) bu = wave_reduce(bu);
+        if (threadIdx.x == 0) {
+            sh[0] = b;
+            shu[0] = bu;
+            if (__hip_atomic_load(d.ticket + TRK_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                d.ticket[TRK_BAD] = 0u;
+                lastflag = 2;
+            }
+        }
+    }
+    __syncthreads();
+    best = sh[0];
+    bestu = shu[0];
+    if (lastflag == 2) giveup = true;
+    __syncthreads();
+    if (ta.approx && !giveup) {
         // |Q~ - Q| <= eps_u + the roundings of (c-2) D - Sp - Sq, each <= 2^-53 of a term <= (c + 2n) Dmax
         const double dmax = __builtin_bit_cast(double, st->dmax_bits);
         const double margin = 2.0 * eps_u + 192.0 * 1.1102230246251565e-16 * ((double)st->n + 4.0) * dmax + 1e-300;
         const bool certain = (bestu.q - margin > best.q) || (bestu.q == inf_f64());
-        if (!certain) {
+        if (!certain && split) giveup = true;  // (the exact sum comes only after this launch: the event scans instead)
+        else if (!certain) {
             // a swept pair may be the minimum: wait for the chain workgroup, sweep again with the exact sum
             if (threadIdx.x == 0) {
                 const unsigned want = (unsigned)st->n_events;
@@ -1117,9 +1241,11 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         }
         // certain: every swept pair's exact Q lies strictly above best.q, so best wins as it stands
     }
+    if (giveup) { best.q = inf_f64(); best.key = ~0ULL; }
     if (threadIdx.x == 0) {
         *d.ticket = 0u;
         st->ev_timed = timed;
+        if (giveup) st->n_sweep_waits++;
         la_track_done(d, best, ta);
         st->stall = (!st->la_hit && !has_scan) ? 1 : 0;
         if (st->stall) st->n_stalled++;
@@ -1218,6 +1344,10 @@ __global__ __launch_bounds__(CH_T) void k_decide4(Dev d, int nparts) {
     __shared__ ChainLds<CH_EPT> L;
     __shared__ State lst;
     __shared__ double red[8];
+    if (blockIdx.x == 1) {  // the walk of a chain sum that k_track's chain workgroup began
+        chain_walk_workgroup(d, L);
+        return;
+    }
     decide4_body(d, nparts, L, lst, red);
 }
 
@@ -1275,7 +1405,7 @@ __global__ __launch_bounds__(CH_T) void k_chain_flush(Dev d) {
     __shared__ ChainLds<CH_EPT> L;
     chain_workgroup(d, L);
     __syncthreads();
-    if (threadIdx.x == 0) d.st->chain_pending = 0;
+    if (threadIdx.x == 0) { d.st->chain_pending = 0; d.ticket[CH_SPLIT_FLAG] = 0u; }
 }
 
 // ------------------------------------------------------------------ k_finalize
@@ -1644,6 +1774,18 @@ __global__ __launch_bounds__(CH_T) void k_test_chain(const double* buf, int m, i
     if (threadIdx.x == 0) *out = r;
 }
 
+// the same through the split form: steps 1-3, records to memory and back, step 4 (m <= CH_SC)
+__global__ __launch_bounds__(CH_T) void k_test_chain_split(const double* buf, int m, int guard_bits, double* out, uint64_t* rec) {
+    __shared__ ChainLds<CH_EPT> L;
+    block_chain_sum<CH_EPT, 1>(buf, m, guard_bits, L, nullptr);
+    chain_records_store(L, rec);
+    __threadfence();
+    __syncthreads();
+    chain_records_load(L, rec);
+    double r = block_chain_sum<CH_EPT, 2>(buf, m, guard_bits, L, nullptr);
+    if (threadIdx.x == 0) *out = r;
+}
+
 // ------------------------------------------------------------------ setup kernels
 __global__ __launch_bounds__(256) void k_init(Dev d) { init_thread(d, blockIdx.x * 256 + threadIdx.x); }
 
@@ -1727,8 +1869,8 @@ struct HipBackend {
     static constexpr int64_t kRowPad = SCAN_TH;
     static constexpr int64_t kColPad = SCR_TW;   // whole screening tiles (and scan tiles) stay in bounds
     // below this many taxa the fp32 copy is not even allocated (FNN_SCREEN_MIN_N, tests)
-    int32_t screen_min_n() const { if (const char* e = std::getenv("FNN_SCREEN_MIN_N")) { int v = std::atoi(e); if (v >= 8) return v; } return 8192; }
-    int screen_min_m = 4096;                     // events with fewer live nodes use the plain scan (FNN_SCREEN_MIN_M)
+    int32_t screen_min_n() const { if (const char* e = std::getenv("FNN_SCREEN_MIN_N")) { int v = std::atoi(e); if (v >= 8) return v; } return 4096; }
+    int screen_min_m = 2048;                     // events with fewer live nodes use the plain scan (FNN_SCREEN_MIN_M)
     hipError_t last = hipSuccess;
     hipStream_t stream = nullptr;
     int device = 0;
@@ -1759,6 +1901,7 @@ struct HipBackend {
                              // correct, but slower than one launch sequence per event)
     int track_grid = 64;    // track workgroups of k_track (FNN_TRACK_GRID); one more computes the pending chain
     bool skip_unsched_scans = true; // FNN_UNSCHED_SCANS=1: keep the (mostly idle) scan kernels in unscheduled events
+    bool chain_split = false;  // the deferred sum in two launches (steps 1-3 in k_track, the walk in k_decide4): measured slower
     bool defer_chain = false; // set by the engine: k_update closes the event, the exact u.Sx sum runs inside the next k_track
     bool scan_nt = true;    // non-temporal matrix loads in the scan (FNN_SCAN_NT)
 
@@ -1815,6 +1958,7 @@ struct HipBackend {
         if (const char* e = std::getenv("FNN_EVENTS_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 63) events_grid = v; }
         if (const char* e = std::getenv("FNN_PERSISTENT")) persistent = std::atoi(e) != 0;
         if (const char* e = std::getenv("FNN_EMIT_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) emit_grid = v; }
+        if (const char* e = std::getenv("FNN_CHAIN_SPLIT")) chain_split = std::atoi(e) != 0;
         if (const char* e = std::getenv("FNN_TRACK_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 1024) track_grid = v; }
         if (const char* e = std::getenv("FNN_SCREEN_MIN_M")) { int v = std::atoi(e); if (v >= 8) screen_min_m = v; }
         opened = true;
@@ -1970,7 +2114,7 @@ struct HipBackend {
         //  device stalls - this and the following such events do nothing - until the host, which
         //  looks at the state every batch, launches an event with a scan)
         const bool has_scan = sched || !screen || !skip_unsched_scans;
-        if (d.la) hipLaunchKernelGGL(k_track, dim3(track_grid + 1), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0, has_scan ? 1 : 0);
+        if (d.la) hipLaunchKernelGGL(k_track, dim3(track_grid + 1), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0, (has_scan ? 1 : 0) | (chain_split ? 0 : 2));
         if (timed) { e0 = next_event(); e1 = next_event(); ev_kind.push_back(screen ? 1 : 0); }
         int nrecs;
         if (screen && !has_scan) nrecs = RES_BLOCKS;  // (k_rx_fill reads one record, the window's)
@@ -2005,7 +2149,7 @@ struct HipBackend {
     void enqueue_rest(const Dev& d, int32_t m_bound, const Cand* src, int nrecs) {
         dim3 g1 = grid1(m_bound);
         hipLaunchKernelGGL(k_rx_fill, g1, dim3(256), 0, stream, d, src, nrecs);
-        hipLaunchKernelGGL(k_decide4, dim3(1), dim3(CH_T), 0, stream, d, (int)g1.x);
+        hipLaunchKernelGGL(k_decide4, dim3(defer_chain && chain_split ? 2 : 1), dim3(CH_T), 0, stream, d, (int)g1.x);
         hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d, defer_chain ? 1 : 0);
         if (!defer_chain) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d);
     }
@@ -2273,8 +2417,23 @@ int32_t fnn_test_chain_sum(int32_t device, const double* host_buf, int32_t m, in
     fnn::ChainStats hs{0, 0, 0, 0};
     if (e == hipSuccess) e = hipMemcpy(out, dout, 8, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(&hs, dst, sizeof(hs), hipMemcpyDeviceToHost);
+    bool split_differs = false;
+    if (e == hipSuccess && m <= fnn::CH_SC && !std::getenv("FNN_CHAIN_STOP")) {
+        // the two-launch form of the engine (records through memory) must give the same bits
+        uint64_t* drec = nullptr;
+        double two = 0.0;
+        if (hipMalloc((void**)&drec, sizeof(uint64_t) * fnn::CHREC_WORDS) != hipSuccess) e = hipErrorOutOfMemory;
+        else {
+            hipLaunchKernelGGL(fnn::k_test_chain_split, dim3(1), dim3(fnn::CH_T), 0, 0, dbuf, m, guard_bits, dout, drec);
+            e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipMemcpy(&two, dout, 8, hipMemcpyDeviceToHost);
+            split_differs = e == hipSuccess && std::memcmp(&two, out, 8) != 0;
+            (void)hipFree(drec);
+        }
+    }
     (void)hipFree(dbuf); (void)hipFree(dout); (void)hipFree(dst);
     if (e != hipSuccess) return fnn::fail(FNN_EHIP, std::string("fnn_test_chain_sum: ") + hipGetErrorString(e));
+    if (split_differs) return fnn::fail(FNN_ESTATE, "fnn_test_chain_sum: the split form of the sum gave different bits");
     if (stats4) { stats4[0] = hs.runs; stats4[1] = hs.mixed; stats4[2] = hs.run_fail; stats4[3] = hs.thread_fail; }
     return FNN_OK;
 }

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../fastneighbornet_amd/csrc/fnn_engine.h"
@@ -400,11 +401,21 @@ static double chain_model(const double* buf, int m, int ept, int guard_bits, fnn
             Mono mt = mono_identity();
             if (ok) {
                 const double invu = inv_ulp(Et);
-                for (int i = 0; i < ept; i++) {
-                    int idx = base + t * ept + i;
-                    double a = idx < m ? buf[idx] : 0.0;
-                    if (!chain_accumulate(a, invu, mt)) { ok = false; break; }
-                }
+                auto chunk = [&](auto tag) {  // the GPU's chunk: addends handled independently, increments summed as a tree
+                    constexpr int N = decltype(tag)::value;
+                    double a[N];
+                    for (int i = 0; i < N; i++) a[i] = (base + t * ept + i < m) ? buf[base + t * ept + i] : 0.0;
+                    return chain_chunk<N>(a, invu, mt);
+                };
+                if (ept == 32) ok = chunk(std::integral_constant<int, 32>());
+                else if (ept == 16) ok = chunk(std::integral_constant<int, 16>());
+                else if (ept == 8) ok = chunk(std::integral_constant<int, 8>());
+                else
+                    for (int i = 0; i < ept; i++) {
+                        int idx = base + t * ept + i;
+                        double a = idx < m ? buf[idx] : 0.0;
+                        if (!chain_accumulate(a, invu, mt)) { ok = false; break; }
+                    }
             }
             pure[t] = ok;
             E[t] = Et;
@@ -423,11 +434,21 @@ static double chain_model(const double* buf, int m, int ept, int guard_bits, fnn
                 int e = t;
                 Mono run = own[t];
                 while (e + 1 < (w + 1) * 64 && pure[e + 1] && E[e + 1] == E[t]) { e++; run = mono_compose(run, own[e]); }
-                if (mono_apply(s, E[t], run)) st.runs++;
+                // (the GPU walker applies the automata on the bit pattern; both forms must agree)
+                double s2 = s;
+                const bool okb = mono_apply_bits(s2, E[t], mono_inc_bits(run.i0), mono_inc_bits(run.i1));
+                const bool okf = mono_apply(s, E[t], run);
+                if (okb != okf || (okf && f2u(s2) != f2u(s))) st.thread_fail += 1000000;  // would show in the tests
+                if (okf) st.runs++;
                 else {
                     st.run_fail++;
-                    for (int j = t; j <= e; j++)
-                        if (!mono_apply(s, E[j], own[j])) { st.thread_fail++; serial(j); }
+                    for (int j = t; j <= e; j++) {
+                        double sj = s;
+                        const bool ob = mono_apply_bits(sj, E[j], mono_inc_bits(own[j].i0), mono_inc_bits(own[j].i1));
+                        const bool of = mono_apply(s, E[j], own[j]);
+                        if (ob != of || (of && f2u(sj) != f2u(s))) st.thread_fail += 1000000;
+                        if (!of) { st.thread_fail++; serial(j); }
+                    }
                 }
                 t = e + 1;
             }

@@ -60,5 +60,6 @@ def test_chain_model_is_bit_exact(emu_api, ept, guard):
         assert a == b or (np.isnan(got) and np.isnan(ref)), (name, got, ref, list(st))
         seen += np.array(list(st))
     assert seen[0] > 0 and seen[1] > 0  # composed runs and one-by-one chunks both occurred
+    assert seen[3] < 1000000  # the integer form of the run update agreed with the fp64 form everywhere
     if guard == 0:
         assert seen[2] > 0 and seen[3] > 0  # mispredicted runs / threads were rejected and redone one by one

@@ -14,3 +14,5 @@ for m in (4096, 16384, 32768):
         out = C.c_double(); st = (C.c_int32 * 4)()
         print(f"m={m} stop_after={stop}:", flush=True)
         a.check(a.test_chain_sum(0, v.ctypes.data_as(C.POINTER(C.c_double)), m, 1, 32, C.byref(out), st))
+        if stop == 0:
+            print(f"[fnn] stats: runs={st[0]} mixed={st[1]} run_fail={st[2]} thread_fail={st[3]}", flush=True)
