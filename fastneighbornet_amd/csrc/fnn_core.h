@@ -731,20 +731,24 @@ FNN_HD void emit(State& st, int32_t kind, int32_t a, int32_t b, int32_t c, int32
     o.flag = flag;
 }
 
+// (values that were just stored are kept in locals, not read back: on the GPU every read-after-write
+//  through memory is one more dependent round trip of the single planning thread)
 FNN_HD void swap_slots(const Dev& d, int32_t s1, int32_t s2) {
-    int32_t t = d.sid[s1]; d.sid[s1] = d.sid[s2]; d.sid[s2] = t;
-    t = d.spos[s1]; d.spos[s1] = d.spos[s2]; d.spos[s2] = t;
-    d.pslot[d.spos[s1]] = s1;
-    d.pslot[d.spos[s2]] = s2;
-    if (d.islot) { d.islot[d.sid[s1]] = s1; d.islot[d.sid[s2]] = s2; }
+    const int32_t id1 = d.sid[s1], id2 = d.sid[s2], p1 = d.spos[s1], p2 = d.spos[s2];
+    d.sid[s1] = id2; d.sid[s2] = id1;
+    d.spos[s1] = p2; d.spos[s2] = p1;
+    d.pslot[p2] = s1;
+    d.pslot[p1] = s2;
+    if (d.islot) { d.islot[id2] = s1; d.islot[id1] = s2; }
     emit(*d.st, OP_SWAP, s1, s2, 0, 0, 0, 0);
 }
 
 FNN_HD void move_slot(const Dev& d, int32_t src, int32_t dst) {
-    d.sid[dst] = d.sid[src];
-    d.spos[dst] = d.spos[src];
-    d.pslot[d.spos[dst]] = dst;
-    if (d.islot) d.islot[d.sid[dst]] = dst;
+    const int32_t id = d.sid[src], ps = d.spos[src];
+    d.sid[dst] = id;
+    d.spos[dst] = ps;
+    d.pslot[ps] = dst;
+    if (d.islot) d.islot[id] = dst;
     emit(*d.st, OP_MOVE, src, dst, 0, 0, 0, 0);
 }
 
@@ -766,12 +770,15 @@ FNN_HD void agg3_plan(const Dev& d, int32_t X, int32_t Y, int32_t Z, int32_t U, 
     d.pslot[pz] = V;
     // remove y: netNodes[y.pos] = netNodes[mc-1] (:641-643)
     int32_t last = d.pslot[mc - 1];
+    int32_t pu = px, pv = pz;  // = spos[U], spos[V] as they stand in memory
     if (py != mc - 1) {
         d.spos[last] = py;
         d.pslot[py] = last;
+        if (last == U) pu = py;
+        if (last == V) pv = py;
     }
     d.pslot[mc - 1] = -1;
-    emit(st, OP_AGG3, X, Y, Z, U, V, d.spos[U] < d.spos[V] ? 1 : 0);
+    emit(st, OP_AGG3, X, Y, Z, U, V, pu < pv ? 1 : 0);
 }
 
 // Symbolic replay of the event's micro-ops: which old rows does every involved slot hold
@@ -985,7 +992,9 @@ FNN_HD bool rx_certify(const Dev& d, const double rxa[4], const double rxs[4]) {
     return true;
 }
 
-FNN_HD void decide(const Dev& d, const double rx[4]) {
+// decide = decide_plan (candidate choice, integer side of the merge, micro-ops) + build_targets
+// (symbolic replay); the GPU runs the second part lane-parallel (fnn_hip.hip: build_targets_wave)
+FNN_HD void decide_plan(const Dev& d, const double rx[4]) {
     State& st = *d.st;
     Event& cur = st.cur;
     int32_t a = st.sa, ap = st.sap, b = st.sb, bp = st.sbp;
@@ -1001,25 +1010,27 @@ FNN_HD void decide(const Dev& d, const double rx[4]) {
     int32_t xn = x < twoP ? (x ^ 1) : -1;
     int32_t yn = y < twoP ? (y ^ 1) : -1;
     st.xs = x; st.ys = y;
-    cur.x_id = d.sid[x];
-    cur.y_id = d.sid[y];
+    const int32_t idx = d.sid[x], idy = d.sid[y];
+    cur.x_id = idx;
+    cur.y_id = idy;
     int32_t m = st.m, P = st.P, nn = st.num_nodes;
 
     if (xn < 0 && yn < 0) {
         // agg2way (:570-577): both isolated. New two-node cluster goes to slots 2P, 2P+1,
         // smaller id in the even slot.
         cur.kind = KIND_2WAY;
-        int32_t lo = d.sid[x] < d.sid[y] ? x : y;
+        int32_t lo = idx < idy ? x : y;
         int32_t hi = (lo == x) ? y : x;
-        cur.u_id = d.sid[x];  // agg2way returns x
+        cur.u_id = idx;  // agg2way returns x
         int32_t t0 = 2 * P, t1 = 2 * P + 1;
         if (lo != t0) { swap_slots(d, lo, t0); if (hi == t0) hi = lo; }
         if (hi != t1) swap_slots(d, hi, t1);
         st.P = P + 1;
         st.c -= 1;
         st.U = t0;  // u = x, and x always has the smaller id (Cx.id < Cy.id, :376-380)
-        if (d.sid[t0] != cur.u_id) st.error = 3;
-        la_note_cluster(d, st, d.sid[t0], d.sid[t1]);
+        // slot t0 now holds the smaller id, t1 the larger one
+        if ((idx < idy ? idx : idy) != cur.u_id) st.error = 3;
+        la_note_cluster(d, st, idx < idy ? idx : idy, idx < idy ? idy : idx);
     } else if (xn < 0 || yn < 0) {
         // agg3way(x, y, y.nbr) (:466) or agg3way(y, x, x.nbr) (:476)
         cur.kind = KIND_3WAY;
@@ -1063,6 +1074,9 @@ FNN_HD void decide(const Dev& d, const double rx[4]) {
         st.U = U;
         la_note_cluster(d, st, nn + 3, nn + 4);
     }
+}
+FNN_HD void decide(const Dev& d, const double rx[4]) {
+    decide_plan(d, rx);
     build_targets(d);
 }
 

@@ -1259,6 +1259,104 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
 // ComputeRx sums are evaluated exactly (block_chain_sum) first.
 // The plan is built by one thread on an LDS copy of the control block (dozens of dependent
 // accesses at LDS instead of L2 latency) that the workgroup copies in and out.
+// build_targets (fnn_core.h) by the 64 lanes of one wave: lane i holds involved slot S[i] and its
+// symbolic row; searches are ballots, the micro-ops are replayed with wave-uniform control and
+// readlane / lane-conditional moves.  (One thread doing this through the LDS copy of the control
+// block was ~150 dependent LDS accesses = 6 us of k_decide4's 14.)  Same results, field by field.
+__device__ __forceinline__ void build_targets_wave(State& st) {
+    const int lane = threadIdx.x & 63;
+    const int nops = __builtin_amdgcn_readfirstlane(st.nops);
+    const int U = __builtin_amdgcn_readfirstlane(st.U), m = __builtin_amdgcn_readfirstlane(st.m);
+    const int ev_finish = __builtin_amdgcn_readfirstlane(st.ev_finish);
+    static_assert(sizeof(Op) == 32, "Op is read as 8 dwords");
+    const int opw = lane < 8 * MAX_OPS ? reinterpret_cast<const int32_t*>(st.ops)[lane] : 0;
+    int err = 0;
+    int Sl = -1, nS = 0;
+    auto add_slot = [&](int sl) {
+        if (__ballot(lane < nS && Sl == sl)) return;
+        if (nS >= MAX_S) { err = 5; return; }
+        if (lane == nS) Sl = sl;
+        nS++;
+    };
+    add_slot(U);
+    add_slot(U + 1);
+    for (int i = 0; i < nops; i++) {
+        const int kind = __builtin_amdgcn_readlane(opw, 8 * i);
+        add_slot(__builtin_amdgcn_readlane(opw, 8 * i + 1));
+        add_slot(__builtin_amdgcn_readlane(opw, 8 * i + 2));
+        if (kind == OP_AGG3) {
+            add_slot(__builtin_amdgcn_readlane(opw, 8 * i + 3));
+            add_slot(__builtin_amdgcn_readlane(opw, 8 * i + 4));
+            add_slot(__builtin_amdgcn_readlane(opw, 8 * i + 5));
+        }
+    }
+    struct Sym { int kind, a, b, c, d; };
+    int sk = T_COPY, sa = Sl, sb = -1, sc = -1, sd = -1;  // this lane's symbolic row
+    auto idx = [&](int sl) {
+        const unsigned long long hit = __ballot(lane < nS && Sl == sl);
+        return hit ? (int)__builtin_ctzll(hit) : 0;
+    };
+    auto get = [&](int i) {
+        Sym t;
+        t.kind = __builtin_amdgcn_readlane(sk, i); t.a = __builtin_amdgcn_readlane(sa, i);
+        t.b = __builtin_amdgcn_readlane(sb, i); t.c = __builtin_amdgcn_readlane(sc, i);
+        t.d = __builtin_amdgcn_readlane(sd, i);
+        return t;
+    };
+    auto put = [&](int i, const Sym& t) {
+        if (lane == i) { sk = t.kind; sa = t.a; sb = t.b; sc = t.c; sd = t.d; }
+    };
+    auto comb = [&](const Sym& A, const Sym& B) {  // value (2/3)*A + B/3
+        Sym r;
+        r.kind = T_COPY; r.a = r.b = r.c = r.d = -1;
+        if (A.kind == T_COPY && B.kind == T_COPY) { r.kind = T_L1; r.a = A.a; r.b = B.a; }
+        else if (A.kind == T_L1 && B.kind == T_L1 && A.b == B.b) { r.kind = T_L2U; r.a = A.a; r.b = A.b; r.c = B.a; }
+        else if (A.kind == T_COPY && B.kind == T_L1) { r.kind = T_L2V; r.d = A.a; r.c = B.a; r.b = B.b; }
+        else err = 6;
+        return r;
+    };
+    for (int i = 0; i < nops; i++) {
+        const int kind = __builtin_amdgcn_readlane(opw, 8 * i);
+        const int oa = __builtin_amdgcn_readlane(opw, 8 * i + 1), ob = __builtin_amdgcn_readlane(opw, 8 * i + 2);
+        if (kind == OP_SWAP) {
+            const int ia = idx(oa), ib = idx(ob);
+            const Sym ta = get(ia), tb = get(ib);
+            put(ia, tb);
+            put(ib, ta);
+        } else if (kind == OP_MOVE) {
+            const Sym t = get(idx(oa));
+            put(idx(ob), t);
+        } else if (kind == OP_AGG3) {
+            const int oc = __builtin_amdgcn_readlane(opw, 8 * i + 3), od = __builtin_amdgcn_readlane(opw, 8 * i + 4),
+                      oe = __builtin_amdgcn_readlane(opw, 8 * i + 5);
+            const Sym sx = get(idx(oa)), sy = get(idx(ob)), sz = get(idx(oc));
+            const Sym nu = comb(sx, sy), nv = comb(sz, sy);
+            put(idx(od), nu);
+            put(idx(oe), nv);
+        }
+    }
+    const bool isUV = (Sl == U || Sl == U + 1);
+    const bool keep = lane < nS && !(Sl >= m && !ev_finish) && !(!isUV && sk == T_COPY && sa == Sl);
+    const unsigned long long km = __ballot(keep);
+    const int pos = __builtin_popcountll(km & ((1ULL << lane) - 1ULL));
+    const int ntgt = __builtin_popcountll(km);
+    if (keep && pos < MAX_TGT) {
+        Tgt t;
+        t.dst = Sl; t.kind = sk; t.a = sa; t.b = sb; t.c = sc; t.d = sd;
+        st.tgt[pos] = t;
+    }
+    if (lane < nS) st.S[lane] = Sl;
+    const unsigned long long um = __ballot(keep && Sl == U), vm = __ballot(keep && Sl == U + 1);
+    if (lane == 0) {
+        st.nS = nS;
+        st.ntgt = ntgt < MAX_TGT ? ntgt : MAX_TGT;
+        st.tU = um ? __builtin_popcountll(km & ((1ULL << __builtin_ctzll(um)) - 1ULL)) : -1;
+        st.tV = vm ? __builtin_popcountll(km & ((1ULL << __builtin_ctzll(vm)) - 1ULL)) : -1;
+        if (ntgt > MAX_TGT) st.error = 7;
+        else if (err) st.error = err;
+    }
+}
+
 __device__ __forceinline__ void decide_on_lds_copy(const Dev& d, State& lst, const double r_in[4], bool use_r,
                                                    int certified) {
     State* gst = d.st;
@@ -1276,8 +1374,10 @@ __device__ __forceinline__ void decide_on_lds_copy(const Dev& d, State& lst, con
         double r[4] = {0.0, 0.0, 0.0, 0.0};
         if (use_r) { r[0] = r_in[0]; r[1] = r_in[1]; r[2] = r_in[2]; r[3] = r_in[3]; }
         if (lst.need_rx) { if (certified) lst.n_rx_certified++; else lst.n_rx_exact++; }
-        decide(dl, r);
+        decide_plan(dl, r);
     }
+    __syncthreads();
+    if (threadIdx.x < 64) build_targets_wave(lst);
     __syncthreads();
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(&lst);
