@@ -49,7 +49,7 @@ class Engine {
     std::vector<fnn_event> events;  // trajectory of the last run
     std::vector<Agg3Rec> agglog;
     int32_t last3[3] = {0, 0, 0};
-    int32_t batch = 32;    // events enqueued between host round trips in run()
+    int32_t batch = 64;    // events enqueued between host round trips in run()
     int64_t ev_counter = 0;  // events enqueued since begin(): drives the schedule of the lookahead windows' base scans
     int64_t sched_at = 0;    // event count at which the host expects the open window to have served its K events
     // several GPUs: 0 = single, 1 = RCCL all-gather on the stream, 2 = host callback (tests)
