@@ -1461,6 +1461,15 @@ __global__ __launch_bounds__(256) void k_update(Dev d, int defer) {
     double dsum = 0.0, dabs = 0.0;
     const bool special = blockIdx.x == gridDim.x - 1;
     if (special) {
+        // the close of the event does not depend on the update (and nothing in the update reads what it
+        // writes): its round trips run beside the phases, in the last wave
+        if (defer && threadIdx.x == 255) {
+            st->upart_n = (int)gridDim.x;
+            st->chain_m = st->m;
+            st->chain_U = st->U;
+            if (!st->ev_finish) st->chain_pending = 1;
+            close_event(d);
+        }
         const int nph = update_special_phases(*st);
         for (int ph = 0; ph < nph; ph++) {
             const double v = update_special(d, ph, (int)threadIdx.x);
@@ -1486,16 +1495,10 @@ __global__ __launch_bounds__(256) void k_update(Dev d, int defer) {
     if (threadIdx.x == 0) {
         d.upart[2 * blockIdx.x] = ((shp[0][0] + shp[1][0]) + shp[2][0]) + shp[3][0];
         d.upart[2 * blockIdx.x + 1] = ((shp[0][1] + shp[1][1]) + shp[2][1]) + shp[3][1];
-        if (special) {
-            st->upart_n = (int)gridDim.x;
-            st->chain_m = st->m;
-            st->chain_U = st->U;
-            if (st->ev_finish) {  // special finish: u, v keep the default Sx (NetNode.java:15); nothing to sum
-                d.Sx[st->U] = 0.0;
-                d.Sx[st->U + 1] = 0.0;
-                st->chain_pending = 0;
-            } else st->chain_pending = 1;
-            close_event(d);
+        if (special && st->ev_finish) {  // special finish: u, v keep the default Sx (NetNode.java:15); nothing to sum
+            d.Sx[st->U] = 0.0;
+            d.Sx[st->U + 1] = 0.0;
+            st->chain_pending = 0;
         }
     }
 }
