@@ -1074,7 +1074,7 @@ __device__ __forceinline__ void sweep_exact_item(const Dev& d, int64_t r, const 
 
 constexpr int TRK_REC_U = 1024;  // offset of the swept-pair records in d.recs
 
-__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed, int has_scan) {
+__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed, int has_scan, int tgroup) {
     __shared__ ChainLds<CH_EPT> L;
     __shared__ Cand sh[TRK_THREADS / 64], shu[TRK_THREADS / 64];
     __shared__ int lastflag;
@@ -1152,20 +1152,23 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         const int lane_ = threadIdx.x & 63, w_ = threadIdx.x >> 6;
         if (lane_ == 0) { sh[w_] = best; shu[w_] = bestu; }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int k = 1; k < TRK_THREADS / 64; k++) {
-                if (cand_better(sh[k], best)) best = sh[k];
-                if (ta.approx && cand_better(shu[k], bestu)) bestu = shu[k];
+        if (w_ == 0) {  // the waves' minima: one more wave reduction (no serial walk through LDS)
+            Cand b2, bu2;
+            b2.q = inf_f64(); b2.key = ~0ULL; bu2 = b2;
+            if (lane_ < TRK_THREADS / 64) { b2 = sh[lane_]; bu2 = shu[lane_]; }
+            best = wave_reduce(b2);
+            if (ta.approx) bestu = wave_reduce(bu2);
+            if (lane_ == 0) {
+                d.recs[wg] = best;
+                if (ta.approx) d.recs[TRK_REC_U + wg] = bestu;
             }
-            d.recs[wg] = best;
-            if (ta.approx) d.recs[TRK_REC_U + wg] = bestu;
         }
     }
     if (threadIdx.x == 0) {
         __threadfence();
         // last of its group of TRK_GROUP workgroups -> last of the groups (counters 128 bytes apart)
-        const unsigned g = (unsigned)wg / TRK_GROUP, ngroups = ((unsigned)G + TRK_GROUP - 1) / TRK_GROUP;
-        const unsigned gsize = g + 1 < ngroups ? (unsigned)TRK_GROUP : (unsigned)G - g * TRK_GROUP;
+        const unsigned g = (unsigned)wg / (unsigned)tgroup, ngroups = ((unsigned)G + tgroup - 1) / (unsigned)tgroup;
+        const unsigned gsize = g + 1 < ngroups ? (unsigned)tgroup : (unsigned)G - g * tgroup;
         int last = 0;
         if (atomicAdd(d.ticket + 32 * (g + 1), 1u) == gsize - 1) {
             d.ticket[32 * (g + 1)] = 0u;
@@ -1183,6 +1186,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         b.q = inf_f64();
         b.key = ~0ULL;
         bu = b;
+        const unsigned badword = __hip_atomic_load(d.ticket + TRK_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = threadIdx.x; i < G; i += 64) {
             Cand c;
             c.q = __builtin_nontemporal_load(&d.recs[i].q);
@@ -1199,7 +1203,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         if (threadIdx.x == 0) {
             sh[0] = b;
             shu[0] = bu;
-            if (__hip_atomic_load(d.ticket + TRK_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            if (badword != 0u) {
                 d.ticket[TRK_BAD] = 0u;
                 lastflag = 2;
             }
@@ -2004,6 +2008,7 @@ struct HipBackend {
                              // correct, but slower than one launch sequence per event)
     int track_grid = 64;    // track workgroups of k_track (FNN_TRACK_GRID); one more computes the pending chain
     bool skip_unsched_scans = true; // FNN_UNSCHED_SCANS=1: keep the (mostly idle) scan kernels in unscheduled events
+    int track_group = TRK_GROUP;  // k_track: workgroups per first-level arrival counter (FNN_TRACK_GROUP)
     bool chain_split = false;  // the deferred sum in two launches (steps 1-3 in k_track, the walk in k_decide4): measured slower
     bool defer_chain = false; // set by the engine: k_update closes the event, the exact u.Sx sum runs inside the next k_track
     bool scan_nt = true;    // non-temporal matrix loads in the scan (FNN_SCAN_NT)
@@ -2062,6 +2067,7 @@ struct HipBackend {
         if (const char* e = std::getenv("FNN_PERSISTENT")) persistent = std::atoi(e) != 0;
         if (const char* e = std::getenv("FNN_EMIT_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) emit_grid = v; }
         if (const char* e = std::getenv("FNN_CHAIN_SPLIT")) chain_split = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FNN_TRACK_GROUP")) { int v = std::atoi(e); if (v >= 2 && v <= 1024) track_group = v; }
         if (const char* e = std::getenv("FNN_TRACK_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 1024) track_grid = v; }
         if (const char* e = std::getenv("FNN_SCREEN_MIN_M")) { int v = std::atoi(e); if (v >= 8) screen_min_m = v; }
         opened = true;
@@ -2217,7 +2223,7 @@ struct HipBackend {
         //  device stalls - this and the following such events do nothing - until the host, which
         //  looks at the state every batch, launches an event with a scan)
         const bool has_scan = sched || !screen || !skip_unsched_scans;
-        if (d.la) hipLaunchKernelGGL(k_track, dim3(track_grid + 1), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0, (has_scan ? 1 : 0) | (chain_split ? 0 : 2));
+        if (d.la) hipLaunchKernelGGL(k_track, dim3(track_grid + 1), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0, (has_scan ? 1 : 0) | (chain_split ? 0 : 2), track_group);
         if (timed) { e0 = next_event(); e1 = next_event(); ev_kind.push_back(screen ? 1 : 0); }
         int nrecs;
         if (screen && !has_scan) nrecs = RES_BLOCKS;  // (k_rx_fill reads one record, the window's)
