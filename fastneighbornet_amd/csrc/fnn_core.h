@@ -104,7 +104,8 @@ struct State {
     // ---- lookahead window (see "Lookahead" below) ----
     int32_t la_on;          // configured: windows enabled (single rank, screening copy present)
     int32_t la_K;           // events one window may serve (upper limit)
-    int32_t la_Kcur;        // ... the open / opening window: min(la_K, 16 + m / 1024) at its base scan
+    int32_t la_Kcur;        // ... the open / opening window: min(la_K, la_kbase + m / la_kdiv) at its base scan
+    int32_t la_kbase, la_kdiv;
     int32_t la_target;      // wanted number of tracked pairs per window
     int32_t la_min_m;       // windows only while m >= la_min_m (the screened regime)
     int32_t la_valid;       // a window is open
@@ -513,7 +514,10 @@ FNN_HD void la_prepare_base(State& st, int32_t* lacnt) {
     if (st.la_valid) st.la_k_prev = st.la_k;
     st.la_valid = 0;
     st.la_emit = 0;
-    st.la_Kcur = 16 + st.m / 1024 < st.la_K ? 16 + st.m / 1024 : st.la_K;  // shorter windows as the problem shrinks
+    {   // shorter windows as the problem shrinks
+        const int32_t kc = st.la_kbase + st.m / st.la_kdiv;
+        st.la_Kcur = kc < st.la_K ? kc : st.la_K;
+    }
     *lacnt = 0;
     if (st.la_on && st.nonneg && st.screen_ok && !st.done && st.m >= st.la_min_m) {
         if (st.la_skip > 0) st.la_skip--;

@@ -209,6 +209,10 @@ class Engine {
             hst.la_Kcur = 0;
             int32_t K = opts.lookahead < 0 ? 0 : (opts.lookahead > 0 ? opts.lookahead : Kdef);
             int32_t target = opts.lookahead_pairs > 0 ? opts.lookahead_pairs : 32768;
+            hst.la_kbase = 16;
+            hst.la_kdiv = 1024;
+            if (const char* e = std::getenv("FNN_LA_KBASE")) { int v = std::atoi(e); if (v >= 1 && v <= 64) hst.la_kbase = v; }
+            if (const char* e = std::getenv("FNN_LA_KDIV")) { int v = std::atoi(e); if (v >= 64) hst.la_kdiv = v; }
             if (const char* e = std::getenv("FNN_LA_K")) K = std::atoi(e);
             if (const char* e = std::getenv("FNN_LA_TARGET")) target = std::atoi(e);
             if (K > LA_KMAX) K = LA_KMAX;
