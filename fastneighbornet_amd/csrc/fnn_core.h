@@ -1189,6 +1189,26 @@ FNN_HD double tgt_value(const Tgt& t, const double* D, int64_t ld, int32_t c) {
     return (2.0 / 3.0) * D[t.d * ld + c] + v1 / 3.0;  // T_L2V
 }
 
+// tgt_value in two steps, so that the loads of several recipes can be in flight together (a recipe's
+// kind is uniform over the threads: branching on it between load and use would serialise the rounds)
+FNN_HD void tgt_load(const Tgt& t, const double* D, int64_t ld, int32_t c, double v[4]) {
+    v[0] = v[1] = v[2] = v[3] = 0.0;
+    if (t.kind != T_L2V) v[0] = D[t.a * ld + c];
+    if (t.kind != T_COPY) v[1] = D[t.b * ld + c];
+    if (t.kind == T_L2U || t.kind == T_L2V) v[2] = D[t.c * ld + c];
+    if (t.kind == T_L2V) v[3] = D[t.d * ld + c];
+}
+FNN_HD double tgt_compute(const Tgt& t, const double v[4]) {
+    if (t.kind == T_COPY) return v[0];
+    if (t.kind == T_L1) return (2.0 / 3.0) * v[0] + v[1] / 3.0;
+    const double v1 = (2.0 / 3.0) * v[2] + v[1] / 3.0;
+    if (t.kind == T_L2U) {
+        const double u1 = (2.0 / 3.0) * v[0] + v[1] / 3.0;
+        return (2.0 / 3.0) * u1 + v1 / 3.0;
+    }
+    return (2.0 / 3.0) * v[3] + v1 / 3.0;  // T_L2V
+}
+
 // Fused per-event update for a cluster whose slot(s) k (and k+1) are NOT involved in the
 // event: subtract_thread + every op_thread + add_thread for these columns in one pass.
 // Reads only rows of involved slots at its own column(s) and writes only entries with
@@ -1224,13 +1244,26 @@ FNN_HD double update_bulk(const Dev& d, int32_t k) {
     double tv[MAX_TGT][2];
     double u0 = 0.0, u1 = 0.0, v0 = 0.0, v1 = 0.0;
 #pragma unroll
-    for (int t = 0; t < MAX_TGT; t++) {
-        tv[t][0] = 0.0; tv[t][1] = 0.0;
-        if (t < st.ntgt) {
-            tv[t][0] = tgt_value(st.tgt[t], D, ld, k);
-            if (paired) tv[t][1] = tgt_value(st.tgt[t], D, ld, k + 1);
-            if (t == st.tU) { u0 = tv[t][0]; u1 = tv[t][1]; }
-            if (t == st.tV) { v0 = tv[t][0]; v1 = tv[t][1]; }
+    for (int t0 = 0; t0 < MAX_TGT; t0 += 4) {  // four recipes' loads in flight, then their values
+        double lv[4][2][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int t = t0 + q;
+            if (t < st.ntgt) {
+                tgt_load(st.tgt[t], D, ld, k, lv[q][0]);
+                if (paired) tgt_load(st.tgt[t], D, ld, k + 1, lv[q][1]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int t = t0 + q;
+            tv[t][0] = 0.0; tv[t][1] = 0.0;
+            if (t < st.ntgt) {
+                tv[t][0] = tgt_compute(st.tgt[t], lv[q][0]);
+                if (paired) tv[t][1] = tgt_compute(st.tgt[t], lv[q][1]);
+                if (t == st.tU) { u0 = tv[t][0]; u1 = tv[t][1]; }
+                if (t == st.tV) { v0 = tv[t][0]; v1 = tv[t][1]; }
+            }
         }
     }
 #pragma unroll
