@@ -2,7 +2,7 @@
 all-gather still runs every event), with screening forced on so that k_resolve's records are
 gathered as they are."""
 import os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: F401  (bench.py order: torch's HIP runtime serves both)
 import fastneighbornet_amd as fa
 from fastneighbornet_amd import distributed as fd

@@ -1,6 +1,6 @@
 """Development aid: timings of the circular split-weight solve (GPU vs the CPU oracle)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import fastneighbornet_amd as fa
 from oracle import nnet_oracle as O, csw_oracle as W
