@@ -52,3 +52,28 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_capi.FnnOpts) == 64
     assert C.sizeof(_capi.FnnStats) == 25 * 8  # 18 named 8-byte fields + reserved[7]
     assert _capi.EVENT_DTYPE.itemsize == 48
+
+
+def test_oracle_is_test_infrastructure_only():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/: no file of
+    the product (the package, its C/C++/HIP sources, the host mirror, the tools) mentions it in code."""
+    offenders = []
+    for base in ("fastneighbornet_amd", "include", "tools"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if not f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", ".c", ".sh")):
+                    continue
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                for line in txt.split("\n"):
+                    code = line.split("#")[0] if f.endswith((".py", ".sh")) else line.split("//")[0]
+                    if re.search(r"(from|import)\s+oracle\b|oracle/|nnet_oracle|csw_oracle", code):
+                        offenders.append(f"{os.path.relpath(os.path.join(dp, f), ROOT)}: {line.strip()[:80]}")
+    assert not offenders, offenders
+    # bench.py: the oracle only inside the cpu_baseline function; __graft_entry__: only build() (compiling
+    # the checker) and smoke()
+    b = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"nnet_oracle|csw_oracle|from oracle|import oracle", b)]
+    assert uses, "bench.py lost its cpu_baseline leg"
+    start = b.index("def cpu_baseline")
+    nxt = b.index("\ndef ", start + 1)
+    assert all(start < u < nxt for u in uses), "bench.py uses the oracle outside cpu_baseline()"
