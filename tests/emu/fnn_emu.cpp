@@ -18,6 +18,8 @@
 #include "../../fastneighbornet_amd/csrc/fnn_engine.h"
 #include "../../fastneighbornet_amd/csrc/fnn_chain.h"
 
+static void build_targets_lanes(fnn::State& st);
+
 namespace {
 
 int g_order_mode = 0;  // 0 forward, 1 reverse, 2 shuffled
@@ -341,7 +343,17 @@ struct EmuBackend {
                     st.n_rx_exact++;
                 }
             }
-            fnn::decide(d, rx);
+            fnn::decide_plan(d, rx);
+            // the GPU replays the micro-ops lane-parallel (fnn_hip.hip: build_targets_wave); the same
+            // algorithm on arrays of 64 "lanes" must give what the generic build_targets gives
+            fnn::State lanes = st;
+            build_targets_lanes(lanes);
+            fnn::build_targets(d);
+            bool same = lanes.nS == st.nS && lanes.ntgt == st.ntgt && lanes.tU == st.tU && lanes.tV == st.tV;
+            for (int i = 0; same && i < st.nS; i++) same = lanes.S[i] == st.S[i];
+            for (int i = 0; same && i < st.ntgt; i++)
+                same = std::memcmp(&lanes.tgt[i], &st.tgt[i], sizeof(fnn::Tgt)) == 0;
+            if (!same && !st.error) st.error = 12;
         }
         // k_update: bulk columns and the special phases run concurrently on the GPU; emulate
         // different interleavings (g_update_mode) to expose any conflict between them
@@ -371,6 +383,72 @@ struct EmuBackend {
 using EmuEngine = fnn::Engine<EmuBackend>;
 
 }  // namespace
+
+// fnn_hip.hip: build_targets_wave on arrays of 64 lanes (ballot = loop over the lanes, readlane = index)
+static void build_targets_lanes(fnn::State& st) {
+    using namespace fnn;
+    const int nops = st.nops, U = st.U, m = st.m, ev_finish = st.ev_finish;
+    int Sl[64], sk[64], sa[64], sb[64], sc[64], sd[64];
+    for (int l = 0; l < 64; l++) Sl[l] = -1;
+    int nS = 0, err = 0;
+    auto ballot = [&](auto pred) { unsigned long long mk = 0; for (int l = 0; l < 64; l++) if (pred(l)) mk |= 1ULL << l; return mk; };
+    auto add_slot = [&](int sl) {
+        if (ballot([&](int l) { return l < nS && Sl[l] == sl; })) return;
+        if (nS >= MAX_S) { err = 5; return; }
+        Sl[nS] = sl;
+        nS++;
+    };
+    add_slot(U);
+    add_slot(U + 1);
+    for (int i = 0; i < nops; i++) {
+        const Op& o = st.ops[i];
+        add_slot(o.a); add_slot(o.b);
+        if (o.kind == OP_AGG3) { add_slot(o.c); add_slot(o.d); add_slot(o.e); }
+    }
+    for (int l = 0; l < 64; l++) { sk[l] = T_COPY; sa[l] = Sl[l]; sb[l] = sc[l] = sd[l] = -1; }
+    struct Sym { int kind, a, b, c, d; };
+    auto idx = [&](int sl) { const unsigned long long hit = ballot([&](int l) { return l < nS && Sl[l] == sl; }); return hit ? __builtin_ctzll(hit) : 0; };
+    auto get = [&](int i) { return Sym{sk[i], sa[i], sb[i], sc[i], sd[i]}; };
+    auto put = [&](int i, const Sym& t) { sk[i] = t.kind; sa[i] = t.a; sb[i] = t.b; sc[i] = t.c; sd[i] = t.d; };
+    auto comb = [&](const Sym& A, const Sym& B) {
+        Sym r{T_COPY, -1, -1, -1, -1};
+        if (A.kind == T_COPY && B.kind == T_COPY) { r.kind = T_L1; r.a = A.a; r.b = B.a; }
+        else if (A.kind == T_L1 && B.kind == T_L1 && A.b == B.b) { r.kind = T_L2U; r.a = A.a; r.b = A.b; r.c = B.a; }
+        else if (A.kind == T_COPY && B.kind == T_L1) { r.kind = T_L2V; r.d = A.a; r.c = B.a; r.b = B.b; }
+        else err = 6;
+        return r;
+    };
+    for (int i = 0; i < nops; i++) {
+        const Op& o = st.ops[i];
+        if (o.kind == OP_SWAP) { const int ia = idx(o.a), ib = idx(o.b); const Sym ta = get(ia), tb = get(ib); put(ia, tb); put(ib, ta); }
+        else if (o.kind == OP_MOVE) { const Sym t = get(idx(o.a)); put(idx(o.b), t); }
+        else if (o.kind == OP_AGG3) {
+            const Sym sx = get(idx(o.a)), sy = get(idx(o.b)), sz = get(idx(o.c));
+            const Sym nu = comb(sx, sy), nv = comb(sz, sy);
+            put(idx(o.d), nu);
+            put(idx(o.e), nv);
+        }
+    }
+    auto keep = [&](int l) {
+        const bool isUV = (Sl[l] == U || Sl[l] == U + 1);
+        return l < nS && !(Sl[l] >= m && !ev_finish) && !(!isUV && sk[l] == T_COPY && sa[l] == Sl[l]);
+    };
+    const unsigned long long km = ballot(keep);
+    const int ntgt = __builtin_popcountll(km);
+    st.tU = -1; st.tV = -1;
+    for (int l = 0; l < 64; l++) {
+        if (!keep(l)) continue;
+        const int pos = __builtin_popcountll(km & ((1ULL << l) - 1ULL));
+        if (pos < MAX_TGT) { Tgt t; t.dst = Sl[l]; t.kind = sk[l]; t.a = sa[l]; t.b = sb[l]; t.c = sc[l]; t.d = sd[l]; st.tgt[pos] = t; }
+        if (Sl[l] == U) st.tU = pos;
+        if (Sl[l] == U + 1) st.tV = pos;
+    }
+    for (int l = 0; l < nS; l++) st.S[l] = Sl[l];
+    st.nS = nS;
+    st.ntgt = ntgt < MAX_TGT ? ntgt : MAX_TGT;
+    if (ntgt > MAX_TGT) st.error = 7;
+    else if (err) st.error = err;
+}
 
 // CPU model of the block-parallel exact chain sum (fnn_hip.hip: block_chain_sum): same
 // primitives (fnn_chain.h), same unit structure (thread chunks of `ept` addends, waves of
