@@ -33,6 +33,8 @@ inline double now_s() {
 }
 
 inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+// workgroups that may write a pair of partial sums into Dev::upart (k_update's grid; k_events' <= 64 main workgroups)
+inline size_t upart_capacity(int32_t n) { size_t g = (size_t)(n > 0 ? n : 1) / 256 + 2; return g < 64 ? 64 : g; }
 
 template <class B>
 class Engine {
@@ -95,7 +97,9 @@ class Engine {
             !(dev.chrec = (uint64_t*)be.alloc(sizeof(uint64_t) * CHREC_WORDS)) ||
             !(dev.lacnt = (int32_t*)be.alloc(256)) ||
             !(dev.lalog = (double*)be.alloc(sizeof(double) * 5 * LA_LOGCAP)) ||
-            !(dev.upart = (double*)be.alloc(sizeof(double) * 2 * 64)) ||
+            // k_update (deferred close) leaves {sum, sum of magnitudes} per workgroup: ceil(m / 256) + 1 workgroups;
+            // the persistent event kernel at most 64 -> size it from the update grid like rxpart
+            !(dev.upart = (double*)be.alloc(sizeof(double) * 2 * upart_capacity(n))) ||
             !(dev.evctl = (uint32_t*)be.alloc(1024)) ||
             !(dev.gsend = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS)) ||
             !(dev.grecv = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS * 64)) ||

@@ -1,0 +1,88 @@
+"""BASELINE.json's configurations 2-4 (4096 / 16384 / 32768 synthetic taxa) against the oracle.
+
+The oracle cannot run these sizes inside a test (n = 32768 is over an hour of CPU), so its results
+were generated once in the build container (tests/golden/make_golden_big.py: the order, the whole
+per-event trajectory and the bit patterns of every scan minimum) and the default HIP mode
+(on-device synthetic matrix, screening + lookahead windows as shipped) must reproduce them exactly.
+On a mismatch the first diverging event is reported.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from common import check_order
+from fastneighbornet_amd._capi import Handle
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TRAJ_FIELDS = ["m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id"]
+
+
+def cases():
+    doc = json.load(open(os.path.join(GOLD, "oracle_big.json")))
+    return {(c["n"], c["dist"], c["seed"]): c for c in doc["cases"]}
+
+
+def test_big_golden_fixtures_are_consistent():
+    """(CPU) every npz matches the hashes recorded next to it; the three BASELINE sizes are present."""
+    cs = cases()
+    for key in [(4096, "uniform53", 1), (4096, "dec4", 1), (16384, "uniform53", 1), (32768, "uniform53", 1)]:
+        assert key in cs, f"golden for {key} missing: run tests/golden/make_golden_big.py"
+    for (n, dist, seed), c in cs.items():
+        z = np.load(os.path.join(GOLD, c["npz"]))
+        assert hashlib.sha256(z["order"].tobytes()).hexdigest() == c["order_sha256"]
+        assert hashlib.sha256(np.ascontiguousarray(z["traj"]).tobytes()).hexdigest() == c["trajectory_sha256"]
+        assert hashlib.sha256(z["best_bits"].tobytes()).hexdigest() == c["best_bits_sha256"]
+        assert z["traj"].shape == (c["n_events"], 8) and z["order"].shape == (n + 1,)
+        check_order(z["order"], n)
+        m, cc = z["traj"][:, 0].astype(np.int64), z["traj"][:, 1].astype(np.int64)
+        assert int((m * (m - 1) // 2 - (m - cc))[z["traj"][:, 6] != 5].sum()) == c["sum_entries"]
+
+
+def test_small_oracle_run_matches_its_big_golden(oracle):
+    """(CPU) the committed n = 4096 golden is what the oracle computes today, serial scan included:
+    the OpenMP scan that generated the big goldens and the reference's serial first-strict-minimum
+    scan (NeighborNetCanonical.java:151-178) give the same trajectory on the first events and on a
+    whole smaller run."""
+    c = cases()[(4096, "dec4", 1)]
+    z = np.load(os.path.join(GOLD, c["npz"]))
+    D = oracle.synth(4096, 1, "dec4")
+    st = oracle.Stepper(D, threads=1)
+    for k in range(24):
+        e = st.step()
+        assert list(e.key()) == z["traj"][k].tolist(), k
+        assert np.float64(e.best).view(np.int64) == z["best_bits"][k], k
+    st.close()
+    D = oracle.synth(600, 3, "dec4")
+    o1, e1, _ = oracle.run(D, threads=1)
+    o8, e8, _ = oracle.run(D, threads=8)
+    assert (o1 == o8).all() and e1.tobytes() == e8.tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,dist,seed", [(4096, "uniform53", 1), (4096, "dec4", 1), (16384, "uniform53", 1),
+                                         (32768, "uniform53", 1)])
+def test_default_mode_matches_oracle_golden(hip_api, n, dist, seed):
+    if (n, dist, seed) not in cases():
+        pytest.skip("golden not generated yet (tests/golden/make_golden_big.py)")
+    c = cases()[(n, dist, seed)]
+    z = np.load(os.path.join(GOLD, c["npz"]))
+    with Handle(hip_api, n, record_events=True) as h:
+        h.synth(seed, dist)
+        order, st = h.run()
+        ev = h.events()
+    traj = np.stack([ev[f] for f in TRAJ_FIELDS], axis=1)
+    best = np.ascontiguousarray(ev["best"]).view(np.int64)
+    k = min(len(traj), len(z["traj"]))
+    bad = np.nonzero((traj[:k] != z["traj"][:k]).any(axis=1) | (best[:k] != z["best_bits"][:k]))[0]
+    assert bad.size == 0, (f"first diverging event {bad[0]}: gpu {traj[bad[0]].tolist()} best {ev['best'][bad[0]]!r} "
+                           f"oracle {z['traj'][bad[0]].tolist()} best {z['best_bits'][bad[0]:bad[0] + 1].view(np.float64)[0]!r}")
+    assert len(traj) == c["n_events"] and st.sum_entries == c["sum_entries"]
+    assert (order == z["order"]).all()
+    assert hashlib.sha256(order.tobytes()).hexdigest() == c["order_sha256"]
+    assert hashlib.sha256(np.ascontiguousarray(traj).tobytes()).hexdigest() == c["trajectory_sha256"]
+    assert hashlib.sha256(best.tobytes()).hexdigest() == c["best_bits_sha256"]
+    if n >= 4096:
+        assert st.n_base_scans > 0 and st.n_window_hits > 0, "the shipped mode (lookahead windows) did not run"
