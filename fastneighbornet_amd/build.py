@@ -36,10 +36,17 @@ def check_isa() -> None:
     an s_cselect / s_cbranch_scc whose SCC producer is not a compare and refuse the build."""
     import re
     import tempfile
+    for src in (SRC, SRC_SPLITS):
+        _check_isa_of(src, re, tempfile)
+
+
+def _check_isa_of(src, re, tempfile) -> None:
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "fnn.s")
-        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                               "-S", "--cuda-device-only", "-o", asm, SRC], stderr=subprocess.DEVNULL)
+        r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                            "-S", "--cuda-device-only", "-o", asm, src], stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-4000:]}")
         writers = re.compile(r"^\s*(s_cmp|s_bitcmp|s_cmpk|s_add|s_sub|s_addc|s_subb|s_and|s_or|s_xor|s_not|s_lshl|"
                              r"s_lshr|s_ashr|s_min|s_max|s_abs|s_andn2|s_orn2|s_nand|s_nor|s_xnor|s_bfe|"
                              r"s_absdiff|s_wqm|s_quadmask|s_bcnt|s_ff|s_flbit|s_addk)")
@@ -62,7 +69,7 @@ def check_isa() -> None:
             if writers.match(line):
                 last, last_i = line, i
         if bad:
-            raise RuntimeError("suspicious SCC use in device ISA (compiler miscompile?):\n" + "\n".join(bad))
+            raise RuntimeError(f"suspicious SCC use in device ISA of {os.path.basename(src)} (compiler miscompile?):\n" + "\n".join(bad))
 
 
 HOST_DIR = os.path.join(HERE, "host")

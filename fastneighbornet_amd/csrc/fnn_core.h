@@ -130,17 +130,20 @@ struct State {
     int32_t ev_timed, la_k_prev;  // the host brackets this event's scan launch with HIP events
     int64_t bytes_timed;      // the part of bytes_streamed that belongs to timed screening launches (k_screen + rescans)
     int64_t bytes_plain;      // ... and to the plain fp64 scans (k_scan; always timed)
-    int64_t n_ev_persistent;  // events completed inside the persistent event kernel
+    int64_t n_ev_persistent;  // (unused; was: events completed inside round 1's persistent event kernel)
     int64_t n_su_exact;       // ... of which the sweep had to wait for the exact row sum of the new cluster
     // deferred row sum of the newest cluster: k_update closes the event, the exact sequential sum is
     // computed by a workgroup of the NEXT event's k_track (or by k_chain_flush before the host looks)
     int32_t chain_pending, chain_m, chain_U, upart_n;
+    // approximate weighted row sums (see "The 4-candidate choice without an O(m) pass"): the two nodes of the newest
+    // cluster (slots tp_U, tp_U + 1) still await the sum of the tp_n per-workgroup partials the update left (0: none)
+    int32_t tp_n, tp_U;
     // an event launched WITHOUT scan kernels found that its window cannot serve it: this and the
     // following such events do nothing until the host (which resyncs every batch) launches one with a scan
     int32_t stall, pad_stall;
     int64_t n_stalled;        // events skipped that way
     int64_t n_sweep_waits;    // k_track: sweeps that had to wait for the exact row sum
-    int64_t ev_ticks[8];      // k_events, workgroup 0: 100 MHz ticks spent in phases A, B, C, wait for the chain, D, barriers
+    int64_t ev_ticks[8];      // k_track phase split in 100 MHz ticks, summed over window events (see k_track: TRK_TICK)
     // ---- current event ----
     int32_t ev_active, ev_finish, need_rx;
     int32_t sa, sap, sb, sbp;  // slots of Cx, Cx.nbr, Cy, Cy.nbr (-1: none)
@@ -165,13 +168,13 @@ struct Dev {
     int64_t ld;
     int32_t n;
     double* Sx;      // per slot: NetNode.Sx
+    double* T;       // per slot: approximate weighted row sum of the node (certified 4-candidate choice only)
     int32_t* sid;    // per slot: NetNode.id
     int32_t* spos;   // per slot: NetNode.positionID
     int32_t* pslot;  // reference position -> slot (-1 if empty)
     double* chain;   // 4 buffers of cstride doubles, addressed through chain_addr(position)
     int64_t cstride; // n rounded up to a whole super-chunk
     Cand* recs;      // per-block scan records
-    double* rxpart;  // per-block partial sums of k_rx_fill: [block][8] = 4 sums + 4 sums of |terms|
     uint16_t* H;     // bf16 screening copy of D (same geometry, H[r][c] == bf16(D[r][c]))
     float* srec;     // screening: per unit [tile][4] lower bounds, then [tile][4] upper bounds
     float* stile;    // screening: per tile lower bound, then per tile upper bound
@@ -182,11 +185,10 @@ struct Dev {
     int32_t* tpairs; // lookahead: tracked pairs {id a, id b, cstamp a, cstamp b} (LA_PCAP records)
     int32_t* fresh;  // lookahead: per fresh cluster {representative id, stamp} (LA_KMAX entries)
     uint32_t* ticket; // lookahead: arrival counter of k_track's workgroups
-    uint64_t* chrec;  // records of a chain sum between its data-parallel part (k_track) and its walk (k_decide4): CHREC_WORDS
     int32_t* lacnt;  // lookahead: append counter of the tracked list (its own word: the control block may be
-                     // cached in LDS by the persistent event kernel while every thread appends)
-    double* upart;   // persistent event kernel: per main workgroup {sum, sum of magnitudes} of the new cluster's row-sum addends
-    uint32_t* evctl; // persistent event kernel: barrier counter, epochs, mailbox (EvCtl)
+                     // cached in LDS by a workgroup while every thread appends)
+    double* upart;   // per workgroup of k_update, 4 doubles: {sum, sum of magnitudes} of the new cluster's exact row-sum
+                     // addends (for the sweep beside the exact chain), and the partial sums of T of its two nodes
     double* lalog;   // lookahead diagnostics: per base scan {event, m, W, pairs, events served by the previous window} (LA_LOGCAP records)
     Cand* gsend;     // multi-GPU: this rank's candidate record(s) of the event (<= GATHER_RECS)
     Cand* grecv;     // multi-GPU: all ranks' candidate records
@@ -207,11 +209,6 @@ constexpr int CH_T = 1024;               // threads of the chain workgroup
 constexpr int CH_EPT = 32;               // addends per thread
 constexpr int CH_SC = CH_T * CH_EPT;     // addends per super-chunk
 constexpr int CH_NSLOT = 48;             // parked ("mixed") chunks per super-chunk
-// layout of Dev::chrec in 8-byte words: increments own[CH_T], sc[CH_T]; then E, flags, slot (CH_T int32 each);
-// then the parked addends
-constexpr int CHREC_OWN = 0, CHREC_SC = CH_T, CHREC_E = 2 * CH_T, CHREC_FLAGS = CHREC_E + CH_T / 2,
-              CHREC_SLOT = CHREC_FLAGS + CH_T / 2, CHREC_VALS = CHREC_SLOT + CH_T / 2,
-              CHREC_WORDS = CHREC_VALS + CH_NSLOT * CH_EPT;
 FNN_HD int64_t chain_addr(int32_t e) {
     const int32_t sc = e / CH_SC, r = e % CH_SC;
     const int32_t t = r / CH_EPT, j = r % CH_EPT;
@@ -638,7 +635,7 @@ FNN_HD void fresh_eval(const Dev& d, int32_t f0, int32_t s, int32_t m, int32_t t
 struct TrackArgs {
     int32_t np, nf0, nf, m, twoP;
     double cm2, coef, th;
-    // persistent event kernel: the swept cluster's exact row sum may still be on its way; the sweep
+    // the swept cluster's exact row sum may still be on its way (k_track's chain workgroup); the sweep
     // then runs with the tree-ordered sum `sxu` and its pairs compete in a separate record
     int32_t approx;
     int32_t usl;  // slot of the cluster whose sum sxu is (-2: not checked)
@@ -725,7 +722,85 @@ FNN_HD void la_track_hit(const Dev& d, const TrackArgs& a) {
 
 // ---------------------------------------------------------------------------
 // plan building (single thread)
+//
+// The integer side of an event reads and writes the slot tables (sid, spos, pslot) a few dozen
+// times, each access depending on the previous one.  On the GPU every such access to memory is a
+// round trip of ~1 us for the single planning thread, so the tables are addressed through an
+// accessor: GlobalTab goes to memory; CachedTab holds the entries an event can touch - the slots of
+// Cx, Cy and their partners, the two slots at the pair / singleton boundary on either side, the last
+// two live slots, and pslot of the last two positions (see tab_keys) - preloaded with ONE batch of
+// independent loads, writes through to memory, and falls back to memory on a miss.
 // ---------------------------------------------------------------------------
+struct GlobalTab {
+    const Dev& d;
+    FNN_HD int32_t sid(int32_t s) const { return d.sid[s]; }
+    FNN_HD int32_t spos(int32_t s) const { return d.spos[s]; }
+    FNN_HD int32_t pslot(int32_t p) const { return d.pslot[p]; }
+    FNN_HD void set_sid(int32_t s, int32_t v) { d.sid[s] = v; }
+    FNN_HD void set_spos(int32_t s, int32_t v) { d.spos[s] = v; }
+    FNN_HD void set_pslot(int32_t p, int32_t v) { d.pslot[p] = v; }
+};
+constexpr int TAB_NK = 10, TAB_NP = 2;
+// the slots (keys) and positions an event with candidates in slots a, b can read; -1 = none
+FNN_HD void tab_keys(int32_t a, int32_t b, int32_t P, int32_t m, int32_t key[TAB_NK], int32_t pkey[TAB_NP]) {
+    key[0] = a; key[1] = a ^ 1; key[2] = b; key[3] = b ^ 1;
+    key[4] = 2 * P; key[5] = 2 * P + 1; key[6] = 2 * P - 2; key[7] = 2 * P - 1;
+    key[8] = m - 1; key[9] = m - 2;
+    pkey[0] = m - 1; pkey[1] = m - 2;
+}
+struct CachedTab {
+    const Dev& d;
+    int32_t *key, *vsid, *vspos;  // [TAB_NK]   (the GPU keeps these arrays in LDS)
+    int32_t *pkey, *vpslot;       // [TAB_NP]
+    int32_t* misses;
+    FNN_HD int32_t sid(int32_t s) {
+        int32_t r = 0; bool hit = false;
+        for (int i = 0; i < TAB_NK; i++) if (key[i] == s) { r = vsid[i]; hit = true; }
+        if (!hit) { r = d.sid[s]; ++*misses; }
+        return r;
+    }
+    FNN_HD int32_t spos(int32_t s) {
+        int32_t r = 0; bool hit = false;
+        for (int i = 0; i < TAB_NK; i++) if (key[i] == s) { r = vspos[i]; hit = true; }
+        if (!hit) { r = d.spos[s]; ++*misses; }
+        return r;
+    }
+    FNN_HD int32_t pslot(int32_t p) {
+        int32_t r = 0; bool hit = false;
+        for (int i = 0; i < TAB_NP; i++) if (pkey[i] == p) { r = vpslot[i]; hit = true; }
+        if (!hit) { r = d.pslot[p]; ++*misses; }
+        return r;
+    }
+    FNN_HD void set_sid(int32_t s, int32_t v) {
+        for (int i = 0; i < TAB_NK; i++) if (key[i] == s) vsid[i] = v;
+        d.sid[s] = v;
+    }
+    FNN_HD void set_spos(int32_t s, int32_t v) {
+        for (int i = 0; i < TAB_NK; i++) if (key[i] == s) vspos[i] = v;
+        d.spos[s] = v;
+    }
+    FNN_HD void set_pslot(int32_t p, int32_t v) {
+        for (int i = 0; i < TAB_NP; i++) if (pkey[i] == p) vpslot[i] = v;
+        d.pslot[p] = v;
+    }
+};
+// fill a CachedTab straight from memory (CPU emulation; the GPU loads the same entries lane-parallel)
+FNN_HD void tab_preload(CachedTab& T, int32_t a, int32_t b, int32_t P, int32_t m) {
+    tab_keys(a, b, P, m, T.key, T.pkey);
+    *T.misses = 0;
+    for (int i = 0; i < TAB_NK; i++) {
+        const bool ok = T.key[i] >= 0 && T.key[i] < T.d.n;
+        if (!ok) T.key[i] = -1;
+        T.vsid[i] = ok ? T.d.sid[T.key[i]] : 0;
+        T.vspos[i] = ok ? T.d.spos[T.key[i]] : 0;
+    }
+    for (int i = 0; i < TAB_NP; i++) {
+        const bool ok = T.pkey[i] >= 0 && T.pkey[i] < T.d.n;
+        if (!ok) T.pkey[i] = -1;
+        T.vpslot[i] = ok ? T.d.pslot[T.pkey[i]] : 0;
+    }
+}
+
 FNN_HD void emit(State& st, int32_t kind, int32_t a, int32_t b, int32_t c, int32_t d, int32_t e,
                  int32_t flag) {
     if (st.nops >= MAX_OPS) { st.error = 2; return; }
@@ -735,23 +810,24 @@ FNN_HD void emit(State& st, int32_t kind, int32_t a, int32_t b, int32_t c, int32
     o.flag = flag;
 }
 
-// (values that were just stored are kept in locals, not read back: on the GPU every read-after-write
-//  through memory is one more dependent round trip of the single planning thread)
-FNN_HD void swap_slots(const Dev& d, int32_t s1, int32_t s2) {
-    const int32_t id1 = d.sid[s1], id2 = d.sid[s2], p1 = d.spos[s1], p2 = d.spos[s2];
-    d.sid[s1] = id2; d.sid[s2] = id1;
-    d.spos[s1] = p2; d.spos[s2] = p1;
-    d.pslot[p2] = s1;
-    d.pslot[p1] = s2;
+// (values that were just stored are kept in locals, not read back)
+template <class Tab>
+FNN_HD void swap_slots(const Dev& d, Tab& T, int32_t s1, int32_t s2) {
+    const int32_t id1 = T.sid(s1), id2 = T.sid(s2), p1 = T.spos(s1), p2 = T.spos(s2);
+    T.set_sid(s1, id2); T.set_sid(s2, id1);
+    T.set_spos(s1, p2); T.set_spos(s2, p1);
+    T.set_pslot(p2, s1);
+    T.set_pslot(p1, s2);
     if (d.islot) { d.islot[id2] = s1; d.islot[id1] = s2; }
     emit(*d.st, OP_SWAP, s1, s2, 0, 0, 0, 0);
 }
 
-FNN_HD void move_slot(const Dev& d, int32_t src, int32_t dst) {
-    const int32_t id = d.sid[src], ps = d.spos[src];
-    d.sid[dst] = id;
-    d.spos[dst] = ps;
-    d.pslot[ps] = dst;
+template <class Tab>
+FNN_HD void move_slot(const Dev& d, Tab& T, int32_t src, int32_t dst) {
+    const int32_t id = T.sid(src), ps = T.spos(src);
+    T.set_sid(dst, id);
+    T.set_spos(dst, ps);
+    T.set_pslot(ps, dst);
     if (d.islot) d.islot[id] = dst;
     emit(*d.st, OP_MOVE, src, dst, 0, 0, 0, 0);
 }
@@ -759,29 +835,31 @@ FNN_HD void move_slot(const Dev& d, int32_t src, int32_t dst) {
 // Integer side of agg3way(x, y, z, ..., num_nodes = nn, num_active = mc)
 // (NetMakerOriginal.java:608-648): nodes x, y, z sit in slots X, Y, Z; the new
 // nodes u (id nn+1) and v (id nn+2) are put in slots U and V, both in {X,Y,Z}.
-FNN_HD void agg3_plan(const Dev& d, int32_t X, int32_t Y, int32_t Z, int32_t U, int32_t V,
+template <class Tab>
+FNN_HD void agg3_plan(const Dev& d, Tab& T, int32_t X, int32_t Y, int32_t Z, int32_t U, int32_t V,
                       int32_t nn, int32_t mc) {
     State& st = *d.st;
-    int32_t px = d.spos[X], py = d.spos[Y], pz = d.spos[Z];
+    int32_t px = T.spos(X), py = T.spos(Y), pz = T.spos(Z);
     Agg3Rec& r = d.agglog[st.n_agg3++];
-    r.u_id = nn + 1; r.x_id = d.sid[X]; r.y_id = d.sid[Y]; r.z_id = d.sid[Z];
-    if (d.islot) { d.islot[r.x_id] = -1; d.islot[r.y_id] = -1; d.islot[r.z_id] = -1; d.islot[nn + 1] = U; d.islot[nn + 2] = V; }
-    d.sid[U] = nn + 1;  // u replaces x in the list (:623-625)
-    d.sid[V] = nn + 2;  // v replaces z (:630-632)
-    d.spos[U] = px;
-    d.spos[V] = pz;
-    d.pslot[px] = U;
-    d.pslot[pz] = V;
+    const int32_t idx = T.sid(X), idy = T.sid(Y), idz = T.sid(Z);
+    r.u_id = nn + 1; r.x_id = idx; r.y_id = idy; r.z_id = idz;
+    if (d.islot) { d.islot[idx] = -1; d.islot[idy] = -1; d.islot[idz] = -1; d.islot[nn + 1] = U; d.islot[nn + 2] = V; }
+    T.set_sid(U, nn + 1);  // u replaces x in the list (:623-625)
+    T.set_sid(V, nn + 2);  // v replaces z (:630-632)
+    T.set_spos(U, px);
+    T.set_spos(V, pz);
+    T.set_pslot(px, U);
+    T.set_pslot(pz, V);
     // remove y: netNodes[y.pos] = netNodes[mc-1] (:641-643)
-    int32_t last = d.pslot[mc - 1];
+    int32_t last = T.pslot(mc - 1);
     int32_t pu = px, pv = pz;  // = spos[U], spos[V] as they stand in memory
     if (py != mc - 1) {
-        d.spos[last] = py;
-        d.pslot[py] = last;
+        T.set_spos(last, py);
+        T.set_pslot(py, last);
         if (last == U) pu = py;
         if (last == V) pv = py;
     }
-    d.pslot[mc - 1] = -1;
+    T.set_pslot(mc - 1, -1);
     emit(st, OP_AGG3, X, Y, Z, U, V, pu < pv ? 1 : 0);
 }
 
@@ -837,10 +915,11 @@ FNN_HD void build_targets(const Dev& d) {
     }
 }
 
-// Special finish, NetMakerOriginal.java:343-360 (num_active == 4, num_clusters == 2)
+// Special finish, NetMakerOriginal.java:343-360 (num_active == 4, num_clusters == 2); rare: tables in memory
 FNN_HD void finish_plan(const Dev& d) {
     State& st = *d.st;
     const double* D = d.D; const int64_t ld = d.ld;
+    GlobalTab T{d};
     st.ev_finish = 1;
     st.need_rx = 0;
     int32_t ps = d.pslot[0];
@@ -855,33 +934,17 @@ FNN_HD void finish_plan(const Dev& d) {
     st.cur.y_id = d.sid[Y];
     st.cur.u_id = st.num_nodes + 1;
     int32_t k = qs >> 1;
-    agg3_plan(d, X, Y, Z, 2 * k, 2 * k + 1, st.num_nodes, 4);
+    agg3_plan(d, T, X, Y, Z, 2 * k, 2 * k + 1, st.num_nodes, 4);
     st.num_nodes += 2;
     st.U = 2 * k;
-    build_targets(d);
+    // (the caller replays the micro-op: build_targets / build_targets_wave)
 }
 
-// The slots of Cx, Cx.nbr, Cy, Cy.nbr from the best candidate, without touching the control
-// block (every workgroup of k_rx_fill derives them for itself; workgroup 0 also runs pick()).
-// Returns false when the event needs no ComputeRx terms (loop ended, special finish, both single).
-FNN_HD bool pick_slots(const Dev& d, Cand best, int32_t z[4]) {
-    const State& st = *d.st;
-    z[0] = z[1] = z[2] = z[3] = -1;
-    if (st.done || st.m <= 3 || (st.m == 4 && st.c == 2)) return false;
-    const int32_t i = (int32_t)(best.key >> 32), j = (int32_t)(best.key & 0xFFFFFFFFu);
-    int32_t a = d.pslot[i], b = d.pslot[j];
-    if (d.sid[a] > d.sid[b]) { int32_t t = a; a = b; b = t; }
-    const int32_t twoP = 2 * st.P;
-    z[0] = a; z[2] = b;
-    z[1] = a < twoP ? (a ^ 1) : -1;
-    z[3] = b < twoP ? (b ^ 1) : -1;
-    return z[1] >= 0 || z[3] >= 0;
-}
-
-// After the scan: turn the best candidate into Cx, Cy (NetMakerOriginal.java:376-380)
-FNN_HD void pick(const Dev& d, Cand best) {
+// After the scan: turn the best candidate into Cx, Cy (NetMakerOriginal.java:376-380).
+// a, b: the slots pslot[i], pslot[j] of the candidate's positions; ida, idb: their node ids.
+FNN_HD void pick(const Dev& d, Cand best, int32_t a, int32_t b, int32_t ida, int32_t idb) {
     State& st = *d.st;
-    st.chain_pending = 0;  // (k_track's chain workgroup has delivered the previous event's u.Sx)
+    st.chain_pending = 0;  // (the previous event's u.Sx is delivered by k_track's chain workgroup before the next kernel)
     st.ev_active = 0;
     if (st.done) return;
     if (st.m <= 3) { st.done = 1; return; }
@@ -904,34 +967,28 @@ FNN_HD void pick(const Dev& d, Cand best) {
         else if (st.ev_timed) st.bytes_timed += bytes;
     }
     st.ev_screened = 0;
-    int32_t i = (int32_t)(best.key >> 32), j = (int32_t)(best.key & 0xFFFFFFFFu);
-    int32_t a = d.pslot[i], b = d.pslot[j];  // Cx = p, Cy = q
-    if (d.sid[a] > d.sid[b]) { int32_t t = a; a = b; b = t; }
+    if (ida > idb) { int32_t t = a; a = b; b = t; t = ida; ida = idb; idb = t; }  // Cx.id < Cy.id
     int32_t twoP = 2 * st.P;
     st.sa = a; st.sb = b;
     st.sap = a < twoP ? (a ^ 1) : -1;
     st.sbp = b < twoP ? (b ^ 1) : -1;
     st.need_rx = (st.sap >= 0 || st.sbp >= 0) ? 1 : 0;
-    cur.cx_id = d.sid[a];
-    cur.cy_id = d.sid[b];
+    cur.cx_id = ida;
+    cur.cy_id = idb;
 }
+// does the event that `pick` would open need a candidate at all? (loop ended / special finish: no)
+FNN_HD bool pick_needs_candidate(const State& st) { return !st.done && st.m > 3 && !(st.m == 4 && st.c == 2); }
 
 // ComputeRx term for slot s (NetMakerOriginal.java:555-558), written to the chain
-// buffer at the node's reference position; the terms are also returned (0 where absent)
-// so that the kernel can form tree-ordered partial sums for the certified decision.
-// write_chain: also store the terms in the chain buffers (only the exact sequential sums read them, and
-// those are needed only when the certified decision fails: the GPU writes them then, not before)
-FNN_HD void rx_fill_thread(const Dev& d, int32_t s, int32_t m, int32_t twoP, const int32_t z[4], double term[4],
-                           bool write_chain = true) {
-    term[0] = term[1] = term[2] = term[3] = 0.0;
+// buffer at the node's reference position (the exact sequential sums read them there)
+FNN_HD void rx_fill_thread(const Dev& d, int32_t s, int32_t m, int32_t twoP, const int32_t z[4]) {
     if (s >= m) return;
     bool full = (s == z[0] || s == z[1] || s == z[2] || s == z[3] || s >= twoP);
-    int32_t pos = write_chain ? d.spos[s] : 0;
+    int32_t pos = d.spos[s];
     for (int k = 0; k < 4; k++) {
         if (z[k] < 0) continue;
         double v = d.D[(int64_t)z[k] * d.ld + s];
-        term[k] = full ? v : v / 2.0;
-        if (write_chain) d.chain[(int64_t)k * d.cstride + chain_addr(pos)] = term[k];
+        d.chain[(int64_t)k * d.cstride + chain_addr(pos)] = full ? v : v / 2.0;
     }
 }
 
@@ -942,15 +999,51 @@ FNN_HD double chain_sum(const double* buf, int32_t m) {
     return s;
 }
 
-// handleAgglomerationEvent: candidate choice (:422-452), bookkeeping of the merge
-// (:462-488) and the micro-op plan for the matrix.  rx = {Rx(Cx), Rx(Cx.nbr),
-// Rx(Cy), Rx(Cy.nbr)}, 0.0 where the reference leaves the 0.0 initialiser.
-// The <=4 candidate values of NetMakerOriginal.java:428-452 in the reference's order
-// (Cx,Cy), (Cx.nbr,Cy), (Cx,Cy.nbr), (Cx.nbr,Cy.nbr); ok[i] = candidate exists.
-FNN_HD void candidate_q(const Dev& d, const double rx[4], double q[4], bool ok[4], double fd[4]) {
+// ---------------------------------------------------------------------------
+// The 4-candidate choice without an O(m) pass.
+//
+// ComputeRx(z) (:549-561) = sum over the live nodes p of w'(p) D[z][p], w' = 1 for singletons and
+// for the (up to four) nodes of the two candidate clusters, 1/2 for every other paired node.  The
+// engine maintains, per node z, the APPROXIMATE weighted row sum
+//     T(z) = sum over live p of w(p) D[z][p],   w = 1 for singletons, 1/2 for paired nodes
+// incrementally in the fused update (every bystander's T changes by the old / new entries towards
+// the merged nodes, which that kernel has in registers anyway; the two new nodes get a fresh tree
+// sum).  Then  Rx(z) = T(z) + 1/2 sum over the PAIRED nodes k among {Cx, Cx.nbr, Cy, Cy.nbr} of
+// D[z][k]: six matrix entries instead of four row sweeps.  T is only ever used to CERTIFY the
+// comparisons of :428-452 (rx_certify): |T_computed - T_real| is bounded by the initial sequential
+// sum (n eps n Dmax), a fresh tree sum (m eps m Dmax) and the drift of <= eps (n + 64) Dmax per
+// event; the reference's own sequential sum is within m eps m Dmax of the real one.  If any two
+// candidates are closer than the sum of their bounds the exact sequential sums decide (rare).
+// ---------------------------------------------------------------------------
+struct Quad {        // what the decision reads besides the control block
+    double Tz[4];    // T of Cx, Cx.nbr, Cy, Cy.nbr (0 where absent)
+    double Dab, Dapb, Dabp, Dapbp;  // D[Cx][Cy], D[Cx.nbr][Cy], D[Cx][Cy.nbr], D[Cx.nbr][Cy.nbr]
+    double Daap, Dbbp;              // D[Cx][Cx.nbr], D[Cy][Cy.nbr]
+};
+FNN_HD void quad_load(const Dev& d, Quad& q) {  // (CPU emulation / rare paths; the GPU loads these lane-parallel)
     const State& st = *d.st;
     const double* D = d.D; const int64_t ld = d.ld;
     const int32_t a = st.sa, ap = st.sap, b = st.sb, bp = st.sbp;
+    q.Tz[0] = d.T[a]; q.Tz[1] = ap >= 0 ? d.T[ap] : 0.0; q.Tz[2] = d.T[b]; q.Tz[3] = bp >= 0 ? d.T[bp] : 0.0;
+    q.Dab = D[a * ld + b];
+    q.Dapb = ap >= 0 ? D[ap * ld + b] : 0.0;
+    q.Dabp = bp >= 0 ? D[a * ld + bp] : 0.0;
+    q.Dapbp = (ap >= 0 && bp >= 0) ? D[ap * ld + bp] : 0.0;
+    q.Daap = ap >= 0 ? D[a * ld + ap] : 0.0;
+    q.Dbbp = bp >= 0 ? D[b * ld + bp] : 0.0;
+}
+FNN_HD void rx_from_T(const State& st, const Quad& q, double rx[4]) {
+    const bool pa = st.sap >= 0, pb = st.sbp >= 0;
+    rx[0] = q.Tz[0] + 0.5 * ((pa ? q.Daap : 0.0) + (pb ? q.Dab + q.Dabp : 0.0));
+    rx[1] = pa ? q.Tz[1] + 0.5 * (q.Daap + (pb ? q.Dapb + q.Dapbp : 0.0)) : 0.0;
+    rx[2] = q.Tz[2] + 0.5 * ((pb ? q.Dbbp : 0.0) + (pa ? q.Dab + q.Dapb : 0.0));
+    rx[3] = pb ? q.Tz[3] + 0.5 * (q.Dbbp + (pa ? q.Dabp + q.Dapbp : 0.0)) : 0.0;
+}
+
+// The <=4 candidate values of NetMakerOriginal.java:428-452 in the reference's order
+// (Cx,Cy), (Cx.nbr,Cy), (Cx,Cy.nbr), (Cx.nbr,Cy.nbr); ok[i] = candidate exists.
+FNN_HD void candidate_q(const State& st, const Quad& qd, const double rx[4], double q[4], bool ok[4], double fd[4]) {
+    const int32_t ap = st.sap, bp = st.sbp;
     int32_t mm = st.c;
     if (ap >= 0) mm++;
     if (bp >= 0) mm++;
@@ -958,34 +1051,36 @@ FNN_HD void candidate_q(const Dev& d, const double rx[4], double q[4], bool ok[4
     ok[0] = true; ok[1] = ap >= 0; ok[2] = bp >= 0; ok[3] = ap >= 0 && bp >= 0;
     q[0] = q[1] = q[2] = q[3] = 0.0;
     fd[0] = fd[1] = fd[2] = fd[3] = 0.0;
-    fd[0] = f * D[a * ld + b];
+    fd[0] = f * qd.Dab;
     q[0] = fd[0] - rx[0] - rx[2];
-    if (ok[1]) { fd[1] = f * D[ap * ld + b]; q[1] = fd[1] - rx[1] - rx[2]; }
-    if (ok[2]) { fd[2] = f * D[a * ld + bp]; q[2] = fd[2] - rx[0] - rx[3]; }
-    if (ok[3]) { fd[3] = f * D[ap * ld + bp]; q[3] = fd[3] - rx[1] - rx[3]; }
+    if (ok[1]) { fd[1] = f * qd.Dapb; q[1] = fd[1] - rx[1] - rx[2]; }
+    if (ok[2]) { fd[2] = f * qd.Dabp; q[2] = fd[2] - rx[0] - rx[3]; }
+    if (ok[3]) { fd[3] = f * qd.Dapbp; q[3] = fd[3] - rx[1] - rx[3]; }
 }
 
-// Can the 4-candidate choice be made from tree-ordered sums?  rxa = approximate Rx (any
-// summation order), rxs = sums of |terms|.  Both the reference's sequential sum and any other
-// order are within gamma_(m-1) * sum|terms| of the exact sum, so |rxa - Rx_seq| <=
-// 2.1 m eps sum|terms|; the three roundings of `f*D - Rx - Ry` add at most 3 eps (|fD| + |Rx| +
-// |Ry|) on each side.  With a safety factor of ~2 on everything: if every pair of existing
-// candidates is further apart than the sum of their bounds, the strict comparisons of
-// :431-451 come out the same with the exact sums, hence the same (x, y).
-FNN_HD bool rx_certify(const Dev& d, const double rxa[4], const double rxs[4]) {
-    const State& st = *d.st;
+// bound on |rxa(z) - ComputeRx(z) as the reference's sequential loop rounds it| (see above; factor 2 of slack)
+FNN_HD double rx_bound(const State& st) {
+    const double eps = 1.1102230246251565e-16;  // 2^-53
+    const double dmax = __builtin_bit_cast(double, st.dmax_bits);
+    const double n = (double)st.n;
+    return 2.0 * eps * dmax * (n + 64.0) * (2.0 * n + (double)st.n_events + 8.0);
+}
+// Can the 4-candidate choice be made from the approximate sums rxa?  If every pair of existing
+// candidates is further apart than the sum of their bounds, the strict comparisons of :431-451
+// come out the same with the exact sums, hence the same (x, y).
+FNN_HD bool rx_certify(const State& st, const Quad& qd, const double rxa[4]) {
     if (st.force_exact_rx) return false;
     double q[4], fd[4], bnd[4];
     bool ok[4];
-    candidate_q(d, rxa, q, ok, fd);
-    const double eps = 1.1102230246251565e-16;  // 2^-53
-    const double mfac = 4.0 * ((double)st.m_old + 8.0) * eps;
+    candidate_q(st, qd, rxa, q, ok, fd);
+    const double eps = 1.1102230246251565e-16;
+    const double e1 = rx_bound(st);
     const int ia[4] = {0, 1, 0, 1}, ib[4] = {2, 2, 3, 3};
     for (int i = 0; i < 4; i++) {
-        const double sab = rxs[ia[i]] + rxs[ib[i]];
+        const double ra = rxa[ia[i]] < 0.0 ? -rxa[ia[i]] : rxa[ia[i]], rb = rxa[ib[i]] < 0.0 ? -rxa[ib[i]] : rxa[ib[i]];
         const double afd = fd[i] < 0.0 ? -fd[i] : fd[i];
-        bnd[i] = mfac * sab + 16.0 * eps * (afd + sab);
-        if (!(bnd[i] == bnd[i]) || !(q[i] == q[i])) return false;  // NaN anywhere: exact path
+        bnd[i] = 2.0 * e1 + 16.0 * eps * (afd + ra + rb);
+        if (!(bnd[i] == bnd[i]) || !(q[i] == q[i]) || !(bnd[i] < 1.7e308)) return false;  // NaN / overflow anywhere: exact path
     }
     for (int i = 0; i < 4; i++)
         for (int j = i + 1; j < 4; j++) {
@@ -996,15 +1091,28 @@ FNN_HD bool rx_certify(const Dev& d, const double rxa[4], const double rxs[4]) {
     return true;
 }
 
-// decide = decide_plan (candidate choice, integer side of the merge, micro-ops) + build_targets
-// (symbolic replay); the GPU runs the second part lane-parallel (fnn_hip.hip: build_targets_wave)
-FNN_HD void decide_plan(const Dev& d, const double rx[4]) {
+// T of the newest cluster's two nodes from the per-workgroup partial sums the update left (tree order)
+FNN_HD void t_finalize(const Dev& d) {
+    State& st = *d.st;
+    if (st.tp_n <= 0) return;
+    double tu = 0.0, tv = 0.0;
+    for (int32_t g = 0; g < st.tp_n; g++) { tu += d.upart[4 * g + 2]; tv += d.upart[4 * g + 3]; }
+    d.T[st.tp_U] = tu;
+    d.T[st.tp_U + 1] = tv;
+    st.tp_n = 0;
+}
+
+// handleAgglomerationEvent: candidate choice (:422-452), bookkeeping of the merge
+// (:462-488) and the micro-op plan for the matrix.  rx = {Rx(Cx), Rx(Cx.nbr),
+// Rx(Cy), Rx(Cy.nbr)}, 0.0 where the reference leaves the 0.0 initialiser.
+template <class Tab>
+FNN_HD void decide_plan(const Dev& d, Tab& T, const Quad& qd, const double rx[4]) {
     State& st = *d.st;
     Event& cur = st.cur;
     int32_t a = st.sa, ap = st.sap, b = st.sb, bp = st.sbp;
     double q[4], fd[4];
     bool ok[4];
-    candidate_q(d, rx, q, ok, fd);
+    candidate_q(st, qd, rx, q, ok, fd);
     int32_t x = a, y = b;
     double best = q[0];
     if (ok[1] && q[1] < best) { x = ap; y = b; best = q[1]; }
@@ -1014,7 +1122,7 @@ FNN_HD void decide_plan(const Dev& d, const double rx[4]) {
     int32_t xn = x < twoP ? (x ^ 1) : -1;
     int32_t yn = y < twoP ? (y ^ 1) : -1;
     st.xs = x; st.ys = y;
-    const int32_t idx = d.sid[x], idy = d.sid[y];
+    const int32_t idx = T.sid(x), idy = T.sid(y);
     cur.x_id = idx;
     cur.y_id = idy;
     int32_t m = st.m, P = st.P, nn = st.num_nodes;
@@ -1027,8 +1135,8 @@ FNN_HD void decide_plan(const Dev& d, const double rx[4]) {
         int32_t hi = (lo == x) ? y : x;
         cur.u_id = idx;  // agg2way returns x
         int32_t t0 = 2 * P, t1 = 2 * P + 1;
-        if (lo != t0) { swap_slots(d, lo, t0); if (hi == t0) hi = lo; }
-        if (hi != t1) swap_slots(d, hi, t1);
+        if (lo != t0) { swap_slots(d, T, lo, t0); if (hi == t0) hi = lo; }
+        if (hi != t1) swap_slots(d, T, hi, t1);
         st.P = P + 1;
         st.c -= 1;
         st.U = t0;  // u = x, and x always has the smaller id (Cx.id < Cy.id, :376-380)
@@ -1043,8 +1151,8 @@ FNN_HD void decide_plan(const Dev& d, const double rx[4]) {
         else { X = y; Y = x; Z = xn; }
         int32_t k = Y >> 1;
         cur.u_id = nn + 1;
-        agg3_plan(d, X, Y, Z, 2 * k, 2 * k + 1, nn, m);
-        if (X != m - 1) move_slot(d, m - 1, X);  // close the hole in the singleton region
+        agg3_plan(d, T, X, Y, Z, 2 * k, 2 * k + 1, nn, m);
+        if (X != m - 1) move_slot(d, T, m - 1, X);  // close the hole in the singleton region
         st.num_nodes = nn + 2;
         st.m = m - 1;
         st.c -= 1;
@@ -1056,21 +1164,21 @@ FNN_HD void decide_plan(const Dev& d, const double rx[4]) {
         cur.kind = KIND_4WAY;
         int32_t kx = x >> 1, ky = y >> 1;
         int32_t U = 2 * kx, V = 2 * kx + 1;
-        agg3_plan(d, xn, x, y, U, V, nn, m);          // u1 = (x2,x), v1 = (x,y)
-        agg3_plan(d, U, V, yn, U, V, nn + 2, m - 1);  // u2 = (u1,v1), v2 = (v1,y2)
+        agg3_plan(d, T, xn, x, y, U, V, nn, m);          // u1 = (x2,x), v1 = (x,y)
+        agg3_plan(d, T, U, V, yn, U, V, nn + 2, m - 1);  // u2 = (u1,v1), v2 = (v1,y2)
         cur.u_id = nn + 3;
         // slots 2ky, 2ky+1 are now empty: refill from the last pair, then shrink the pair
         // region by one and refill its last two slots from the end of the singleton region
         int32_t lastp = P - 1;
         if (ky != lastp) {
-            move_slot(d, 2 * lastp, 2 * ky);
-            move_slot(d, 2 * lastp + 1, 2 * ky + 1);
+            move_slot(d, T, 2 * lastp, 2 * ky);
+            move_slot(d, T, 2 * lastp + 1, 2 * ky + 1);
             if (kx == lastp) U = 2 * ky;
         }
         int32_t h0 = 2 * lastp, h1 = 2 * lastp + 1;
         int32_t S = m - 2 * P;
-        if (S >= 1) move_slot(d, m - 1, h0);
-        if (S >= 2) move_slot(d, m - 2, h1);
+        if (S >= 1) move_slot(d, T, m - 1, h0);
+        if (S >= 2) move_slot(d, T, m - 2, h1);
         st.P = P - 1;
         st.num_nodes = nn + 4;
         st.m = m - 2;
@@ -1079,60 +1187,106 @@ FNN_HD void decide_plan(const Dev& d, const double rx[4]) {
         la_note_cluster(d, st, nn + 3, nn + 4);
     }
 }
-FNN_HD void decide(const Dev& d, const double rx[4]) {
-    decide_plan(d, rx);
-    build_targets(d);
-}
+
+// ---------------------------------------------------------------------------
+// The <= MAX_S slots involved in an event go through the reference's own per-node bodies
+// (subtractClusterDistance, the micro-ops, updateClusterDistances) one after the other.  Every
+// entry they read or write has BOTH indices in the involved set S (checked case by case in
+// DESIGN.md "k_update"), so they work on the S x S block of the matrix.  The bodies are written
+// against an accessor: GlobalAcc addresses the matrix in memory; BlockAcc a copy of the block
+// (the GPU keeps it in LDS: ~10 dependent phases at LDS instead of global-memory latency).
+// ---------------------------------------------------------------------------
+struct GlobalAcc {
+    const Dev& d;
+    FNN_HD double get(int32_t r, int32_t c) const { return d.D[(int64_t)r * d.ld + c]; }
+    FNN_HD void put(int32_t r, int32_t c, double v) const { store_d(d, r, c, v); }
+    FNN_HD double sx(int32_t s) const { return d.Sx[s]; }
+    FNN_HD void set_sx(int32_t s, double v) const { d.Sx[s] = v; }
+    FNN_HD double t(int32_t s) const { return d.T[s]; }
+    FNN_HD void set_t(int32_t s, double v) const { d.T[s] = v; }
+};
+struct BlockAcc {
+    double* blk;       // [MAX_S][MAX_S], entry (i, j) = D[S[i]][S[j]]
+    double* sxl;       // [MAX_S] row sums (NetNode.Sx)
+    double* tl;        // [MAX_S] approximate weighted row sums (Dev::T)
+    const int32_t* S;  // the involved slots
+    int32_t nS;
+    int32_t* err;      // set to 13 if a slot outside S is addressed (never expected)
+    FNN_HD int ix(int32_t s) const {
+#pragma unroll
+        for (int i = 0; i < MAX_S; i++)
+            if (i < nS && S[i] == s) return i;
+        *err = 13;
+        return 0;
+    }
+    FNN_HD double get(int32_t r, int32_t c) const { return blk[ix(r) * MAX_S + ix(c)]; }
+    FNN_HD void put(int32_t r, int32_t c, double v) const { blk[ix(r) * MAX_S + ix(c)] = v; }
+    FNN_HD double sx(int32_t s) const { return sxl[ix(s)]; }
+    FNN_HD void set_sx(int32_t s, double v) const { sxl[ix(s)] = v; }
+    FNN_HD double t(int32_t s) const { return tl[ix(s)]; }
+    FNN_HD void set_t(int32_t s, double v) const { tl[ix(s)] = v; }
+};
 
 // subtractClusterDistance(p, x); subtractClusterDistance(p, y) for p = node in slot s
 // (NetMakerOriginal.java:455-461, 681-696).  Old layout.
-FNN_HD void subtract_thread(const Dev& d, int32_t s) {
-    const State& st = *d.st;
+template <class Acc>
+FNN_HD void subtract_thread(const Acc& A, const State& st, int32_t s) {
     if (s >= st.m_old) return;
     if (s == st.xs || s == st.ys) return;  // i != x.positionID && i != y.positionID
     int32_t twoP = 2 * st.P_old;
     bool sp = s < twoP;
     if (sp && (s & 1)) return;  // not the representative
-    const double* D = d.D; const int64_t ld = d.ld;
-    double sx = d.Sx[s];
-    double sxn = sp ? d.Sx[s ^ 1] : 0.0;
+    double sx = A.sx(s);
+    double sxn = sp ? A.sx(s ^ 1) : 0.0;
+    double told0 = 0.0, told1 = 0.0;  // what the merging nodes contributed to T of node s (and of its partner)
+    bool bystander = true;
     for (int k = 0; k < 2; k++) {
         int32_t t = k == 0 ? st.xs : st.ys;
         int32_t tn = t < twoP ? (t ^ 1) : -1;
-        if (s == t || s == tn) continue;
+        if (s == t || s == tn) { bystander = false; continue; }
         double v;
-        if (!sp && tn < 0) v = D[t * ld + s];
-        else if (sp && tn < 0) v = (D[t * ld + s] + D[t * ld + (s ^ 1)]) / 2.0;
-        else if (!sp && tn >= 0) v = (D[t * ld + s] + D[tn * ld + s]) / 2.0;
-        else v = (((D[t * ld + s] + D[tn * ld + s]) + D[t * ld + (s ^ 1)]) + D[tn * ld + (s ^ 1)]) / 4.0;
+        if (!sp && tn < 0) { const double e = A.get(t, s); v = e; told0 += e; }
+        else if (sp && tn < 0) { const double e0 = A.get(t, s), e1 = A.get(t, s ^ 1); v = (e0 + e1) / 2.0; told0 += e0; told1 += e1; }
+        else if (!sp && tn >= 0) { const double e0 = A.get(t, s), f0 = A.get(tn, s); v = (e0 + f0) / 2.0; told0 += 0.5 * (e0 + f0); }
+        else {
+            const double e0 = A.get(t, s), f0 = A.get(tn, s), e1 = A.get(t, s ^ 1), f1 = A.get(tn, s ^ 1);
+            v = (((e0 + f0) + e1) + f1) / 4.0;
+            told0 += 0.5 * (e0 + f0); told1 += 0.5 * (e1 + f1);
+        }
         sx -= v;   // p.Sx -= Dpx
         sxn -= v;  // p.nbr.Sx -= Dpx
     }
-    d.Sx[s] = sx;
-    if (sp) d.Sx[s ^ 1] = sxn;
+    A.set_sx(s, sx);
+    if (sp) A.set_sx(s ^ 1, sxn);
+    if (bystander) {  // (a node of a merging cluster either disappears or gets a fresh T)
+        A.set_t(s, A.t(s) - told0);
+        if (sp) A.set_t(s ^ 1, A.t(s ^ 1) - told1);
+    }
 }
 
 // Bulk + special parts of one micro-op for slot k
-FNN_HD void op_thread(const Dev& d, const Op& op, int32_t k) {
+template <class Acc>
+FNN_HD void op_thread(const Acc& A, const Op& op, int32_t k) {
     if (k >= op.mcur) return;
-    double* D = d.D; const int64_t ld = d.ld;
     if (op.kind == OP_SWAP) {
         int32_t a = op.a, b = op.b;
         if (k == a) {
-            double t = d.Sx[a]; d.Sx[a] = d.Sx[b]; d.Sx[b] = t;
+            double t = A.sx(a); A.set_sx(a, A.sx(b)); A.set_sx(b, t);
+            t = A.t(a); A.set_t(a, A.t(b)); A.set_t(b, t);
         } else if (k != b) {
-            double ta = D[a * ld + k], tb = D[b * ld + k];
-            store_d(d, a, k, tb); store_d(d, k, a, tb);
-            store_d(d, b, k, ta); store_d(d, k, b, ta);
+            double ta = A.get(a, k), tb = A.get(b, k);
+            A.put(a, k, tb); A.put(k, a, tb);
+            A.put(b, k, ta); A.put(k, b, ta);
         }
     } else if (op.kind == OP_MOVE) {
         int32_t src = op.a, dst = op.b;
         if (k == src) {
-            store_d(d, dst, dst, 0.0);
-            d.Sx[dst] = d.Sx[src];
+            A.put(dst, dst, 0.0);
+            A.set_sx(dst, A.sx(src));
+            A.set_t(dst, A.t(src));
         } else if (k != dst) {
-            double t = D[src * ld + k];
-            store_d(d, dst, k, t); store_d(d, k, dst, t);
+            double t = A.get(src, k);
+            A.put(dst, k, t); A.put(k, dst, t);
         }
     } else if (op.kind == OP_AGG3) {
         int32_t X = op.a, Y = op.b, Z = op.c, U = op.d, V = op.e;
@@ -1140,39 +1294,54 @@ FNN_HD void op_thread(const Dev& d, const Op& op, int32_t k) {
             // the aliased entry D[u][v] and the diagonal (NetMakerOriginal.java:653-656, 670):
             // the in-place loop writes D[u][v] twice, once at p = u and once at p = v, the
             // second write reading the first
-            double dxz = D[X * ld + Z], dyx = D[Y * ld + X], dyz = D[Y * ld + Z];
+            double dxz = A.get(X, Z), dyx = A.get(Y, X), dyz = A.get(Y, Z);
             double uv;
             if (op.flag) uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + dyx / 3.0) + dyz / 3.0;
             else uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + dyz / 3.0) + dyx / 3.0;
-            store_d(d, U, U, 0.0); store_d(d, V, V, 0.0);
-            store_d(d, U, V, uv); store_d(d, V, U, uv);
+            A.put(U, U, 0.0); A.put(V, V, 0.0);
+            A.put(U, V, uv); A.put(V, U, uv);
         } else if (k != Y && k != Z) {
-            double dx = D[X * ld + k], dy = D[Y * ld + k], dz = D[Z * ld + k];
+            double dx = A.get(X, k), dy = A.get(Y, k), dz = A.get(Z, k);
             double nu = (2.0 / 3.0) * dx + dy / 3.0;
             double nv = (2.0 / 3.0) * dz + dy / 3.0;
-            store_d(d, U, k, nu); store_d(d, k, U, nu);
-            store_d(d, V, k, nv); store_d(d, k, V, nv);
+            A.put(U, k, nu); A.put(k, U, nu);
+            A.put(V, k, nv); A.put(k, V, nv);
         }
     }
 }
 
 // updateClusterDistances(u), per-node part (NetMakerOriginal.java:520-533). New layout.
-FNN_HD double add_thread(const Dev& d, int32_t s) {
-    const State& st = *d.st;
+// (the addend of the new cluster's sequential row sum goes to the chain buffer in memory either way)
+// tuv[0..1] receive this node's (and its partner's) terms of T of the new cluster's two nodes u, v.
+template <class Acc>
+FNN_HD double add_thread(const Acc& A, const Dev& d, const State& st, int32_t s, double tuv[2]) {
+    tuv[0] = tuv[1] = 0.0;
     if (s >= st.m) return 0.0;
     int32_t twoP = 2 * st.P;
     int32_t U = st.U, V = st.U + 1;
-    const double* D = d.D; const int64_t ld = d.ld;
     double val = 0.0;
     bool sp = s < twoP;
     bool rep = !sp || !(s & 1);
     if (rep && s != U) {
         double dpu;
-        if (!sp) dpu = (D[U * ld + s] + D[V * ld + s]) / 2.0;
-        else dpu = (((D[U * ld + s] + D[V * ld + s]) + D[U * ld + s + 1]) + D[V * ld + s + 1]) / 4.0;
-        d.Sx[s] += dpu;
-        if (sp) d.Sx[s + 1] += dpu;
+        const double u0 = A.get(U, s), v0 = A.get(V, s);
+        if (!sp) {
+            dpu = (u0 + v0) / 2.0;
+            A.set_t(s, A.t(s) + 0.5 * (u0 + v0));
+            tuv[0] = u0; tuv[1] = v0;
+        } else {
+            const double u1 = A.get(U, s + 1), v1 = A.get(V, s + 1);
+            dpu = (((u0 + v0) + u1) + v1) / 4.0;
+            A.set_t(s, A.t(s) + 0.5 * (u0 + v0));
+            A.set_t(s + 1, A.t(s + 1) + 0.5 * (u1 + v1));
+            tuv[0] = 0.5 * (u0 + u1); tuv[1] = 0.5 * (v0 + v1);
+        }
+        A.set_sx(s, A.sx(s) + dpu);
+        if (sp) A.set_sx(s + 1, A.sx(s + 1) + dpu);
         val = dpu;
+    } else if (s == U) {  // the partner's weight 1/2 in each other's sum
+        const double uv = A.get(U, V);
+        tuv[0] = 0.5 * uv; tuv[1] = 0.5 * uv;
     }
     d.chain[chain_addr(d.spos[s])] = val;  // adding +0.0 to a running sum that starts at +0.0 changes no bit
     return val;  // (this node's addend of the new cluster's row sum)
@@ -1214,8 +1383,10 @@ FNN_HD double tgt_compute(const Tgt& t, const double v[4]) {
 // Reads only rows of involved slots at its own column(s) and writes only entries with
 // exactly one index equal to its own column(s), so it cannot conflict with any other thread;
 // the involved slots themselves are handled by update_special_*.
-FNN_HD double update_bulk(const Dev& d, int32_t k) {
+// tuv[0..1] receive this cluster's terms of T of the new cluster's two nodes.
+FNN_HD double update_bulk(const Dev& d, int32_t k, double tuv[2]) {
     const State& st = *d.st;
+    tuv[0] = tuv[1] = 0.0;
     if (k >= st.m_old) return 0.0;
     const int32_t twoP = 2 * st.P_old;
     const bool paired = k < twoP;
@@ -1223,6 +1394,7 @@ FNN_HD double update_bulk(const Dev& d, int32_t k) {
     for (int i = 0; i < st.nS; i++) if (st.S[i] == k) return 0.0;
     double* D = d.D; const int64_t ld = d.ld;
     double sx0 = 0.0, sx1 = 0.0;
+    double told0 = 0.0, told1 = 0.0;  // what the merging nodes contributed to T of node k (k + 1)
     if (!st.ev_finish) {
         // subtractClusterDistance(p, x); subtractClusterDistance(p, y) (:455-461, 681-696)
         sx0 = d.Sx[k];
@@ -1231,10 +1403,14 @@ FNN_HD double update_bulk(const Dev& d, int32_t k) {
             const int32_t t = q == 0 ? st.xs : st.ys;
             const int32_t tn = t < twoP ? (t ^ 1) : -1;
             double v;
-            if (!paired && tn < 0) v = D[t * ld + k];
-            else if (paired && tn < 0) v = (D[t * ld + k] + D[t * ld + k + 1]) / 2.0;
-            else if (!paired && tn >= 0) v = (D[t * ld + k] + D[tn * ld + k]) / 2.0;
-            else v = (((D[t * ld + k] + D[tn * ld + k]) + D[t * ld + k + 1]) + D[tn * ld + k + 1]) / 4.0;
+            if (!paired && tn < 0) { const double e = D[t * ld + k]; v = e; told0 += e; }
+            else if (paired && tn < 0) { const double e0 = D[t * ld + k], e1 = D[t * ld + k + 1]; v = (e0 + e1) / 2.0; told0 += e0; told1 += e1; }
+            else if (!paired && tn >= 0) { const double e0 = D[t * ld + k], f0 = D[tn * ld + k]; v = (e0 + f0) / 2.0; told0 += 0.5 * (e0 + f0); }
+            else {
+                const double e0 = D[t * ld + k], f0 = D[tn * ld + k], e1 = D[t * ld + k + 1], f1 = D[tn * ld + k + 1];
+                v = (((e0 + f0) + e1) + f1) / 4.0;
+                told0 += 0.5 * (e0 + f0); told1 += 0.5 * (e1 + f1);
+            }
             sx0 -= v;
             sx1 -= v;
         }
@@ -1285,10 +1461,14 @@ FNN_HD double update_bulk(const Dev& d, int32_t k) {
         else dpu = (((u0 + v0) + u1) + v1) / 4.0;
         d.Sx[k] = sx0 + dpu;
         d.chain[chain_addr(d.spos[k])] = dpu;
+        // approximate weighted row sums: the merged nodes go, the new cluster's two nodes come (weight 1/2 each)
+        d.T[k] = (d.T[k] - told0) + 0.5 * (u0 + v0);
         if (paired) {
             d.Sx[k + 1] = sx1 + dpu;
             d.chain[chain_addr(d.spos[k + 1])] = 0.0;
-        }
+            d.T[k + 1] = (d.T[k + 1] - told1) + 0.5 * (u1 + v1);
+            tuv[0] = 0.5 * (u0 + u1); tuv[1] = 0.5 * (v0 + v1);
+        } else { tuv[0] = u0; tuv[1] = v0; }
         return dpu;  // (this cluster's addend of the new cluster's row sum)
     }
     return 0.0;
@@ -1298,19 +1478,37 @@ FNN_HD double update_bulk(const Dev& d, int32_t k) {
 // phase 0 subtract, phases 1..nops one micro-op each, last phase add.  Within a phase the
 // columns are independent; phases are separated by a workgroup barrier on the GPU.
 FNN_HD int32_t update_special_phases(const State& st) { return st.nops + 2; }
-FNN_HD double update_special(const Dev& d, int32_t phase, int32_t i) {
+template <class Acc>
+FNN_HD double update_special_acc(const Acc& A, const Dev& d, int32_t phase, int32_t i, double tuv[2]) {
     const State& st = *d.st;
+    tuv[0] = tuv[1] = 0.0;
     if (i >= st.nS) return 0.0;
     const int32_t k = st.S[i];
-    if (phase == 0) { if (!st.ev_finish) subtract_thread(d, k); }
-    else if (phase <= st.nops) { Op op = st.ops[phase - 1]; op_thread(d, op, k); }
-    else { if (!st.ev_finish) return add_thread(d, k); }
+    if (phase == 0) { if (!st.ev_finish) subtract_thread(A, st, k); }
+    else if (phase <= st.nops) { Op op = st.ops[phase - 1]; op_thread(A, op, k); }
+    else { if (!st.ev_finish) return add_thread(A, d, st, k, tuv); }
     return 0.0;
+}
+FNN_HD double update_special(const Dev& d, int32_t phase, int32_t i, double tuv[2]) { return update_special_acc(GlobalAcc{d}, d, phase, i, tuv); }
+// the block form: copy the S x S block and the row sums of S out of memory ... (phases on the copy) ... and back
+FNN_HD void special_block_load(const Dev& d, double* blk, double* sxl, double* tl, int32_t e) {  // e in [0, MAX_S * MAX_S)
+    const State& st = *d.st;
+    const int32_t i = e / MAX_S, j = e % MAX_S;
+    if (i < st.nS && j < st.nS) blk[e] = d.D[(int64_t)st.S[i] * d.ld + st.S[j]];
+    if (j == 0 && i < st.nS) sxl[i] = d.Sx[st.S[i]];
+    if (j == 1 && i < st.nS) tl[i] = d.T[st.S[i]];
+}
+FNN_HD void special_block_store(const Dev& d, const double* blk, const double* sxl, const double* tl, int32_t e) {
+    const State& st = *d.st;
+    const int32_t i = e / MAX_S, j = e % MAX_S;
+    if (i < st.nS && j < st.nS) store_d(d, st.S[i], st.S[j], blk[e]);
+    if (j == 0 && i < st.nS) d.Sx[st.S[i]] = sxl[i];
+    if (j == 1 && i < st.nS) d.T[st.S[i]] = tl[i];
 }
 
 // u.Sx = sequential sum; u.nbr.Sx = u.Sx (:518-519, 532, 535); close the event
-// everything that closes an event except the new cluster's exact row sum (the persistent event
-// kernel computes that sum beside the next event, see k_events)
+// everything that closes an event except the new cluster's exact row sum (computed beside the next
+// event's tracking, see k_track)
 FNN_HD void close_event(const Dev& d);
 FNN_HD void finalize(const Dev& d, double usx) {
     State& st = *d.st;
@@ -1351,6 +1549,7 @@ FNN_HD void init_thread(const Dev& d, int32_t k) {
             if (j0 + u < d.n && j0 + u != k) s += v[u];
     }
     d.Sx[k] = s;
+    d.T[k] = s;  // all singletons: the weighted row sum is the row sum
     d.sid[k] = k + 1;
     d.spos[k] = k;
     d.pslot[k] = k;

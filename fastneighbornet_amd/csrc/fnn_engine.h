@@ -33,7 +33,7 @@ inline double now_s() {
 }
 
 inline int64_t round_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
-// workgroups that may write a pair of partial sums into Dev::upart (k_update's grid; k_events' <= 64 main workgroups)
+// workgroups that may write a pair of partial sums into Dev::upart (k_update's grid)
 inline size_t upart_capacity(int32_t n) { size_t g = (size_t)(n > 0 ? n : 1) / 256 + 2; return g < 64 ? 64 : g; }
 
 template <class B>
@@ -84,7 +84,7 @@ class Engine {
             !(dev.pslot = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
             !(dev.chain = (double*)be.alloc(sizeof(double) * 4 * (size_t)dev.cstride)) ||
             !(dev.recs = (Cand*)be.alloc(sizeof(Cand) * be.max_records(n))) ||
-            !(dev.rxpart = (double*)be.alloc(sizeof(double) * 8 * (nn / 256 + 2))) ||
+            !(dev.T = (double*)be.alloc(sizeof(double) * (nn + 8))) ||
             !(dev.srec = (float*)be.alloc(sizeof(float) * (2 * (size_t)screen_unit_count(n > 0 ? n : 1) + 16))) ||
             !(dev.stile = (float*)be.alloc(sizeof(float) * (2 * (size_t)screen_unit_count(n > 0 ? n : 1) / 4 + 16))) ||
             !(dev.shit = (uint64_t*)be.alloc(sizeof(uint64_t) * ((size_t)screen_unit_count(n > 0 ? n : 1) + 16))) ||
@@ -94,13 +94,11 @@ class Engine {
             !(dev.tpairs = (int32_t*)be.alloc(sizeof(int32_t) * 4 * LA_PCAP)) ||
             !(dev.fresh = (int32_t*)be.alloc(sizeof(int32_t) * 2 * LA_KMAX)) ||
             !(dev.ticket = (uint32_t*)be.alloc(sizeof(uint32_t) * 32 * 72)) ||
-            !(dev.chrec = (uint64_t*)be.alloc(sizeof(uint64_t) * CHREC_WORDS)) ||
             !(dev.lacnt = (int32_t*)be.alloc(256)) ||
             !(dev.lalog = (double*)be.alloc(sizeof(double) * 5 * LA_LOGCAP)) ||
             // k_update (deferred close) leaves {sum, sum of magnitudes} per workgroup: ceil(m / 256) + 1 workgroups;
-            // the persistent event kernel at most 64 -> size it from the update grid like rxpart
-            !(dev.upart = (double*)be.alloc(sizeof(double) * 2 * upart_capacity(n))) ||
-            !(dev.evctl = (uint32_t*)be.alloc(1024)) ||
+            // -> sized from the update grid like rxpart
+            !(dev.upart = (double*)be.alloc(sizeof(double) * 4 * upart_capacity(n))) ||
             !(dev.gsend = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS)) ||
             !(dev.grecv = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS * 64)) ||
             !(dev.st = (State*)be.alloc(sizeof(State))) ||
@@ -120,7 +118,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.recs); be.free(dev.rxpart); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.chrec); be.free(dev.lacnt); be.free(dev.lalog); be.free(dev.upart); be.free(dev.evctl); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.recs); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }
@@ -239,7 +237,8 @@ class Engine {
             be.memset(dev.ticket, 0, sizeof(uint32_t) * 32 * 72) != FNN_OK || be.memset(dev.lacnt, 0, 256) != FNN_OK)
             return fail(FNN_EHIP, "fnn_begin: memset failed (" + be.err() + ")");
         if (n > 3) {
-            if (dev.H && be.launch_prep_screen(dev, nrows) != FNN_OK)
+            // max |D| (error bounds of the screening pass and of the certified 4-candidate choice), the bf16 copy if wanted
+            if (be.launch_prep_screen(dev, nrows) != FNN_OK)
                 return fail(FNN_EHIP, "fnn_begin: bf16 copy failed (" + be.err() + ")");
             if (be.launch_init(dev) != FNN_OK || be.sync() != FNN_OK)
                 return fail(FNN_EHIP, "fnn_begin: init failed (" + be.err() + ")");
@@ -267,8 +266,6 @@ class Engine {
     }
 
     // one event: scan (+ exchange of the per-rank candidates) + the rest of the sequence.
-    // window hits run inside the persistent event kernel (single rank, screened regime)
-    bool use_events() const { return dev.la && be.persistent && comm_mode == 0 && m_bound >= be.screen_min_m; }
     // after a state download: when will the open window have served its K events?
     void resync_schedule() {
         if (!dev.la) return;
@@ -308,16 +305,8 @@ class Engine {
         if (!begun) return fail(FNN_ESTATE, "fnn_step: call fnn_begin first");
         if (ended) return 0;
         int32_t rc;
-        bool served = false;
-        if (use_events() && hst.la_valid) {  // one event inside the persistent kernel, if the open window can serve it
-            const int64_t before = hst.n_events;
-            if (be.launch_events(dev, 1) != FNN_OK || be.sync() != FNN_OK) return fail(FNN_EHIP, "fnn_step: launch failed (" + be.err() + ")");
-            rc = pull_state();
-            if (rc != FNN_OK) return rc;
-            served = hst.n_events > before;
-        }
-        if (!served) {
-            rc = enqueue_event(use_events() ? (hst.la_valid ? 0 : 1) : -1);
+        {
+            rc = enqueue_event();
             if (rc != FNN_OK) return rc;
             if (be.sync() != FNN_OK) return fail(FNN_EHIP, "fnn_step: sync failed (" + be.err() + ")");
             rc = pull_state();
@@ -356,10 +345,7 @@ class Engine {
             // cluster is computed inside the next event's k_track (flushed before the host looks)
             be.defer_chain = dev.la != 0 && !std::getenv("FNN_NO_DEFER");
             for (int i = 0; i < batch; i++) {
-                // the persistent kernel serves the open window; whatever event is left then needs a scan
-                const bool evm = use_events();
-                if (evm && be.launch_events(dev, hst.la_K + 2) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
-                int32_t rce = enqueue_event(evm ? 1 : -1);
+                int32_t rce = enqueue_event();
                 if (rce != FNN_OK) return rce;
             }
             if (be.defer_chain && be.launch_chain_flush(dev) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
@@ -420,7 +406,7 @@ class Engine {
         stats.n_window_hits = hst.n_la_hits;
         stats.n_window_fails = hst.n_la_fail;
         stats.window_pairs = hst.la_pairs_sum;
-        stats.n_events_persistent = hst.n_ev_persistent;
+        stats.n_events_persistent = 0;  // (the persistent event kernel of round 1 is gone; field kept for ABI stability)
         stats.n_sweeps_exact = hst.n_su_exact + hst.n_sweep_waits;
         stats.n_stalled_events = hst.n_stalled;
         be.collect_timing(stats);

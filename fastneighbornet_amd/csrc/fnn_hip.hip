@@ -25,7 +25,6 @@
 //               exact u.Sx sum is deferred to the next k_track
 //   k_finalize  exact sequential u.Sx sum (:532), event log, loop condition (:339) - stepping API and
 //               configurations without windows; k_chain_flush: a deferred sum before the host looks
-//   k_events    experimental persistent kernel for window events (off by default)
 // Several GPUs: every rank scans 1/world of the tiles; the candidate records are all-gathered
 // (k_reduce_local + ncclAllGather) between the scan and k_rx_fill.
 #include <hip/hip_runtime.h>
@@ -647,7 +646,7 @@ __global__ __launch_bounds__(256) void k_prep_screen(Dev d, int64_t nrows) {
     const int64_t total = nrows * d.ld;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const double v = d.D[i];
-        d.H[i] = bf16_from_double(v);
+        if (d.H) d.H[i] = bf16_from_double(v);
         const int64_t r = i / d.ld, c = i - r * d.ld;
         if (r < d.n && c < d.n) {
             const unsigned long long x = f2u(v) & 0x7FFFFFFFFFFFFFFFULL;
@@ -689,61 +688,6 @@ __global__ __launch_bounds__(1024) void k_reduce_local(Dev d, int nrecs) {
     __shared__ Cand sh[16];
     Cand best = reduce_records(d, d.recs, nrecs, sh);
     if (threadIdx.x == 0) d.gsend[0] = best;
-}
-
-// ------------------------------------------------------------------ k_rx_fill
-// ComputeRx terms into the chain buffers + per-workgroup partial sums (tree order) of the terms
-// and of their magnitudes for the certified 4-candidate decision (fnn_core.h: rx_certify)
-__global__ __launch_bounds__(256) void k_rx_fill(Dev d, const Cand* src, int nrecs) {
-    __shared__ double sh[4][8];
-    __shared__ Cand shc[4];
-    __shared__ int zsh[5];
-    const State* st = d.st;
-    if (st->stall) return;  // (no scan kernels in this launch sequence and the window could not serve the event)
-    // the event's best candidate: every workgroup reduces the records for itself (no cross-
-    // workgroup hand-off); workgroup 0 also turns it into the event's control state
-    Cand best;
-    best.q = inf_f64();
-    best.key = ~0ULL;
-    if (st->la_hit) nrecs = 1;  // the lookahead window's minimum, left in recs[0] by k_track
-    if (!st->done)
-        for (int i = threadIdx.x; i < nrecs; i += 256) {
-            const Cand c = src[i];
-            if (cand_better(c, best)) best = c;
-        }
-    best = block_reduce<4>(best, shc);
-    if (threadIdx.x == 0) {
-        int32_t z[4];
-        const bool need = pick_slots(d, best, z);
-        zsh[0] = z[0]; zsh[1] = z[1]; zsh[2] = z[2]; zsh[3] = z[3]; zsh[4] = need ? 1 : 0;
-    }
-    __syncthreads();
-    const int32_t z[4] = {zsh[0], zsh[1], zsh[2], zsh[3]};
-    const bool need = zsh[4] != 0;
-    const int32_t m = st->m, twoP = 2 * st->P;  // (pick() does not change m, P)
-    __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) pick(d, best);
-    if (!need) return;
-    double term[4];
-    rx_fill_thread(d, blockIdx.x * 256 + threadIdx.x, m, twoP, z, term, false);
-    double v[8];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { v[k] = term[k]; v[4 + k] = term[k] < 0.0 ? -term[k] : term[k]; }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] += __shfl_down(v[k], off, 64);
-    }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) sh[w][k] = v[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        const int k = threadIdx.x;
-        d.rxpart[(size_t)blockIdx.x * 8 + k] = ((sh[0][k] + sh[1][k]) + sh[2][k]) + sh[3][k];
-    }
 }
 
 // ------------------------------------------------------------------ exact block-parallel chain sum
@@ -959,314 +903,22 @@ __device__ __forceinline__ double block_chain_sum(const double* __restrict__ buf
 }
 
 
-// ------------------------------------------------------------------ k_track
-// k_track: serve the event from the open lookahead window (fnn_core.h "Lookahead").  The work
-// items (tracked pairs, then the sweep of the newest cluster's rows) are spread over the track
-// workgroups; the last one to arrive reduces the per-workgroup minima and decides whether the
-// window certifies the minimum (la_hit: the scan kernels of this event return at once) or the
-// event has to scan.  force_base: the host's schedule asks for a new window at this event.
-//
-// Workgroup 0 is the CHAIN workgroup: when the previous event's k_update left the new cluster's
-// exact sequential row sum to be computed (chain_pending; ~20 us of one workgroup), it is computed
-// here, BESIDE the tracking.  Only the sweep of that cluster's own rows needs the sum: it runs on
-// the tree-ordered sum of k_update's partials, and its pairs compete in a separate record.  Both
-// summation orders are within eps of the exact sum, so if the best swept pair lies further than
-// the margin above the best other pair, the winner - an exactly evaluated pair - is certain.
-// Otherwise the last workgroup waits for the chain workgroup and sweeps again with the exact sum.
-constexpr int TRK_THREADS = 1024;
-constexpr int TRK_GROUP = 16;   // arrival tickets in two levels: same-address device-scope atomics cost ~50 ns each
-constexpr int TRK_FLAG = 32 * 65;  // word of d.ticket that carries "chain of event # done"
-constexpr int TRK_BAD = 32 * 67;   // word of d.ticket: a sweep item did not find the cluster it expected
-
-constexpr int CH_SPLIT_FLAG = 32 * 66;  // word of d.ticket: "records of a split chain sum are waiting in d.chrec"
-
-// The chain sum in two launches: its data-parallel steps beside the tracking (k_track), its walk beside
-// the candidate choice (k_decide4) - the sum is due only before k_update touches the row sums again.
-// Only for launch sequences without scan kernels (a scan needs every row sum) and one super-chunk.
-// has_scan bit 1 = "do not split" (FNN_CHAIN_SPLIT=0).
-__device__ __forceinline__ bool chain_split_mode(const State* st, int has_scan) {
-    return has_scan == 0 && st->chain_m <= CH_SC;
-}
-
-__device__ __forceinline__ void chain_records_store(const ChainLds<CH_EPT>& L, uint64_t* rec) {
-    const int tid = threadIdx.x;
-    rec[CHREC_OWN + tid] = L.own[tid];
-    rec[CHREC_SC + tid] = L.sc[tid];
-    reinterpret_cast<int32_t*>(rec + CHREC_E)[tid] = L.E[tid];
-    reinterpret_cast<int32_t*>(rec + CHREC_FLAGS)[tid] = L.flags[tid];
-    reinterpret_cast<int32_t*>(rec + CHREC_SLOT)[tid] = L.slot[tid];
-    const int nv = min(L.slot_count, CH_NSLOT) * CH_EPT;
-    const double* v = &L.vals[0][0];
-    for (int i = tid; i < nv; i += CH_T) rec[CHREC_VALS + i] = f2u(v[i]);
-}
-__device__ __forceinline__ void chain_records_load(ChainLds<CH_EPT>& L, const uint64_t* rec) {
-    const int tid = threadIdx.x;
-    L.own[tid] = rec[CHREC_OWN + tid];
-    L.sc[tid] = rec[CHREC_SC + tid];
-    L.E[tid] = reinterpret_cast<const int32_t*>(rec + CHREC_E)[tid];
-    L.flags[tid] = reinterpret_cast<const int32_t*>(rec + CHREC_FLAGS)[tid];
-    L.slot[tid] = reinterpret_cast<const int32_t*>(rec + CHREC_SLOT)[tid];
-    double* v = &L.vals[0][0];
-    for (int i = tid; i < CH_NSLOT * CH_EPT; i += CH_T) v[i] = u2f(rec[CHREC_VALS + i]);
-    if (tid == 0) L.s = 0.0;
-}
-
-__device__ __forceinline__ void chain_deliver(const Dev& d, double usx) {
-    State* st = d.st;
-    d.Sx[st->chain_U] = usx;      // u.Sx and u.nbr.Sx (NetMakerOriginal.java:532, 535)
-    d.Sx[st->chain_U + 1] = usx;
-}
-
-__device__ __forceinline__ void chain_workgroup(const Dev& d, ChainLds<CH_EPT>& L, bool split = false) {
-    State* st = d.st;
-    if (!st->chain_pending) return;
-    if (split) {
-        block_chain_sum<CH_EPT, 1>(d.chain, st->chain_m, CH_GUARD_BITS, L, nullptr);
-        chain_records_store(L, d.chrec);
-        __syncthreads();
-        if (threadIdx.x == 0) { __threadfence(); d.ticket[CH_SPLIT_FLAG] = 1u; }
-        return;
-    }
-    const double usx = block_chain_sum<CH_EPT>(d.chain, st->chain_m, CH_GUARD_BITS, L, nullptr);
-    if (threadIdx.x == 0) {
-        chain_deliver(d, usx);
-        d.ticket[CH_SPLIT_FLAG] = 0u;
-        __threadfence();
-        __hip_atomic_store(d.ticket + TRK_FLAG, (unsigned)st->n_events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// second half of a split chain sum (k_decide4's second workgroup)
-__device__ __forceinline__ void chain_walk_workgroup(const Dev& d, ChainLds<CH_EPT>& L) {
-    if (d.ticket[CH_SPLIT_FLAG] != 1u) return;
-    const State* st = d.st;
-    chain_records_load(L, d.chrec);
-    const double usx = block_chain_sum<CH_EPT, 2>(d.chain, st->chain_m, CH_GUARD_BITS, L, nullptr);
-    if (threadIdx.x == 0) {
-        chain_deliver(d, usx);
-        d.ticket[CH_SPLIT_FLAG] = 0u;
-        // (workgroup 0 copies the whole control block in and out, except when it has nothing to do:
-        //  only then may this workgroup write to it)
-        if (!st->ev_active || st->ev_finish || st->stall) d.st->chain_pending = 0;
-    }
-}
-
-// exact evaluation of the sweep items only, without inserting pairs (the approximate sweep did that)
-__device__ __forceinline__ void sweep_exact_item(const Dev& d, int64_t r, const TrackArgs& ta, Cand& bx) {
-    const int32_t half = (ta.m + 1) / 2;
-    const int32_t fi = ta.nf0 + (int32_t)(r / half), cp = (int32_t)(r % half);
-    if (fi >= ta.nf) return;
-    const int32_t id = d.fresh[2 * fi], stamp = d.fresh[2 * fi + 1];
-    const int32_t f0 = d.islot[id];
-    if (f0 < 0 || d.cstamp[id] != stamp) return;
-    const int32_t s2 = 2 * cp;
-    if (s2 >= ta.m || s2 == f0) return;
-    const double* F0 = d.D + (int64_t)f0 * d.ld + s2;
-    const double* F1 = F0 + d.ld;
-    const double a0 = F0[0], a1 = F0[1], b0 = F1[0], b1 = F1[1];
-    if (f0 > s2)
-        scan_micro(f0, s2, ta.m, ta.twoP, ta.cm2, a0, a1, b0, b1, d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1],
-                   d.Sx[s2], d.Sx[s2 + 1], d.spos[s2], d.spos[s2 + 1], bx);
-    else
-        scan_micro(s2, f0, ta.m, ta.twoP, ta.cm2, a0, b0, a1, b1, d.Sx[s2], d.Sx[s2 + 1], d.spos[s2], d.spos[s2 + 1],
-                   d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1], bx);
-}
-
-constexpr int TRK_REC_U = 1024;  // offset of the swept-pair records in d.recs
-
-__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed, int has_scan, int tgroup) {
-    __shared__ ChainLds<CH_EPT> L;
-    __shared__ Cand sh[TRK_THREADS / 64], shu[TRK_THREADS / 64];
-    __shared__ int lastflag;
-    __shared__ double shs[2];
-    State* st = d.st;
-    const bool split = chain_split_mode(st, has_scan);
-    has_scan &= 1;
-    if (blockIdx.x == 0) {  // the chain workgroup
-        chain_workgroup(d, L, split);
-        return;
-    }
-    const int wg = (int)blockIdx.x - 1, G = (int)gridDim.x - 1;
-    if (st->done) return;
-    if (!has_scan && st->stall) {  // (the launch sequence has no scan kernels and the window is gone: nothing to do)
-        if (wg == 0 && threadIdx.x == 0) st->n_stalled++;
-        return;
-    }
-    if (force_base || !la_active(*st)) {
-        if (wg == 0 && threadIdx.x == 0) {
-            st->ev_timed = timed;
-            if (st->la_valid) st->la_prev_end = 0;  // the window ends on schedule
-            la_prepare_base(*st, d.lacnt);
-            st->stall = has_scan ? 0 : 1;
-            if (!has_scan) st->n_stalled++;
-        }
-        return;
-    }
-    TrackArgs ta = track_args(*st);
-    const int64_t items = track_item_count(ta);
-    // The swept cluster's exact row sum is being computed by workgroup 0: the sweep runs on the tree-ordered
-    // sum of k_update's partials, which are fetched now and summed after the tracked pairs (their loads
-    // overlap).  (More than one unswept cluster is not expected: the window ends.)
-    double eps_u = 0.0;
-    bool giveup = false;  // the window cannot serve this event: it ends here (as after a failed certification)
-    const bool pending = st->chain_pending != 0 && ta.nf > ta.nf0;
-    if (pending && ta.nf - ta.nf0 != 1) giveup = true;
-    const bool approx = pending && !giveup;
-    double2 up0 = make_double2(0.0, 0.0), up1 = up0, up2 = up0;
-    const int npart = approx ? st->upart_n : 0;
-    if (threadIdx.x < 64) {
-        const double2* up = reinterpret_cast<const double2*>(d.upart);
-        if ((int)threadIdx.x < npart) up0 = up[threadIdx.x];
-        if ((int)threadIdx.x + 64 < npart) up1 = up[threadIdx.x + 64];
-        if ((int)threadIdx.x + 128 < npart) up2 = up[threadIdx.x + 128];
-    }
-    Cand best, bestu;
-    best.q = inf_f64();
-    best.key = ~0ULL;
-    bestu = best;
-    const int64_t stride = (int64_t)G * TRK_THREADS, start = (int64_t)wg * TRK_THREADS + threadIdx.x;
-    for (int64_t it = start; it < ta.np; it += stride) track_pair_item(d, it, ta, best);
-    if (approx) {
-        if (threadIdx.x < 64) {
-            double su = (up0.x + up1.x) + up2.x, sa = (up0.y + up1.y) + up2.y;
-            for (int b = threadIdx.x + 192; b < npart; b += 64) { su += d.upart[2 * b]; sa += d.upart[2 * b + 1]; }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) { su += __shfl_down(su, off, 64); sa += __shfl_down(sa, off, 64); }
-            if (threadIdx.x == 0) { shs[0] = su; shs[1] = sa; }
-        }
-        __syncthreads();
-        ta.approx = 1;
-        ta.usl = st->chain_U;
-        ta.sxu = shs[0];
-        // both the sequential and the tree order are within gamma_m sum|terms| of the exact sum
-        eps_u = 4.0 * ((double)ta.m + 8.0) * 1.1102230246251565e-16 * shs[1];
-    }
-    bool swept_ok = true;
-    if (!giveup)
-        for (int64_t r = start; r < items - ta.np; r += stride) swept_ok = track_sweep_item(d, r, ta, best, bestu) && swept_ok;
-    if (!swept_ok) atomicOr(d.ticket + TRK_BAD, 1u);  // (not expected: the swept cluster is not the chain's)
-    // both minima in one pass: wave reduction, one barrier, thread 0 folds the waves
-    {
-        best = wave_reduce(best);
-        if (ta.approx) bestu = wave_reduce(bestu);
-        const int lane_ = threadIdx.x & 63, w_ = threadIdx.x >> 6;
-        if (lane_ == 0) { sh[w_] = best; shu[w_] = bestu; }
-        __syncthreads();
-        if (w_ == 0) {  // the waves' minima: one more wave reduction (no serial walk through LDS)
-            Cand b2, bu2;
-            b2.q = inf_f64(); b2.key = ~0ULL; bu2 = b2;
-            if (lane_ < TRK_THREADS / 64) { b2 = sh[lane_]; bu2 = shu[lane_]; }
-            best = wave_reduce(b2);
-            if (ta.approx) bestu = wave_reduce(bu2);
-            if (lane_ == 0) {
-                d.recs[wg] = best;
-                if (ta.approx) d.recs[TRK_REC_U + wg] = bestu;
-            }
-        }
-    }
-    if (threadIdx.x == 0) {
-        __threadfence();
-        // last of its group of TRK_GROUP workgroups -> last of the groups (counters 128 bytes apart)
-        const unsigned g = (unsigned)wg / (unsigned)tgroup, ngroups = ((unsigned)G + tgroup - 1) / (unsigned)tgroup;
-        const unsigned gsize = g + 1 < ngroups ? (unsigned)tgroup : (unsigned)G - g * tgroup;
-        int last = 0;
-        if (atomicAdd(d.ticket + 32 * (g + 1), 1u) == gsize - 1) {
-            d.ticket[32 * (g + 1)] = 0u;
-            __threadfence();
-            last = atomicAdd(d.ticket, 1u) == ngroups - 1 ? 1 : 0;
-        }
-        lastflag = last;
-    }
-    __syncthreads();
-    if (!lastflag) return;
-    __threadfence();
-    // the records of all workgroups, both sets at once, by the first wave
-    if (threadIdx.x < 64) {
-        Cand b, bu;
-        b.q = inf_f64();
-        b.key = ~0ULL;
-        bu = b;
-        const unsigned badword = __hip_atomic_load(d.ticket + TRK_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int i = threadIdx.x; i < G; i += 64) {
-            Cand c;
-            c.q = __builtin_nontemporal_load(&d.recs[i].q);
-            c.key = __builtin_nontemporal_load(&d.recs[i].key);
-            if (cand_better(c, b)) b = c;
-            if (ta.approx) {
-                c.q = __builtin_nontemporal_load(&d.recs[TRK_REC_U + i].q);
-                c.key = __builtin_nontemporal_load(&d.recs[TRK_REC_U + i].key);
-                if (cand_better(c, bu)) bu = c;
-            }
-        }
-        b = wave_reduce(b);
-        if (ta.approx) bu = wave_reduce(bu);
-        if (threadIdx.x == 0) {
-            sh[0] = b;
-            shu[0] = bu;
-            if (badword != 0u) {
-                d.ticket[TRK_BAD] = 0u;
-                lastflag = 2;
-            }
-        }
-    }
-    __syncthreads();
-    best = sh[0];
-    bestu = shu[0];
-    if (lastflag == 2) giveup = true;
-    __syncthreads();
-    if (ta.approx && !giveup) {
-        // |Q~ - Q| <= eps_u + the roundings of (c-2) D - Sp - Sq, each <= 2^-53 of a term <= (c + 2n) Dmax
-        const double dmax = __builtin_bit_cast(double, st->dmax_bits);
-        const double margin = 2.0 * eps_u + 192.0 * 1.1102230246251565e-16 * ((double)st->n + 4.0) * dmax + 1e-300;
-        const bool certain = (bestu.q - margin > best.q) || (bestu.q == inf_f64());
-        if (!certain && split) giveup = true;  // (the exact sum comes only after this launch: the event scans instead)
-        else if (!certain) {
-            // a swept pair may be the minimum: wait for the chain workgroup, sweep again with the exact sum
-            if (threadIdx.x == 0) {
-                const unsigned want = (unsigned)st->n_events;
-                long spins = 0;
-                while (__hip_atomic_load(d.ticket + TRK_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-                    if (++spins > 20000000) { st->error = 10; break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                __threadfence();
-                st->n_sweep_waits++;
-            }
-            __syncthreads();
-            Cand bx;
-            bx.q = inf_f64();
-            bx.key = ~0ULL;
-            for (int64_t r = threadIdx.x; r < items - ta.np; r += TRK_THREADS) sweep_exact_item(d, r, ta, bx);
-            bx = block_reduce<TRK_THREADS / 64>(bx, sh);
-            if (threadIdx.x == 0) sh[0] = bx;
-            __syncthreads();
-            bx = sh[0];
-            if (cand_better(bx, best)) best = bx;
-        }
-        // certain: every swept pair's exact Q lies strictly above best.q, so best wins as it stands
-    }
-    if (giveup) { best.q = inf_f64(); best.key = ~0ULL; }
-    if (threadIdx.x == 0) {
-        *d.ticket = 0u;
-        st->ev_timed = timed;
-        if (giveup) st->n_sweep_waits++;
-        la_track_done(d, best, ta);
-        st->stall = (!st->la_hit && !has_scan) ? 1 : 0;
-        if (st->stall) st->n_stalled++;
-    }
-}
-
-// ------------------------------------------------------------------ k_decide4
-// Candidate choice + merge plan (NetMakerOriginal.java:413-488), one workgroup.  Common case:
-// the choice among the <=4 candidates is certified from the tree-ordered partial sums of
-// k_rx_fill.  Otherwise (candidates closer than the error bound, e.g. exact ties) the <=4
-// ComputeRx sums are evaluated exactly (block_chain_sum) first.
-// The plan is built by one thread on an LDS copy of the control block (dozens of dependent
-// accesses at LDS instead of L2 latency) that the workgroup copies in and out.
-// build_targets (fnn_core.h) by the 64 lanes of one wave: lane i holds involved slot S[i] and its
-// symbolic row; searches are ballots, the micro-ops are replayed with wave-uniform control and
-// readlane / lane-conditional moves.  (One thread doing this through the LDS copy of the control
-// block was ~150 dependent LDS accesses = 6 us of k_decide4's 14.)  Same results, field by field.
+// ------------------------------------------------------------------ the decide step
+// Cx / Cy from the event's best candidate (NetMakerOriginal.java:376-380), the 4-candidate choice
+// (:413-452) and the merge plan (:462-488), by ONE workgroup: the last tracking workgroup of k_track
+// for events served by a lookahead window, k_decide for events that scanned.
+//   * the candidate's slots, the slot-table entries the plan can touch (fnn_core.h: tab_keys), the
+//     4 x 4 block of the matrix over the two clusters' nodes and their approximate weighted row sums
+//     T are fetched lane-parallel in two round trips; wave 1 sums the partial sums of T of the
+//     previous event's new cluster beside the first one;
+//   * the choice among the <= 4 candidates is certified from T (fnn_core.h: rx_from_T, rx_certify);
+//     only if two candidates are closer than the error bound (exact ties, ...) the whole workgroup
+//     evaluates the <= 4 ComputeRx sums exactly (block_chain_sum) first;
+//   * one thread replays the integer side of the merge on the preloaded table entries (CachedTab:
+//     registers; stores write through), one wave replays the micro-ops symbolically
+//     (build_targets_wave: lane i holds involved slot S[i] and its symbolic row; searches are
+//     ballots, the micro-ops run with wave-uniform control through readlane and lane-conditional
+//     moves).  All of it on an LDS copy of the control block that the workgroup copies in and out.
 __device__ __forceinline__ void build_targets_wave(State& st) {
     const int lane = threadIdx.x & 63;
     const int nops = __builtin_amdgcn_readfirstlane(st.nops);
@@ -1361,149 +1013,529 @@ __device__ __forceinline__ void build_targets_wave(State& st) {
     }
 }
 
-__device__ __forceinline__ void decide_on_lds_copy(const Dev& d, State& lst, const double r_in[4], bool use_r,
-                                                   int certified) {
-    State* gst = d.st;
-    constexpr int NW = (int)(sizeof(State) / 4);
-    static_assert(sizeof(State) % 4 == 0, "State must be a whole number of dwords");
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(gst);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&lst);
-        for (int i = threadIdx.x; i < NW; i += blockDim.x) dst[i] = src[i];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        Dev dl = d;
-        dl.st = &lst;
-        double r[4] = {0.0, 0.0, 0.0, 0.0};
-        if (use_r) { r[0] = r_in[0]; r[1] = r_in[1]; r[2] = r_in[2]; r[3] = r_in[3]; }
-        if (lst.need_rx) { if (certified) lst.n_rx_certified++; else lst.n_rx_exact++; }
-        decide_plan(dl, r);
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) build_targets_wave(lst);
-    __syncthreads();
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&lst);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(gst);
-        for (int i = threadIdx.x; i < NW; i += blockDim.x) dst[i] = src[i];
-    }
+
+struct DecideLds {
+    State lst;                 // the control block while the workgroup works on it
+    int32_t key[TAB_NK], vsid[TAB_NK], vspos[TAB_NK];
+    int32_t pkey[TAB_NP], vpslot[TAB_NP];
+    int32_t ij[2], ab[2];      // reference positions and slots of the candidate's two nodes
+    int32_t need, cert, exact, misses;
+    long long tk[10];          // k_track: timestamps of the phase split (diagnostic)
+    double quad[16];           // D over {a, a^1, b, b^1} x {a, a^1, b, b^1}
+    double tz[4];              // T of a, a^1, b, b^1
+    double tfin[2];            // T of the previous event's new cluster, just summed
+    double rx[4];
+    Quad qd;
+};
+
+constexpr int ST_NW = (int)(sizeof(State) / 4);
+static_assert(sizeof(State) % 4 == 0, "State must be a whole number of dwords");
+__device__ __forceinline__ void state_in(State& lst, const State* gst) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(gst);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&lst);
+    for (int i = threadIdx.x; i < ST_NW; i += blockDim.x) dst[i] = src[i];
+}
+__device__ __forceinline__ void state_out(State* gst, const State& lst) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&lst);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(gst);
+    for (int i = threadIdx.x; i < ST_NW; i += blockDim.x) dst[i] = src[i];
 }
 
-__device__ __forceinline__ void decide4_body(const Dev& d, int nparts, ChainLds<CH_EPT>& L, State& lst, double* red) {
-    State* st = d.st;
-    if (!st->ev_active || st->ev_finish || st->stall) return;
-    const int need_rx = st->need_rx;
-    double rxa[4] = {0.0, 0.0, 0.0, 0.0};
-    int certified = 1;
-    if (need_rx) {
-        {   // sum the partials of k_rx_fill ([workgroup][8] doubles): one load per thread, all in flight
-            // at once (any summation order will do: the sums are only certified, not used as exact)
-            __shared__ double wred[CH_T / 64][8];
-            double v = 0.0;
-            for (int idx = threadIdx.x; idx < nparts * 8; idx += CH_T) v += d.rxpart[idx];
-            // lanes l, l + 8, l + 16, ... of a wave hold the same component k = l & 7
-            v += __shfl_xor(v, 8, 64);
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            const int lane_ = threadIdx.x & 63, w_ = threadIdx.x >> 6;
-            if (lane_ < 8) wred[w_][lane_] = v;
-            __syncthreads();
-            if (threadIdx.x < 8) {
-                double acc = 0.0;
-                for (int q = 0; q < CH_T / 64; q++) acc += wred[q][threadIdx.x];
-                red[threadIdx.x] = acc;
-            }
+// All threads of a 1024-thread workgroup call this; S.lst holds the control block (visible to the whole
+// workgroup); `best` is valid in thread 0.  d.st is NOT used: dl.st points at the LDS copy.
+__device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds<CH_EPT>& L, Cand best) {
+    State& lst = S.lst;
+    Dev dl = d;
+    dl.st = &lst;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) {
+        S.need = pick_needs_candidate(lst) ? 1 : 0;
+        S.ij[0] = (int32_t)(best.key >> 32);
+        S.ij[1] = (int32_t)(best.key & 0xFFFFFFFFu);
+        S.cert = 1;
+        S.exact = 0;
+    }
+    __syncthreads();
+    const bool need = S.need != 0;
+    const int32_t m = lst.m, P = lst.P;
+    // round trip 1: the candidate's slots, pslot of the last two positions; T of the newest cluster
+    if (wv == 0) {
+        if (lane < 2 && need) S.ab[lane] = d.pslot[S.ij[lane]];
+        if (lane >= 2 && lane < 2 + TAB_NP) {
+            const int32_t pk = m - 1 - (lane - 2);
+            S.pkey[lane - 2] = pk >= 0 ? pk : -1;
+            S.vpslot[lane - 2] = pk >= 0 ? d.pslot[pk] : 0;
         }
-        __syncthreads();
-        double rxs[4];
+    } else if (wv == 1) {
+        const int np = lst.tp_n;
+        if (np > 0) {
+            double tu = 0.0, tv = 0.0;
+            for (int g = lane; g < np; g += 64) {
+                const double2 v = *reinterpret_cast<const double2*>(d.upart + 4 * g + 2);
+                tu += v.x; tv += v.y;
+            }
 #pragma unroll
-        for (int k = 0; k < 4; k++) { rxa[k] = red[k]; rxs[k] = red[4 + k]; }
-        certified = rx_certify(d, rxa, rxs) ? 1 : 0;
-        if (!certified) {
-            // rare: the <=4 sums exactly, one after the other in this workgroup; their addends go to the
-            // chain buffers first (the rx phase only formed the tree sums)
-            const int z[4] = {st->sa, st->sap, st->sb, st->sbp};
-            const int m_old = st->m_old;
-            {
-                const int32_t zz[4] = {z[0], z[1], z[2], z[3]};
-                const int32_t twoP_old = 2 * st->P_old;
-                for (int32_t sl = threadIdx.x; sl < m_old; sl += blockDim.x) {
-                    double term[4];
-                    rx_fill_thread(d, sl, m_old, twoP_old, zz, term, true);
-                }
-                __threadfence_block();
-                __syncthreads();
-            }
-            for (int b = 0; b < 4; b++) {
-                rxa[b] = 0.0;
-                if (z[b] >= 0) rxa[b] = block_chain_sum<CH_EPT>(d.chain + (size_t)b * d.cstride, m_old, CH_GUARD_BITS, L, nullptr);
+            for (int off = 32; off >= 1; off >>= 1) { tu += __shfl_down(tu, off, 64); tv += __shfl_down(tv, off, 64); }
+            if (lane == 0) {
+                S.tfin[0] = tu; S.tfin[1] = tv;
+                d.T[lst.tp_U] = tu;
+                d.T[lst.tp_U + 1] = tv;
             }
         }
     }
-    decide_on_lds_copy(d, lst, rxa, need_rx != 0, certified);
-}
-
-__global__ __launch_bounds__(CH_T) void k_decide4(Dev d, int nparts) {
-    __shared__ ChainLds<CH_EPT> L;
-    __shared__ State lst;
-    __shared__ double red[8];
-    if (blockIdx.x == 1) {  // the walk of a chain sum that k_track's chain workgroup began
-        chain_walk_workgroup(d, L);
+    __syncthreads();
+    const int32_t tpU = lst.tp_n > 0 ? lst.tp_U : -2;
+    __syncthreads();
+    if (tid == 64) lst.tp_n = 0;
+    // round trip 2: table entries, the 4 x 4 block, T
+    if (wv == 0 && need) {
+        const int32_t a = S.ab[0], b = S.ab[1];
+        int32_t key[TAB_NK], pkey[TAB_NP];
+        tab_keys(a, b, P, m, key, pkey);
+        const int32_t s4[4] = {a, a ^ 1, b, b ^ 1};
+        if (lane < TAB_NK) {
+            int32_t k = -1;
+#pragma unroll
+            for (int q = 0; q < TAB_NK; q++) if (q == lane) k = key[q];
+            if (k < 0 || k >= d.n) k = -1;
+            S.key[lane] = k;
+            S.vsid[lane] = k >= 0 ? d.sid[k] : 0;
+            S.vspos[lane] = k >= 0 ? d.spos[k] : 0;
+        } else if (lane >= 16 && lane < 32) {
+            const int r = (lane - 16) >> 2, c = (lane - 16) & 3;
+            int32_t sr = 0, sc = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { if (q == r) sr = s4[q]; if (q == c) sc = s4[q]; }
+            S.quad[lane - 16] = d.D[(int64_t)sr * d.ld + sc];
+        } else if (lane >= 32 && lane < 36) {
+            int32_t sl = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (q == lane - 32) sl = s4[q];
+            S.tz[lane - 32] = sl == tpU ? S.tfin[0] : (sl == tpU + 1 ? S.tfin[1] : d.T[sl]);
+        }
+    }
+    __syncthreads();
+    // Cx / Cy, then the certified choice
+    Quad& qd = S.qd;
+    if (tid == 0) {
+        const int32_t a = need ? S.ab[0] : 0, b = need ? S.ab[1] : 0;
+        pick(dl, best, a, b, need ? S.vsid[0] : 0, need ? S.vsid[2] : 0);
+        if (lst.ev_active && !lst.ev_finish) {
+            // (pick may have exchanged the two nodes: Cx is the one with the smaller id)
+            const int oa = lst.sa == a ? 0 : 2, ob = 2 - oa;
+            auto q4 = [&](int r, int c) { return S.quad[r * 4 + c]; };
+            qd.Tz[0] = S.tz[oa]; qd.Tz[1] = lst.sap >= 0 ? S.tz[oa + 1] : 0.0;
+            qd.Tz[2] = S.tz[ob]; qd.Tz[3] = lst.sbp >= 0 ? S.tz[ob + 1] : 0.0;
+            qd.Dab = q4(oa, ob);
+            qd.Dapb = lst.sap >= 0 ? q4(oa + 1, ob) : 0.0;
+            qd.Dabp = lst.sbp >= 0 ? q4(oa, ob + 1) : 0.0;
+            qd.Dapbp = (lst.sap >= 0 && lst.sbp >= 0) ? q4(oa + 1, ob + 1) : 0.0;
+            qd.Daap = lst.sap >= 0 ? q4(oa, oa + 1) : 0.0;
+            qd.Dbbp = lst.sbp >= 0 ? q4(ob, ob + 1) : 0.0;
+            double rx[4] = {0.0, 0.0, 0.0, 0.0};
+            if (lst.need_rx) {
+                rx_from_T(lst, qd, rx);
+                if (rx_certify(lst, qd, rx)) lst.n_rx_certified++;
+                else { S.cert = 0; lst.n_rx_exact++; }
+            }
+            S.rx[0] = rx[0]; S.rx[1] = rx[1]; S.rx[2] = rx[2]; S.rx[3] = rx[3];
+        }
+    }
+    __syncthreads();
+    if (!lst.ev_active) return;  // the loop has ended
+    if (lst.ev_finish) {         // the special finish: planned inside pick; only the symbolic replay is left
+        if (tid < 64) build_targets_wave(lst);
+        __syncthreads();
         return;
     }
-    decide4_body(d, nparts, L, lst, red);
+    if (!S.cert) {
+        // rare: the <= 4 sums exactly, one after the other in this workgroup; their addends go to the chain buffers first
+        const int32_t z[4] = {lst.sa, lst.sap, lst.sb, lst.sbp};
+        const int32_t m_old = lst.m_old, twoP_old = 2 * lst.P_old;
+        for (int32_t sl = tid; sl < m_old; sl += blockDim.x) rx_fill_thread(d, sl, m_old, twoP_old, z);
+        __threadfence_block();
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            double r = 0.0;
+            if (z[b] >= 0) r = block_chain_sum<CH_EPT>(d.chain + (size_t)b * d.cstride, m_old, CH_GUARD_BITS, L, nullptr);
+            if (tid == 0) S.rx[b] = r;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        S.misses = 0;
+        CachedTab T{d, S.key, S.vsid, S.vspos, S.pkey, S.vpslot, &S.misses};
+        const double rx[4] = {S.rx[0], S.rx[1], S.rx[2], S.rx[3]};
+        decide_plan(dl, T, qd, rx);
+    }
+    __syncthreads();
+    if (tid < 64) build_targets_wave(lst);
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ k_decide
+// the decide step of an event that scanned: the scan's (or all ranks') candidate records are reduced first
+__global__ __launch_bounds__(CH_T) void k_decide(Dev d, const Cand* src, int nrecs) {
+    __shared__ ChainLds<CH_EPT> L;
+    __shared__ DecideLds S;
+    __shared__ Cand shc[CH_T / 64];
+    State* st = d.st;
+    if (st->stall || st->la_hit) return;  // (nothing to decide / the tail of k_track has decided this event already)
+    state_in(S.lst, st);
+    Cand best = reduce_records(d, src, nrecs, shc);
+    __syncthreads();
+    decide_step(d, S, L, best);
+    __syncthreads();
+    state_out(st, S.lst);
+}
+
+// ------------------------------------------------------------------ k_track
+// k_track: serve the event from the open lookahead window (fnn_core.h "Lookahead").  The work
+// items (tracked pairs, then the sweep of the newest cluster's rows) are spread over the track
+// workgroups; the last one to arrive reduces the per-workgroup minima and decides whether the
+// window certifies the minimum (la_hit: the scan kernels of this event return at once) or the
+// event has to scan.  force_base: the host's schedule asks for a new window at this event.
+//
+// Workgroup 0 is the CHAIN workgroup: when the previous event's k_update left the new cluster's
+// exact sequential row sum to be computed (chain_pending; ~20 us of one workgroup), it is computed
+// here, BESIDE the tracking.  Only the sweep of that cluster's own rows needs the sum: it runs on
+// the tree-ordered sum of k_update's partials, and its pairs compete in a separate record.  Both
+// summation orders are within eps of the exact sum, so if the best swept pair lies further than
+// the margin above the best other pair, the winner - an exactly evaluated pair - is certain.
+// Otherwise the last workgroup waits for the chain workgroup and sweeps again with the exact sum.
+constexpr int TRK_THREADS = 1024;
+constexpr int TRK_GROUP = 16;   // arrival tickets in two levels: same-address device-scope atomics cost ~50 ns each
+constexpr int TRK_FLAG = 32 * 65;  // word of d.ticket that carries "chain of event # done"
+constexpr int TRK_BAD = 32 * 67;   // word of d.ticket: a sweep item did not find the cluster it expected
+
+__device__ __forceinline__ void chain_deliver(const Dev& d, double usx) {
+    State* st = d.st;
+    d.Sx[st->chain_U] = usx;      // u.Sx and u.nbr.Sx (NetMakerOriginal.java:532, 535)
+    d.Sx[st->chain_U + 1] = usx;
+}
+
+__device__ __forceinline__ void chain_workgroup(const Dev& d, ChainLds<CH_EPT>& L) {
+    State* st = d.st;
+    if (!st->chain_pending) return;
+    const double usx = block_chain_sum<CH_EPT>(d.chain, st->chain_m, CH_GUARD_BITS, L, nullptr);
+    if (threadIdx.x == 0) {
+        chain_deliver(d, usx);
+        __threadfence();
+        __hip_atomic_store(d.ticket + TRK_FLAG, (unsigned)st->n_events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// exact evaluation of the sweep items only, without inserting pairs (the approximate sweep did that)
+__device__ __forceinline__ void sweep_exact_item(const Dev& d, int64_t r, const TrackArgs& ta, Cand& bx) {
+    const int32_t half = (ta.m + 1) / 2;
+    const int32_t fi = ta.nf0 + (int32_t)(r / half), cp = (int32_t)(r % half);
+    if (fi >= ta.nf) return;
+    const int32_t id = d.fresh[2 * fi], stamp = d.fresh[2 * fi + 1];
+    const int32_t f0 = d.islot[id];
+    if (f0 < 0 || d.cstamp[id] != stamp) return;
+    const int32_t s2 = 2 * cp;
+    if (s2 >= ta.m || s2 == f0) return;
+    const double* F0 = d.D + (int64_t)f0 * d.ld + s2;
+    const double* F1 = F0 + d.ld;
+    const double a0 = F0[0], a1 = F0[1], b0 = F1[0], b1 = F1[1];
+    if (f0 > s2)
+        scan_micro(f0, s2, ta.m, ta.twoP, ta.cm2, a0, a1, b0, b1, d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1],
+                   d.Sx[s2], d.Sx[s2 + 1], d.spos[s2], d.spos[s2 + 1], bx);
+    else
+        scan_micro(s2, f0, ta.m, ta.twoP, ta.cm2, a0, b0, a1, b1, d.Sx[s2], d.Sx[s2 + 1], d.spos[s2], d.spos[s2 + 1],
+                   d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1], bx);
+}
+
+constexpr int TRK_REC_U = 1024;  // offset of the swept-pair records in d.recs
+
+__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed, int has_scan, int tgroup, int ticks) {
+    __shared__ ChainLds<CH_EPT> L;
+    __shared__ DecideLds S;
+    __shared__ Cand sh[TRK_THREADS / 64], shu[TRK_THREADS / 64];
+    __shared__ int lastflag;
+    __shared__ double shs[2];
+    State* st = d.st;
+    if (blockIdx.x == 0) {  // the chain workgroup
+        chain_workgroup(d, L);
+        return;
+    }
+    const int wg = (int)blockIdx.x - 1, G = (int)gridDim.x - 1;
+    // phase split of the last-arriving workgroup (diagnostic, FNN_TICKS=1): thread 0 stamps the 100 MHz clock
+    const bool prof = ticks != 0 && threadIdx.x == 0;
+#define TRK_TICK(slot) do { if (prof) S.tk[(slot) + 1] = (long long)wall_clock64(); } while (0)
+    if (prof) S.tk[0] = (long long)wall_clock64();
+    if (st->done) {
+        if (wg == 0 && threadIdx.x == 0) st->ev_active = 0;  // (a launch sequence without a decide kernel must not replay the last event)
+        return;
+    }
+    if (!has_scan && st->stall) {  // (the launch sequence has no scan kernels and the window is gone: nothing to do)
+        if (wg == 0 && threadIdx.x == 0) st->n_stalled++;
+        return;
+    }
+    if (force_base || !la_active(*st)) {
+        if (wg == 0 && threadIdx.x == 0) {
+            st->ev_timed = timed;
+            if (st->la_valid) st->la_prev_end = 0;  // the window ends on schedule
+            la_prepare_base(*st, d.lacnt);
+            st->stall = has_scan ? 0 : 1;
+            if (!has_scan) st->n_stalled++;
+        }
+        return;
+    }
+    TrackArgs ta = track_args(*st);
+    const int64_t items = track_item_count(ta);
+    // The swept cluster's exact row sum is being computed by workgroup 0: the sweep runs on the tree-ordered
+    // sum of k_update's partials, which are fetched now and summed after the tracked pairs (their loads
+    // overlap).  (More than one unswept cluster is not expected: the window ends.)
+    double eps_u = 0.0;
+    bool giveup = false;  // the window cannot serve this event: it ends here (as after a failed certification)
+    const bool pending = st->chain_pending != 0 && ta.nf > ta.nf0;
+    if (pending && ta.nf - ta.nf0 != 1) giveup = true;
+    const bool approx = pending && !giveup;
+    double2 up0 = make_double2(0.0, 0.0), up1 = up0, up2 = up0;
+    const int npart = approx ? st->upart_n : 0;
+    if (threadIdx.x < 64) {
+        const double2* up = reinterpret_cast<const double2*>(d.upart);  // [workgroup] {sum, sum of magnitudes | T partials}
+        if ((int)threadIdx.x < npart) up0 = up[2 * threadIdx.x];
+        if ((int)threadIdx.x + 64 < npart) up1 = up[2 * (threadIdx.x + 64)];
+        if ((int)threadIdx.x + 128 < npart) up2 = up[2 * (threadIdx.x + 128)];
+    }
+    Cand best, bestu;
+    best.q = inf_f64();
+    best.key = ~0ULL;
+    bestu = best;
+    const int64_t stride = (int64_t)G * TRK_THREADS, start = (int64_t)wg * TRK_THREADS + threadIdx.x;
+    TRK_TICK(0);
+    for (int64_t it = start; it < ta.np; it += stride) track_pair_item(d, it, ta, best);
+    TRK_TICK(1);
+    if (approx) {
+        if (threadIdx.x < 64) {
+            double su = (up0.x + up1.x) + up2.x, sa = (up0.y + up1.y) + up2.y;
+            for (int b = threadIdx.x + 192; b < npart; b += 64) { su += d.upart[4 * b]; sa += d.upart[4 * b + 1]; }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { su += __shfl_down(su, off, 64); sa += __shfl_down(sa, off, 64); }
+            if (threadIdx.x == 0) { shs[0] = su; shs[1] = sa; }
+        }
+        __syncthreads();
+        ta.approx = 1;
+        ta.usl = st->chain_U;
+        ta.sxu = shs[0];
+        // both the sequential and the tree order are within gamma_m sum|terms| of the exact sum
+        eps_u = 4.0 * ((double)ta.m + 8.0) * 1.1102230246251565e-16 * shs[1];
+    }
+    bool swept_ok = true;
+    if (!giveup)
+        for (int64_t r = start; r < items - ta.np; r += stride) swept_ok = track_sweep_item(d, r, ta, best, bestu) && swept_ok;
+    if (!swept_ok) atomicOr(d.ticket + TRK_BAD, 1u);  // (not expected: the swept cluster is not the chain's)
+    TRK_TICK(2);
+    // both minima in one pass: wave reduction, one barrier, thread 0 folds the waves
+    {
+        best = wave_reduce(best);
+        if (ta.approx) bestu = wave_reduce(bestu);
+        const int lane_ = threadIdx.x & 63, w_ = threadIdx.x >> 6;
+        if (lane_ == 0) { sh[w_] = best; shu[w_] = bestu; }
+        __syncthreads();
+        if (w_ == 0) {  // the waves' minima: one more wave reduction (no serial walk through LDS)
+            Cand b2, bu2;
+            b2.q = inf_f64(); b2.key = ~0ULL; bu2 = b2;
+            if (lane_ < TRK_THREADS / 64) { b2 = sh[lane_]; bu2 = shu[lane_]; }
+            best = wave_reduce(b2);
+            if (ta.approx) bestu = wave_reduce(bu2);
+            if (lane_ == 0) {
+                d.recs[wg] = best;
+                if (ta.approx) d.recs[TRK_REC_U + wg] = bestu;
+            }
+        }
+    }
+    TRK_TICK(3);
+    if (threadIdx.x == 0) {
+        __threadfence();
+        // last of its group of TRK_GROUP workgroups -> last of the groups (counters 128 bytes apart)
+        const unsigned g = (unsigned)wg / (unsigned)tgroup, ngroups = ((unsigned)G + tgroup - 1) / (unsigned)tgroup;
+        const unsigned gsize = g + 1 < ngroups ? (unsigned)tgroup : (unsigned)G - g * tgroup;
+        int last = 0;
+        if (atomicAdd(d.ticket + 32 * (g + 1), 1u) == gsize - 1) {
+            d.ticket[32 * (g + 1)] = 0u;
+            __threadfence();
+            last = atomicAdd(d.ticket, 1u) == ngroups - 1 ? 1 : 0;
+        }
+        lastflag = last;
+    }
+    __syncthreads();
+    if (!lastflag) return;
+    __threadfence();
+    TRK_TICK(4);
+    // from here on this workgroup works on an LDS copy of the control block (no other workgroup writes to it
+    // during this launch); the copy goes back at the end
+    state_in(S.lst, st);
+    State& lst = S.lst;
+    Dev dl = d;
+    dl.st = &lst;
+    // the records of all workgroups, both sets at once, by the first wave
+    if (threadIdx.x < 64) {
+        Cand b, bu;
+        b.q = inf_f64();
+        b.key = ~0ULL;
+        bu = b;
+        const unsigned badword = __hip_atomic_load(d.ticket + TRK_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = threadIdx.x; i < G; i += 64) {
+            Cand c;
+            c.q = __builtin_nontemporal_load(&d.recs[i].q);
+            c.key = __builtin_nontemporal_load(&d.recs[i].key);
+            if (cand_better(c, b)) b = c;
+            if (ta.approx) {
+                c.q = __builtin_nontemporal_load(&d.recs[TRK_REC_U + i].q);
+                c.key = __builtin_nontemporal_load(&d.recs[TRK_REC_U + i].key);
+                if (cand_better(c, bu)) bu = c;
+            }
+        }
+        b = wave_reduce(b);
+        if (ta.approx) bu = wave_reduce(bu);
+        if (threadIdx.x == 0) {
+            sh[0] = b;
+            shu[0] = bu;
+            if (badword != 0u) {
+                d.ticket[TRK_BAD] = 0u;
+                lastflag = 2;
+            }
+        }
+    }
+    __syncthreads();
+    best = sh[0];
+    bestu = shu[0];
+    if (lastflag == 2) giveup = true;
+    __syncthreads();
+    TRK_TICK(5);
+    if (ta.approx && !giveup) {
+        // |Q~ - Q| <= eps_u + the roundings of (c-2) D - Sp - Sq, each <= 2^-53 of a term <= (c + 2n) Dmax
+        const double dmax = __builtin_bit_cast(double, st->dmax_bits);
+        const double margin = 2.0 * eps_u + 192.0 * 1.1102230246251565e-16 * ((double)st->n + 4.0) * dmax + 1e-300;
+        const bool certain = (bestu.q - margin > best.q) || (bestu.q == inf_f64());
+        if (!certain) {
+            // a swept pair may be the minimum: wait for the chain workgroup, sweep again with the exact sum
+            if (threadIdx.x == 0) {
+                const unsigned want = (unsigned)lst.n_events;
+                long spins = 0;
+                while (__hip_atomic_load(d.ticket + TRK_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+                    if (++spins > 20000000) { lst.error = 10; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __threadfence();
+                lst.n_sweep_waits++;
+            }
+            __syncthreads();
+            Cand bx;
+            bx.q = inf_f64();
+            bx.key = ~0ULL;
+            for (int64_t r = threadIdx.x; r < items - ta.np; r += TRK_THREADS) sweep_exact_item(d, r, ta, bx);
+            bx = block_reduce<TRK_THREADS / 64>(bx, sh);
+            if (threadIdx.x == 0) sh[0] = bx;
+            __syncthreads();
+            bx = sh[0];
+            if (cand_better(bx, best)) best = bx;
+        }
+        // certain: every swept pair's exact Q lies strictly above best.q, so best wins as it stands
+    }
+    if (giveup) { best.q = inf_f64(); best.key = ~0ULL; }
+    if (threadIdx.x == 0) {
+        *d.ticket = 0u;
+        lst.ev_timed = timed;
+        if (giveup) lst.n_sweep_waits++;
+        la_track_done(dl, best, ta);
+        lst.stall = (!lst.la_hit && !has_scan) ? 1 : 0;
+        if (lst.stall) lst.n_stalled++;
+    }
+    __syncthreads();
+    TRK_TICK(6);
+    // the window has certified the minimum: Cx / Cy, the 4-candidate choice and the merge plan follow at once
+    // (the launch sequence of a window event has no decide kernel); otherwise the event scans (or stalls)
+    if (lst.la_hit) decide_step(d, S, L, best);
+    TRK_TICK(7);
+    if (prof) {
+        for (int q = 0; q < 8; q++) lst.ev_ticks[q] += S.tk[q + 1] - S.tk[q];
+    }
+    __syncthreads();
+    state_out(st, lst);
+#undef TRK_TICK
 }
 
 // ------------------------------------------------------------------ k_update
 // subtract + every micro-op + add of one event in ONE launch (fnn_core.h: update_bulk /
 // update_special).  The last workgroup handles the <= 8 involved slots in phases.
 __global__ __launch_bounds__(256) void k_update(Dev d, int defer) {
-    __shared__ double shp[4][2];
+    __shared__ double shp[4][4];
     State* st = d.st;
     if (!st->ev_active || st->stall) return;
-    double dsum = 0.0, dabs = 0.0;
+    double dsum = 0.0, dabs = 0.0, tu = 0.0, tv = 0.0;
     const bool special = blockIdx.x == gridDim.x - 1;
     if (special) {
+        // the <= 8 involved slots: their S x S block of the matrix, their row sums and their T are copied to LDS,
+        // the reference's per-node bodies run on the copy in phases (subtract, one per micro-op, add: up to 8
+        // dependent steps at LDS instead of global-memory latency), and the block goes back in one sweep
+        __shared__ double blk[MAX_S * MAX_S], sxl[MAX_S], tl[MAX_S];
+        __shared__ int32_t berr;
+        if (threadIdx.x == 0) berr = 0;
+        if (threadIdx.x < MAX_S * MAX_S) special_block_load(d, blk, sxl, tl, (int32_t)threadIdx.x);
         // the close of the event does not depend on the update (and nothing in the update reads what it
         // writes): its round trips run beside the phases, in the last wave
-        if (defer && threadIdx.x == 255) {
-            st->upart_n = (int)gridDim.x;
-            st->chain_m = st->m;
-            st->chain_U = st->U;
-            if (!st->ev_finish) st->chain_pending = 1;
-            close_event(d);
+        if (threadIdx.x == 255) {
+            st->tp_n = st->ev_finish ? 0 : (int)gridDim.x;  // partial sums of T of the new cluster's nodes: the next decide step adds them up
+            st->tp_U = st->U;
+            if (defer) {
+                st->upart_n = (int)gridDim.x;
+                st->chain_m = st->m;
+                st->chain_U = st->U;
+                if (!st->ev_finish) st->chain_pending = 1;
+                close_event(d);
+            }
         }
+        int32_t Sl[MAX_S];
+#pragma unroll
+        for (int i = 0; i < MAX_S; i++) Sl[i] = st->S[i];
+        const BlockAcc A{blk, sxl, tl, Sl, st->nS, &berr};
         const int nph = update_special_phases(*st);
+        __syncthreads();
         for (int ph = 0; ph < nph; ph++) {
-            const double v = update_special(d, ph, (int)threadIdx.x);
-            dsum += v;
-            dabs += v < 0.0 ? -v : v;
-            __syncthreads();  // a phase's stores are visible to the next phase (same CU, same L1)
+            if (threadIdx.x < MAX_S) {
+                double tuv[2];
+                const double v = update_special_acc(A, d, ph, (int)threadIdx.x, tuv);
+                dsum += v;
+                dabs += v < 0.0 ? -v : v;
+                tu += tuv[0];
+                tv += tuv[1];
+            }
+            __syncthreads();  // a phase's LDS stores are visible to the next phase
         }
+        if (threadIdx.x < MAX_S * MAX_S) special_block_store(d, blk, sxl, tl, (int32_t)threadIdx.x);
+        if (threadIdx.x == 0 && berr) st->error = berr;
     } else {
-        const double v = update_bulk(d, blockIdx.x * 256 + threadIdx.x);
+        double tuv[2];
+        const double v = update_bulk(d, blockIdx.x * 256 + threadIdx.x, tuv);
         dsum = v;
         dabs = v < 0.0 ? -v : v;
+        tu = tuv[0];
+        tv = tuv[1];
     }
-    if (!defer) return;  // k_finalize follows
-    // deferred row sum of the new cluster: tree-ordered partial sums for the next event's sweep, and
-    // the event is closed here; the exact sequential sum is computed beside the next event's tracking
+    // per-workgroup partial sums (tree order): of the new cluster's row-sum addends and their magnitudes (for
+    // the next event's sweep while the exact sequential sum is on its way) and of T of its two nodes
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         dsum += __shfl_down(dsum, off, 64);
         dabs += __shfl_down(dabs, off, 64);
+        tu += __shfl_down(tu, off, 64);
+        tv += __shfl_down(tv, off, 64);
     }
-    if ((threadIdx.x & 63) == 0) { shp[threadIdx.x >> 6][0] = dsum; shp[threadIdx.x >> 6][1] = dabs; }
+    if ((threadIdx.x & 63) == 0) { double* r = shp[threadIdx.x >> 6]; r[0] = dsum; r[1] = dabs; r[2] = tu; r[3] = tv; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        d.upart[2 * blockIdx.x] = ((shp[0][0] + shp[1][0]) + shp[2][0]) + shp[3][0];
-        d.upart[2 * blockIdx.x + 1] = ((shp[0][1] + shp[1][1]) + shp[2][1]) + shp[3][1];
-        if (special && st->ev_finish) {  // special finish: u, v keep the default Sx (NetNode.java:15); nothing to sum
-            d.Sx[st->U] = 0.0;
-            d.Sx[st->U + 1] = 0.0;
-            st->chain_pending = 0;
-        }
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        d.upart[4 * blockIdx.x + k] = ((shp[0][k] + shp[1][k]) + shp[2][k]) + shp[3][k];
+    }
+    if (defer && threadIdx.x == 0 && special && st->ev_finish) {  // special finish: u, v keep the default Sx (NetNode.java:15); nothing to sum
+        d.Sx[st->U] = 0.0;
+        d.Sx[st->U + 1] = 0.0;
+        st->chain_pending = 0;
     }
 }
 
@@ -1512,7 +1544,7 @@ __global__ __launch_bounds__(CH_T) void k_chain_flush(Dev d) {
     __shared__ ChainLds<CH_EPT> L;
     chain_workgroup(d, L);
     __syncthreads();
-    if (threadIdx.x == 0) { d.st->chain_pending = 0; d.ticket[CH_SPLIT_FLAG] = 0u; }
+    if (threadIdx.x == 0) d.st->chain_pending = 0;
 }
 
 // ------------------------------------------------------------------ k_finalize
@@ -1525,371 +1557,11 @@ __global__ __launch_bounds__(CH_T) void k_finalize(Dev d) {
     if (threadIdx.x == 0) finalize(d, usx);
 }
 
-// ------------------------------------------------------------------ k_events
-// Persistent event kernel: while a lookahead window is open, whole events run inside ONE launch.
-// gridDim.x - 1 "main" workgroups of 1024 threads share the slots (thread-stride loops) and meet
-// at four grid barriers per event:
-//   A  track: tracked pairs + the sweep of the newest cluster's rows        (k_track's body)
-//   B  everybody reduces the records, checks the window, forms Cx / Cy, ComputeRx terms (k_rx_fill's)
-//   C  workgroup 0: certified 4-candidate choice + merge plan                (k_decide4's)
-//   D  fused update of all columns, the involved slots in the last main workgroup (k_update's),
-//      close of the event.
-// The exact sequential row sum of the new cluster u (k_finalize's chain, ~20 us) is computed by the
-// extra "chain" workgroup BESIDE phases A - C of the next event: only u's own row sweep needs u.Sx
-// there, and it runs on the tree-ordered sum first.  Its pairs compete in a separate record; the
-// tree sum is within eps of the exact one, so if the best swept pair is further than the margin
-// above the best other pair, the winner (an exactly evaluated pair) is certain.  Otherwise the main
-// workgroups wait for the chain and sweep once more with the exact sum.  Phase D of the next event
-// (the first to modify u.Sx) always waits for the chain.  Anything but a window hit (window
-// expired or failed, loop end, too few live nodes) makes all workgroups leave; the host-driven
-// launch sequence then handles that event.
-struct EvCtl {  // zeroed by the host before every launch; hot words on separate cache lines
-    unsigned bar_count, pad0[31];
-    unsigned upd_epoch, pad1[31];    // events (1-based, this launch) whose update is complete
-    unsigned chain_epoch, pad2[31];  // events whose exact u.Sx has been written
-    unsigned stop, abort_, pad3[30]; // stop: main workgroups have left after `stop - 1` events
-    int req_m, req_U, pad4[30];      // mailbox of the chain request
-};
-static_assert(sizeof(EvCtl) <= 1024, "EvCtl");
-
-constexpr long EV_SPIN_LIMIT = 4000000;  // ~ seconds; a wait this long means something is broken: give up, never hang
-
-__device__ __forceinline__ unsigned ev_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ev_store(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// thread 0 waits until *p >= want (or the abort flag); returns false on abort / timeout
-__device__ __forceinline__ bool ev_wait(EvCtl* ctl, const unsigned* p, unsigned want) {
-    __shared__ int ok;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long spins = 0;
-        int good = 1;
-        while (ev_load(p) < want) {
-            if (ev_load(&ctl->abort_) || ++spins > EV_SPIN_LIMIT) { ev_store(&ctl->abort_, 1u); good = 0; break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        __threadfence();
-        ok = good;
-    }
-    __syncthreads();
-    return ok != 0;
-}
-// barrier over the nmain main workgroups; `round` counts this workgroup's barriers
-__device__ __forceinline__ bool ev_barrier(EvCtl* ctl, unsigned& round, unsigned nmain) {
-    __syncthreads();
-    round += 1;
-    if (threadIdx.x == 0) {
-        __threadfence();
-        atomicAdd(&ctl->bar_count, 1u);
-    }
-    return ev_wait(ctl, &ctl->bar_count, round * nmain);
-}
-
-__device__ __forceinline__ Cand ev_reduce_records(const Cand* recs, int n, Cand* sh) {
-    Cand best;
-    best.q = inf_f64();
-    best.key = ~0ULL;
-    for (int i = threadIdx.x; i < n; i += CH_T) {
-        Cand c = recs[i];
-        if (cand_better(c, best)) best = c;
-    }
-    __syncthreads();
-    best = block_reduce<CH_T / 64>(best, sh);
-    __shared__ Cand bc;
-    if (threadIdx.x == 0) bc = best;
-    __syncthreads();
-    best = bc;
-    __syncthreads();
-    return best;
-}
-
-constexpr int EV_REC_U = 256, EV_REC_X = 512;  // offsets of the swept-pair records in d.recs
-
-__global__ __launch_bounds__(CH_T) void k_events(Dev d, int max_events) {
-    __shared__ ChainLds<CH_EPT> L;
-    __shared__ State lst;
-    __shared__ double red[16][10];
-    __shared__ Cand shc[16];
-    __shared__ int zsh[6];
-    State* st = d.st;
-    EvCtl* ctl = reinterpret_cast<EvCtl*>(d.evctl);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int nmain = (int)gridDim.x - 1, w = (int)blockIdx.x;
-
-    if (w == nmain) {
-        // ---- the chain workgroup: exact sequential row sum of the new cluster of every event
-        for (unsigned e = 1;; e++) {
-            __shared__ int go;
-            __syncthreads();
-            if (tid == 0) {
-                long spins = 0;
-                int g = 1;
-                while (ev_load(&ctl->upd_epoch) < e) {
-                    const unsigned stop = ev_load(&ctl->stop);
-                    if (stop != 0 && stop <= e) { g = 0; break; }  // the main workgroups left after e - 1 events
-                    if (ev_load(&ctl->abort_) || ++spins > 8 * EV_SPIN_LIMIT) { ev_store(&ctl->abort_, 1u); g = 0; break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                __threadfence();
-                go = g;
-            }
-            __syncthreads();
-            if (!go) return;
-            const int cm = ctl->req_m, cu = ctl->req_U;
-            const double usx = block_chain_sum<CH_EPT>(d.chain, cm, CH_GUARD_BITS, L, nullptr);
-            if (tid == 0) {
-                d.Sx[cu] = usx;      // u.Sx and u.nbr.Sx (NetMakerOriginal.java:532, 535)
-                d.Sx[cu + 1] = usx;
-                __threadfence();
-                ev_store(&ctl->chain_epoch, e);
-            }
-        }
-    }
-
-    // ---- main workgroups.  Every workgroup works on an LDS copy of the control block (one coalesced
-    // load instead of dozens of dependent global accesses); workgroup 0 is its only writer and
-    // publishes it before the barrier that ends a phase in which it changed.
-    long long tk = 0, tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool prof = (w == 0 && tid == 0);
-#define EV_TICK(slot) do { if (prof) { const long long now_ = (long long)wall_clock64(); tacc[slot] += now_ - tk; tk = now_; } } while (0)
-    if (prof) tk = (long long)wall_clock64();
-    constexpr int NW = (int)(sizeof(State) / 4);
-    auto state_in = [&]() {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(st);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&lst);
-        __syncthreads();
-        for (int i = tid; i < NW; i += CH_T) dst[i] = src[i];
-        __syncthreads();
-    };
-    auto state_out = [&]() {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&lst);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(st);
-        __syncthreads();
-        for (int i = tid; i < NW; i += CH_T) dst[i] = src[i];
-    };
-    Dev dl = d;
-    dl.st = &lst;
-    unsigned round = 0;
-    int ev = 0;
-    bool aborted = false, failed = false;
-    for (;; ev++) {
-        if (w != 0 || ev == 0) state_in();
-        if (ev >= max_events || lst.done || lst.error || !la_active(lst)) break;
-        // ---- A: track
-        TrackArgs ta = track_args(lst);
-        double eps_u = 0.0;
-        if (ev > 0 && ta.nf > ta.nf0) {  // the newest cluster's exact row sum is on its way: tree-ordered sum first
-            if (tid < 64) {
-                double su = 0.0, sa = 0.0;
-                for (int b = tid; b < nmain; b += 64) { su += d.upart[2 * b]; sa += d.upart[2 * b + 1]; }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) { su += __shfl_down(su, off, 64); sa += __shfl_down(sa, off, 64); }
-                if (tid == 0) { red[0][8] = su; red[0][9] = sa; }
-            }
-            __syncthreads();
-            ta.approx = 1;
-            ta.sxu = red[0][8];
-            // both the sequential and the tree order are within gamma_m sum|terms| of the exact sum
-            eps_u = 4.0 * ((double)ta.m + 8.0) * 1.1102230246251565e-16 * red[0][9];
-            __syncthreads();
-        }
-        const int64_t items = track_item_count(ta);
-        Cand bo, bu;
-        bo.q = inf_f64(); bo.key = ~0ULL;
-        bu = bo;
-        for (int64_t it = (int64_t)w * CH_T + tid; it < items; it += (int64_t)nmain * CH_T) track_item(d, it, ta, bo, bu);
-        bo = block_reduce<CH_T / 64>(bo, shc);
-        if (tid == 0) d.recs[w] = bo;
-        __syncthreads();
-        bu = block_reduce<CH_T / 64>(bu, shc);
-        if (tid == 0) d.recs[EV_REC_U + w] = bu;
-        EV_TICK(0);
-        if (!ev_barrier(ctl, round, nmain)) { aborted = true; break; }
-        EV_TICK(5);
-        // ---- B: the event's minimum; every main workgroup derives the same verdict
-        bo = ev_reduce_records(d.recs, nmain, shc);
-        Cand best = bo;
-        if (ta.approx) {
-            bu = ev_reduce_records(d.recs + EV_REC_U, nmain, shc);
-            // |Q~ - Q| <= eps_u + the roundings of (c-2) D - Sp - Sq, each <= 2^-53 of a term <= (c + 2n) Dmax
-            const double dmax = __builtin_bit_cast(double, lst.dmax_bits);
-            const double margin = 2.0 * eps_u + 64.0 * 1.1102230246251565e-16 * ((double)lst.n + 4.0) * dmax * 3.0 + 1e-300;
-            const bool certain = (bu.q - margin > bo.q) || (bu.q == inf_f64());
-            if (!certain) {
-                // a swept pair may be the minimum: wait for the exact row sum, sweep again
-                if (!ev_wait(ctl, &ctl->chain_epoch, (unsigned)ev)) { aborted = true; break; }
-                Cand bx;
-                bx.q = inf_f64(); bx.key = ~0ULL;
-                for (int64_t it = (int64_t)ta.np + (int64_t)w * CH_T + tid; it < items; it += (int64_t)nmain * CH_T) {
-                    // sweep items only; the exact pass must not insert the pairs a second time
-                    const int64_t r = it - ta.np;
-                    const int32_t half = (ta.m + 1) / 2;
-                    const int32_t fi = ta.nf0 + (int32_t)(r / half), cp = (int32_t)(r % half);
-                    if (fi >= ta.nf) continue;
-                    const int32_t id = d.fresh[2 * fi], stamp = d.fresh[2 * fi + 1];
-                    const int32_t f0 = d.islot[id];
-                    if (f0 < 0 || d.cstamp[id] != stamp) continue;
-                    const int32_t s2 = 2 * cp;
-                    if (s2 >= ta.m || s2 == f0) continue;
-                    const double* F0 = d.D + (int64_t)f0 * d.ld + s2;
-                    const double* F1 = F0 + d.ld;
-                    const double a0 = F0[0], a1 = F0[1], b0 = F1[0], b1 = F1[1];
-                    if (f0 > s2)
-                        scan_micro(f0, s2, ta.m, ta.twoP, ta.cm2, a0, a1, b0, b1, d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1],
-                                   d.Sx[s2], d.Sx[s2 + 1], d.spos[s2], d.spos[s2 + 1], bx);
-                    else
-                        scan_micro(s2, f0, ta.m, ta.twoP, ta.cm2, a0, b0, a1, b1, d.Sx[s2], d.Sx[s2 + 1], d.spos[s2], d.spos[s2 + 1],
-                                   d.Sx[f0], d.Sx[f0 + 1], d.spos[f0], d.spos[f0 + 1], bx);
-                }
-                bx = block_reduce<CH_T / 64>(bx, shc);
-                if (tid == 0) d.recs[EV_REC_X + w] = bx;
-                if (!ev_barrier(ctl, round, nmain)) { aborted = true; break; }
-                bu = ev_reduce_records(d.recs + EV_REC_X, nmain, shc);
-                if (w == 0 && tid == 0) lst.n_su_exact++;
-                if (cand_better(bu, best)) best = bu;
-            }
-            // certain: every swept pair's exact Q is strictly above bo.q, so bo wins as it stands
-        }
-        if (!(best.q <= lst.la_theta_eff)) { failed = true; break; }  // the window cannot certify this event: the host-driven path scans
-        // Cx / Cy, ComputeRx terms + tree partial sums (k_rx_fill's body over this workgroup's slots)
-        if (tid == 0) {
-            int32_t z[4];
-            const bool need = pick_slots(dl, best, z);
-            zsh[0] = z[0]; zsh[1] = z[1]; zsh[2] = z[2]; zsh[3] = z[3]; zsh[4] = need ? 1 : 0;
-        }
-        __syncthreads();
-        {
-            const int32_t z[4] = {zsh[0], zsh[1], zsh[2], zsh[3]};
-            const bool need = zsh[4] != 0;
-            const int32_t m = ta.m, twoP = ta.twoP;
-            double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (need) {
-                for (int32_t sl = w * CH_T + tid; sl < m; sl += nmain * CH_T) {
-                    double term[4];
-                    rx_fill_thread(d, sl, m, twoP, z, term, false);
-#pragma unroll
-                    for (int k = 0; k < 4; k++) { v[k] += term[k]; v[4 + k] += term[k] < 0.0 ? -term[k] : term[k]; }
-                }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-                    for (int k = 0; k < 8; k++) v[k] += __shfl_down(v[k], off, 64);
-                }
-                if (lane == 0) {
-#pragma unroll
-                    for (int k = 0; k < 8; k++) red[wv][k] = v[k];
-                }
-                __syncthreads();
-                if (tid < 8) {
-                    double acc = 0.0;
-                    for (int q = 0; q < CH_T / 64; q++) acc += red[q][tid];
-                    d.rxpart[(size_t)w * 8 + tid] = acc;
-                }
-            }
-        }
-        if (w == 0) {
-            __syncthreads();
-            if (tid == 0) {
-                la_track_hit(dl, ta);
-                pick(dl, best);
-            }
-            state_out();
-        }
-        EV_TICK(1);
-        if (!ev_barrier(ctl, round, nmain)) { aborted = true; break; }
-        EV_TICK(5);
-        // ---- C: 4-candidate choice + merge plan (on workgroup 0's copy of the control block)
-        if (w == 0) {
-            decide4_body(dl, nmain, L, lst, &red[0][0]);
-            state_out();
-        }
-        EV_TICK(2);
-        if (!ev_barrier(ctl, round, nmain)) { aborted = true; break; }
-        EV_TICK(5);
-        // ---- D: fused update; from here on u.Sx of the PREVIOUS event must be exact
-        // (the update reads the plan from the published control block: uniform global loads are cheaper
-        //  here than LDS reads)
-        if (ev > 0 && !ev_wait(ctl, &ctl->chain_epoch, (unsigned)ev)) { aborted = true; break; }
-        EV_TICK(3);
-        {
-            double dsum = 0.0, dabs = 0.0;
-            const int32_t m_old = st->m_old;
-            for (int32_t k = w * CH_T + tid; k < m_old; k += nmain * CH_T) {
-                const double v = update_bulk(d, k);
-                dsum += v;
-                dabs += v < 0.0 ? -v : v;
-            }
-            if (w == nmain - 1) {
-                const int nph = update_special_phases(*st);
-                for (int ph = 0; ph < nph; ph++) {
-                    const double v = update_special(d, ph, tid);
-                    dsum += v;
-                    dabs += v < 0.0 ? -v : v;
-                    __syncthreads();
-                }
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                dsum += __shfl_down(dsum, off, 64);
-                dabs += __shfl_down(dabs, off, 64);
-            }
-            if (lane == 0) { red[wv][8] = dsum; red[wv][9] = dabs; }
-            __syncthreads();
-            if (tid == 0) {
-                double a = 0.0, b = 0.0;
-                for (int q = 0; q < CH_T / 64; q++) { a += red[q][8]; b += red[q][9]; }
-                d.upart[2 * w] = a;
-                d.upart[2 * w + 1] = b;
-            }
-            if (w == 0) {
-                if (tid == 0) {
-                    ctl->req_m = lst.m;  // (the chain covers the positions of the new layout, as k_finalize does)
-                    ctl->req_U = lst.U;
-                    close_event(dl);     // everything of finalize() but u.Sx, which the chain workgroup delivers
-                    lst.n_ev_persistent++;
-                }
-                state_out();
-            }
-        }
-        EV_TICK(4);
-        if (!ev_barrier(ctl, round, nmain)) { aborted = true; break; }
-        EV_TICK(5);
-        if (w == 0 && tid == 0) { __threadfence(); ev_store(&ctl->upd_epoch, (unsigned)(ev + 1)); }
-    }
-    // `ev` events were completed by this launch; the chain workgroup leaves once it has served them.
-    // (Workgroup 0's copy equals the published control block here: every break happens before it
-    //  changes anything in the current event.)
-    if (w == 0 && tid == 0) {
-        for (int q = 0; q < 8; q++) st->ev_ticks[q] += tacc[q];
-        if (aborted || ev_load(&ctl->abort_)) st->error = 9;
-        if (failed) {  // as k_track records it: the window ends here, the next launch sequence opens a new one
-            st->n_la_fail++;
-            st->la_prev_end = 1;
-            la_prepare_base(*st, d.lacnt);
-        }
-        __threadfence();
-        ev_store(&ctl->stop, (unsigned)(ev + 1));
-    }
-#undef EV_TICK
-}
-
 // diagnostic entry: the block chain sum on an arbitrary buffer (tests)
 template <int EPT>
 __global__ __launch_bounds__(CH_T) void k_test_chain(const double* buf, int m, int guard_bits, double* out, ChainStats* stats) {
     __shared__ ChainLds<EPT> L;
     double r = block_chain_sum<EPT>(buf, m, guard_bits, L, stats);
-    if (threadIdx.x == 0) *out = r;
-}
-
-// the same through the split form: steps 1-3, records to memory and back, step 4 (m <= CH_SC)
-__global__ __launch_bounds__(CH_T) void k_test_chain_split(const double* buf, int m, int guard_bits, double* out, uint64_t* rec) {
-    __shared__ ChainLds<CH_EPT> L;
-    block_chain_sum<CH_EPT, 1>(buf, m, guard_bits, L, nullptr);
-    chain_records_store(L, rec);
-    __threadfence();
-    __syncthreads();
-    chain_records_load(L, rec);
-    double r = block_chain_sum<CH_EPT, 2>(buf, m, guard_bits, L, nullptr);
     if (threadIdx.x == 0) *out = r;
 }
 
@@ -2003,15 +1675,12 @@ struct HipBackend {
     int scan_grid = 8192;   // workgroups of the scan (FNN_SCAN_GRID)
     int unsched_grid = 2048; // workgroups of the screening launches that only run when a lookahead window fails (FNN_UNSCHED_GRID)
     int emit_grid = 256;    // workgroups of k_emit (FNN_EMIT_GRID)
-    int events_grid = 16;   // main workgroups of k_events (FNN_EVENTS_GRID); one more computes the chains
-    bool persistent = false; // FNN_PERSISTENT=1: run window hits inside the persistent event kernel k_events (experimental:
-                             // correct, but slower than one launch sequence per event)
     int track_grid = 64;    // track workgroups of k_track (FNN_TRACK_GRID); one more computes the pending chain
     bool skip_unsched_scans = true; // FNN_UNSCHED_SCANS=1: keep the (mostly idle) scan kernels in unscheduled events
     int track_group = TRK_GROUP;  // k_track: workgroups per first-level arrival counter (FNN_TRACK_GROUP)
-    bool chain_split = false;  // the deferred sum in two launches (steps 1-3 in k_track, the walk in k_decide4): measured slower
     bool defer_chain = false; // set by the engine: k_update closes the event, the exact u.Sx sum runs inside the next k_track
     bool scan_nt = true;    // non-temporal matrix loads in the scan (FNN_SCAN_NT)
+    bool ticks = false;     // FNN_TICKS=1: k_track records the phase split of its last workgroup (fnn_debug_event_ticks)
 
     std::string err() const { return comm_err.empty() ? std::string(hipGetErrorString(last)) : comm_err; }
 
@@ -2061,12 +1730,10 @@ struct HipBackend {
             return fail(FNN_EHIP, "hipStreamCreate failed (" + err() + ")");
         if (const char* e = std::getenv("FNN_SCAN_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) scan_grid = v; }
         if (const char* e = std::getenv("FNN_SCAN_NT")) scan_nt = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FNN_TICKS")) ticks = std::atoi(e) != 0;
         if (const char* e = std::getenv("FNN_UNSCHED_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) unsched_grid = v; }
         if (const char* e = std::getenv("FNN_UNSCHED_SCANS")) skip_unsched_scans = std::atoi(e) == 0;
-        if (const char* e = std::getenv("FNN_EVENTS_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 63) events_grid = v; }
-        if (const char* e = std::getenv("FNN_PERSISTENT")) persistent = std::atoi(e) != 0;
         if (const char* e = std::getenv("FNN_EMIT_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) emit_grid = v; }
-        if (const char* e = std::getenv("FNN_CHAIN_SPLIT")) chain_split = std::atoi(e) != 0;
         if (const char* e = std::getenv("FNN_TRACK_GROUP")) { int v = std::atoi(e); if (v >= 2 && v <= 1024) track_group = v; }
         if (const char* e = std::getenv("FNN_TRACK_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 1024) track_grid = v; }
         if (const char* e = std::getenv("FNN_SCREEN_MIN_M")) { int v = std::atoi(e); if (v >= 8) screen_min_m = v; }
@@ -2196,7 +1863,8 @@ struct HipBackend {
         return FNN_OK;
     }
     int32_t launch_prep_screen(const Dev& d, int64_t nrows) {
-        hipLaunchKernelGGL(k_prep_screen, dim3(8192), dim3(256), 0, stream, d, nrows);
+        const int64_t want = (nrows * d.ld + 255) / 256;
+        hipLaunchKernelGGL(k_prep_screen, dim3((unsigned)(want < 8192 ? (want > 0 ? want : 1) : 8192)), dim3(256), 0, stream, d, nrows);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
     int32_t launch_init(const Dev& d) {
@@ -2223,10 +1891,10 @@ struct HipBackend {
         //  device stalls - this and the following such events do nothing - until the host, which
         //  looks at the state every batch, launches an event with a scan)
         const bool has_scan = sched || !screen || !skip_unsched_scans;
-        if (d.la) hipLaunchKernelGGL(k_track, dim3(track_grid + 1), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0, (has_scan ? 1 : 0) | (chain_split ? 0 : 2), track_group);
+        if (d.la) hipLaunchKernelGGL(k_track, dim3(track_grid + 1), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0, has_scan ? 1 : 0, track_group, ticks ? 1 : 0);
         if (timed) { e0 = next_event(); e1 = next_event(); ev_kind.push_back(screen ? 1 : 0); }
         int nrecs;
-        if (screen && !has_scan) nrecs = RES_BLOCKS;  // (k_rx_fill reads one record, the window's)
+        if (screen && !has_scan) nrecs = 0;  // (a window event: the tail of k_track decides; no decide kernel follows)
         else if (screen) {
             int nt = (tri_tile_count(m_bound, SCR_TH, SCR_R) + d.world - 1) / d.world;
             const int want = sched ? scan_grid : unsched_grid;
@@ -2254,11 +1922,11 @@ struct HipBackend {
         if (timed) (screen ? scan_launches : plain_launches)++;
         return nrecs;
     }
-    // everything after the scan; `src` holds the nrecs candidate records to reduce
+    // everything after the scan; `src` holds the nrecs candidate records to reduce (0: a window event, already
+    // decided by the tail of k_track - or stalled)
     void enqueue_rest(const Dev& d, int32_t m_bound, const Cand* src, int nrecs) {
         dim3 g1 = grid1(m_bound);
-        hipLaunchKernelGGL(k_rx_fill, g1, dim3(256), 0, stream, d, src, nrecs);
-        hipLaunchKernelGGL(k_decide4, dim3(defer_chain && chain_split ? 2 : 1), dim3(CH_T), 0, stream, d, (int)g1.x);
+        if (nrecs > 0) hipLaunchKernelGGL(k_decide, dim3(1), dim3(CH_T), 0, stream, d, src, nrecs);
         hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d, defer_chain ? 1 : 0);
         if (!defer_chain) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d);
     }
@@ -2272,13 +1940,6 @@ struct HipBackend {
     // a pending deferred row sum, before the host reads the state
     int32_t launch_chain_flush(const Dev& d) {
         hipLaunchKernelGGL(k_chain_flush, dim3(1), dim3(CH_T), 0, stream, d);
-        return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
-    }
-    // persistent event kernel: serves up to max_events window hits in one launch (no-op otherwise)
-    int32_t launch_events(const Dev& d, int32_t max_events) {
-        hipLaunchKernelGGL(k_chain_flush, dim3(1), dim3(CH_T), 0, stream, d);
-        if (!HIPOK(hipMemsetAsync(d.evctl, 0, sizeof(EvCtl), stream))) return FNN_EHIP;
-        hipLaunchKernelGGL(k_events, dim3(events_grid + 1), dim3(CH_T), 0, stream, d, (int)max_events);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
     // several GPUs: scan of this rank's tiles ... (all-gather of the candidate records) ... the rest
@@ -2526,23 +2187,8 @@ int32_t fnn_test_chain_sum(int32_t device, const double* host_buf, int32_t m, in
     fnn::ChainStats hs{0, 0, 0, 0};
     if (e == hipSuccess) e = hipMemcpy(out, dout, 8, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(&hs, dst, sizeof(hs), hipMemcpyDeviceToHost);
-    bool split_differs = false;
-    if (e == hipSuccess && m <= fnn::CH_SC && !std::getenv("FNN_CHAIN_STOP")) {
-        // the two-launch form of the engine (records through memory) must give the same bits
-        uint64_t* drec = nullptr;
-        double two = 0.0;
-        if (hipMalloc((void**)&drec, sizeof(uint64_t) * fnn::CHREC_WORDS) != hipSuccess) e = hipErrorOutOfMemory;
-        else {
-            hipLaunchKernelGGL(fnn::k_test_chain_split, dim3(1), dim3(fnn::CH_T), 0, 0, dbuf, m, guard_bits, dout, drec);
-            e = hipDeviceSynchronize();
-            if (e == hipSuccess) e = hipMemcpy(&two, dout, 8, hipMemcpyDeviceToHost);
-            split_differs = e == hipSuccess && std::memcmp(&two, out, 8) != 0;
-            (void)hipFree(drec);
-        }
-    }
     (void)hipFree(dbuf); (void)hipFree(dout); (void)hipFree(dst);
     if (e != hipSuccess) return fnn::fail(FNN_EHIP, std::string("fnn_test_chain_sum: ") + hipGetErrorString(e));
-    if (split_differs) return fnn::fail(FNN_ESTATE, "fnn_test_chain_sum: the split form of the sum gave different bits");
     if (stats4) { stats4[0] = hs.runs; stats4[1] = hs.mixed; stats4[2] = hs.run_fail; stats4[3] = hs.thread_fail; }
     return FNN_OK;
 }

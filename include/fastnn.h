@@ -53,12 +53,15 @@ typedef struct fnn_opts {
     int32_t force_exact_rx;/* diagnostic: 1 = always evaluate the ComputeRx sums with the exact
                               sequential-sum kernel instead of certifying the 4-candidate choice
                               from tree sums (same result; exercises the rare path) */
-    int32_t disable_screen;/* 1 = always scan the fp64 matrix in full; default (0): events with many
-                              live nodes first stream an fp32 copy of the matrix (half the bytes) to
-                              find, within a rigorous error bound, the few tile units that can hold
-                              the minimum, and only those are rescanned in fp64 (same result) */
+    int32_t disable_screen;/* 1 = always scan the fp64 matrix in full; default (0): from 4096 taxa on, events
+                              with >= 2048 live nodes first stream a bf16 copy of the matrix (2 bytes per entry,
+                              a quarter of the fp64 bytes) to find, within a rigorous error bound, the few
+                              32 x 512 tile units that can hold the minimum; only those are rescanned in
+                              fp64 (same result) */
     int32_t lookahead;     /* events one screening pass may serve ("lookahead window"): 0 = default
-                              (16 + n / 1024, at most 64), < 0 = off (every event scans), > 0 = that many; same result either way */
+                              (min(16 + n / 1024, 64) at most, and min(that, 16 + m / 1024) for a window opened
+                              with m live nodes: 48 at n = 32768), < 0 = off (every event scans), > 0 = that
+                              many (capped at 512); same result either way */
     int32_t lookahead_pairs;/* wanted number of tracked pairs per window (0 = default 32768) */
     int32_t reserved[9];
 } fnn_opts;
@@ -89,16 +92,16 @@ typedef struct fnn_stats {
     int64_t scan_launches;   /* number of those launches */
     int64_t scan_bytes;      /* matrix bytes those launches had to stream: E_t entries at 2 B (bf16 screening
                                 copy) per launch, plus the fp64 rescans of the candidate units */
-    int64_t n_rx_certified;  /* events whose 4-candidate choice was certified from tree sums */
+    int64_t n_rx_certified;  /* events whose 4-candidate choice was certified from approximate row sums */
     int64_t n_rx_exact;      /* events that needed the exact sequential ComputeRx sums */
-    int64_t n_screen_events; /* events whose scan went through the fp32 screening pass */
-    int64_t n_rescan_units;  /* 32 x 256 units rescanned in fp64 over those events */
+    int64_t n_screen_events; /* events whose scan went through the bf16 screening pass */
+    int64_t n_rescan_units;  /* 32 x 512 units rescanned in fp64 over those events */
     int64_t n_base_scans;    /* events that ran a scan (all of them without lookahead windows) */
     int64_t n_window_hits;   /* events whose minimum came from an open lookahead window (no scan) */
     int64_t n_window_fails;  /* events whose window could not certify the minimum (they rescanned) */
     int64_t window_pairs;    /* tracked pairs summed over all windows */
     int64_t bytes_total;     /* matrix bytes read by ALL scan work of the run (timed or not, window items too) */
-    int64_t n_events_persistent; /* events completed inside the persistent event kernel (k_events) */
+    int64_t n_events_persistent; /* always 0 (round 1's experimental persistent event kernel was removed; kept for layout) */
     int64_t n_sweeps_exact;  /* ... whose sweep of the newest cluster's rows had to wait for its exact row sum */
     double  t_plain_s;       /* sum of the durations of the plain fp64 scan launches (k_scan; m below the screening threshold) */
     int64_t plain_launches;  /* number of those launches */
@@ -166,8 +169,10 @@ int32_t fnn_get_live_matrix(fnn_handle* h, double* out);
  * the number of records copied (at most 8192 are kept). */
 int64_t fnn_debug_window_log(fnn_handle* h, double* out, int64_t max_records);
 
-/* Diagnostic: 100 MHz ticks workgroup 0 of the persistent event kernel spent in {phase A, B, C, waiting for
- * the chain, phase D, grid barriers, -, -} over the last run. */
+/* Diagnostic: 100 MHz ticks (s_memrealtime) that thread 0 of the LAST-arriving tracking workgroup of k_track
+ * spent, summed over the window events of the last run, in {prologue (control block, partial sums), tracked
+ * pairs, sweep of the newest cluster's rows, workgroup reduction, arrival tickets, reading all workgroups'
+ * records, the window's verdict, the decision tail (Cx/Cy, 4-candidate choice, merge plan)}. */
 int32_t fnn_debug_event_ticks(fnn_handle* h, int64_t* out8);
 
 /* Enable per-launch HIP-event timing of the scan kernel (bench.py's roofline

@@ -8,6 +8,7 @@
 // a container without a GPU.  It is NOT part of the product and libfastnn_hip.so
 // never falls back to it.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -47,10 +48,8 @@ struct EmuBackend {
     static constexpr int64_t kColPad = 2048;
     int32_t screen_min_n() const { return 8; }   // tiny on purpose: the CPU tests exercise screening
     int32_t screen_min_m = 8;
-    bool persistent = false;  // (the persistent event kernel exists only on the GPU)
     bool defer_chain = false; // (so does the deferred chain sum)
     int32_t launch_chain_flush(const fnn::Dev&) { return FNN_OK; }
-    int32_t launch_events(const fnn::Dev&, int32_t) { return FNN_OK; }
     std::string err() const { return "emu"; }
     int32_t open(int32_t) { return FNN_OK; }
     void close() {}
@@ -115,7 +114,7 @@ struct EmuBackend {
         for (int64_t r = 0; r < nrows; r++)
             for (int64_t c = 0; c < d.ld; c++) {
                 double v = d.D[r * d.ld + c];
-                d.H[r * d.ld + c] = fnn::bf16_from_double(v);
+                if (d.H) d.H[r * d.ld + c] = fnn::bf16_from_double(v);
                 uint64_t b;
                 std::memcpy(&b, &v, 8);
                 b &= 0x7FFFFFFFFFFFFFFFULL;
@@ -305,45 +304,59 @@ struct EmuBackend {
         return event_rest(d, m_bound, best);
     }
 
+    // weighted row sum of the node in slot z, recomputed from the matrix (check of Dev::T, small problems only)
+    static double t_recompute(const fnn::Dev& d, int32_t z) {
+        const fnn::State& st = *d.st;
+        long double acc = 0.0L;
+        for (int32_t p = 0; p < st.m; p++)
+            if (p != z) acc += (long double)(p < 2 * st.P ? 0.5 : 1.0) * (long double)d.D[(int64_t)z * d.ld + p];
+        return (double)acc;
+    }
+
     int32_t event_rest(const fnn::Dev& d, int32_t m_bound, fnn::Cand best) {
         fnn::State& st = *d.st;
-        // pick (done by workgroup 0 of k_rx_fill on the GPU)
-        int32_t zs[4];
-        const bool zneed = fnn::pick_slots(d, best, zs);  // what the other workgroups of k_rx_fill derive
-        fnn::pick(d, best);
+        // ---- the decide step (tail of k_track for window events, k_decide otherwise)
+        fnn::t_finalize(d);
+        if (d.n <= 300 && !st.done && !st.error) {  // Dev::T against the matrix, within the certification's own bound
+            const double bound = fnn::rx_bound(st);
+            for (int32_t z = 0; z < st.m; z++) {
+                const double want = t_recompute(d, z);
+                if (!(std::fabs(d.T[z] - want) <= 0.25 * bound)) { st.error = 16; break; }
+            }
+        }
+        int32_t a = 0, b = 0, ida = 0, idb = 0;
+        if (fnn::pick_needs_candidate(st)) {
+            a = d.pslot[(int32_t)(best.key >> 32)]; b = d.pslot[(int32_t)(best.key & 0xFFFFFFFFu)];
+            ida = d.sid[a]; idb = d.sid[b];
+        }
+        fnn::pick(d, best, a, b, ida, idb);
         if (!st.ev_active) return FNN_OK;
-        if (!st.ev_finish && (zneed != (st.need_rx != 0) ||
-                              (zneed && (zs[0] != st.sa || zs[1] != st.sap || zs[2] != st.sb || zs[3] != st.sbp))))
-            st.error = 8;
         if (!st.ev_finish) {
-            // k_rx_fill (+ per-block partial sums) and k_decide4 (certify, else exact chains)
+            fnn::Quad qd;
+            fnn::quad_load(d, qd);
             double rx[4] = {0.0, 0.0, 0.0, 0.0};
-            bool certified = true;
             if (st.need_rx) {
-                const int32_t nblk = (m_bound + 255) / 256;
-                for (int32_t b = 0; b < nblk; b++) {
-                    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    const int32_t zz[4] = {st.sa, st.sap, st.sb, st.sbp};
-                    for (int32_t t : thread_order(256)) {
-                        double term[4];
-                        fnn::rx_fill_thread(d, b * 256 + t, st.m_old, 2 * st.P_old, zz, term);
-                        for (int k = 0; k < 4; k++) { acc[k] += term[k]; acc[4 + k] += term[k] < 0 ? -term[k] : term[k]; }
-                    }
-                    for (int k = 0; k < 8; k++) d.rxpart[(size_t)b * 8 + k] = acc[k];
-                }
-                double rxa[4] = {0, 0, 0, 0}, rxs[4] = {0, 0, 0, 0};
-                for (int32_t b : thread_order(nblk))
-                    for (int k = 0; k < 4; k++) { rxa[k] += d.rxpart[(size_t)b * 8 + k]; rxs[k] += d.rxpart[(size_t)b * 8 + 4 + k]; }
-                certified = fnn::rx_certify(d, rxa, rxs);
-                if (certified) { for (int k = 0; k < 4; k++) rx[k] = rxa[k]; st.n_rx_certified++; }
-                else {
-                    int32_t z[4] = {st.sa, st.sap, st.sb, st.sbp};
-                    for (int k = 0; k < 4; k++)
-                        if (z[k] >= 0) rx[k] = fnn::chain_sum(d.chain + (int64_t)k * d.cstride, st.m_old);
+                fnn::rx_from_T(st, qd, rx);
+                if (fnn::rx_certify(st, qd, rx)) st.n_rx_certified++;
+                else {  // the exact sequential sums (ComputeRx, NetMakerOriginal.java:549-561)
+                    const int32_t z[4] = {st.sa, st.sap, st.sb, st.sbp};
+                    for (int32_t t : thread_order(st.m_old)) fnn::rx_fill_thread(d, t, st.m_old, 2 * st.P_old, z);
+                    for (int k = 0; k < 4; k++) rx[k] = z[k] >= 0 ? fnn::chain_sum(d.chain + (int64_t)k * d.cstride, st.m_old) : 0.0;
                     st.n_rx_exact++;
                 }
             }
-            fnn::decide_plan(d, rx);
+            // the plan on the slot tables in memory, or (as the GPU does) on a preloaded copy of the
+            // entries an event can touch; a miss of that copy is a finding
+            if (g_order_mode == 0) { fnn::GlobalTab T{d}; fnn::decide_plan(d, T, qd, rx); }
+            else {
+                int32_t key[fnn::TAB_NK], vsid[fnn::TAB_NK], vspos[fnn::TAB_NK], pkey[fnn::TAB_NP], vpslot[fnn::TAB_NP], misses = 0;
+                fnn::CachedTab T{d, key, vsid, vspos, pkey, vpslot, &misses};
+                fnn::tab_preload(T, st.sa, st.sb, st.P, st.m);
+                fnn::decide_plan(d, T, qd, rx);
+                if (misses && !st.error) st.error = 15;
+            }
+        }
+        {
             // the GPU replays the micro-ops lane-parallel (fnn_hip.hip: build_targets_wave); the same
             // algorithm on arrays of 64 "lanes" must give what the generic build_targets gives
             fnn::State lanes = st;
@@ -356,21 +369,60 @@ struct EmuBackend {
             if (!same && !st.error) st.error = 12;
         }
         // k_update: bulk columns and the special phases run concurrently on the GPU; emulate
-        // different interleavings (g_update_mode) to expose any conflict between them
+        // different interleavings (g_update_mode) to expose any conflict between them.
+        // The GPU runs the special phases on a copy of the S x S block of the involved slots (LDS):
+        // the same phases on such a copy (BlockAcc) must leave exactly what the phases on the matrix leave.
         {
             const int32_t nph = fnn::update_special_phases(st);
-            auto bulk = [&]() { for (int32_t k : thread_order(m_bound)) fnn::update_bulk(d, k); };
-            auto special = [&](int32_t ph) { for (int32_t i : thread_order(fnn::MAX_S)) fnn::update_special(d, ph, i); };
+            double blk[fnn::MAX_S * fnn::MAX_S] = {0}, sxl[fnn::MAX_S] = {0}, tl[fnn::MAX_S] = {0};
+            int32_t berr = 0;
+            double tu = 0.0, tv = 0.0, tub = 0.0, tvb = 0.0, tuv[2];
+            for (int32_t e : thread_order(fnn::MAX_S * fnn::MAX_S)) fnn::special_block_load(d, blk, sxl, tl, e);
+            {
+                int32_t Sl[fnn::MAX_S];
+                for (int i = 0; i < fnn::MAX_S; i++) Sl[i] = st.S[i];
+                const fnn::BlockAcc A{blk, sxl, tl, Sl, st.nS, &berr};
+                for (int32_t ph = 0; ph < nph; ph++)
+                    for (int32_t i : thread_order(fnn::MAX_S)) { fnn::update_special_acc(A, d, ph, i, tuv); tub += tuv[0]; tvb += tuv[1]; }
+            }
+            auto bulk1 = [&](int32_t k) { fnn::update_bulk(d, k, tuv); tu += tuv[0]; tv += tuv[1]; };
+            auto bulk = [&]() { for (int32_t k : thread_order(m_bound)) bulk1(k); };
+            auto special = [&](int32_t ph) { for (int32_t i : thread_order(fnn::MAX_S)) { fnn::update_special(d, ph, i, tuv); tu += tuv[0]; tv += tuv[1]; } };
             if (g_update_mode == 0) { bulk(); for (int32_t ph = 0; ph < nph; ph++) special(ph); }
             else if (g_update_mode == 1) { for (int32_t ph = 0; ph < nph; ph++) special(ph); bulk(); }
             else {  // bulk split in two halves around the middle phase
                 std::vector<int32_t> ord = thread_order(m_bound);
                 size_t half = ord.size() / 2;
                 for (int32_t ph = 0; ph < nph; ph++) {
-                    if (ph == nph / 2) for (size_t q = 0; q < half; q++) fnn::update_bulk(d, ord[q]);
+                    if (ph == nph / 2) for (size_t q = 0; q < half; q++) bulk1(ord[q]);
                     special(ph);
                 }
-                for (size_t q = half; q < ord.size(); q++) fnn::update_bulk(d, ord[q]);
+                for (size_t q = half; q < ord.size(); q++) bulk1(ord[q]);
+            }
+            // the partial sums of T of the new cluster's two nodes (one "workgroup" here); summed by the next decide step
+            d.upart[2] = tu; d.upart[3] = tv;
+            st.tp_n = st.ev_finish ? 0 : 1;
+            st.tp_U = st.U;
+            (void)tub; (void)tvb;
+            bool same = berr == 0 || st.ev_finish;
+            if (st.ev_finish) same = true;
+            for (int i = 0; same && !st.ev_finish && i < st.nS; i++) {
+                same = std::memcmp(&sxl[i], &d.Sx[st.S[i]], 8) == 0 && std::memcmp(&tl[i], &d.T[st.S[i]], 8) == 0;
+                for (int j = 0; same && j < st.nS; j++)
+                    same = std::memcmp(&blk[i * fnn::MAX_S + j], &d.D[(int64_t)st.S[i] * d.ld + st.S[j]], 8) == 0;
+            }
+            if (!same && !st.error) {
+                st.error = berr ? 13 : 14;
+                if (std::getenv("FNN_DEBUG")) {
+                    std::fprintf(stderr, "[emu] block mismatch: nS=%d kind=%d nops=%d finish=%d S=", st.nS, st.cur.kind, st.nops, st.ev_finish);
+                    for (int i = 0; i < st.nS; i++) std::fprintf(stderr, "%d ", st.S[i]);
+                    std::fprintf(stderr, "\n");
+                    for (int i = 0; i < st.nS; i++) {
+                        std::fprintf(stderr, "  sx %g vs %g |", sxl[i], d.Sx[st.S[i]]);
+                        for (int j = 0; j < st.nS; j++) std::fprintf(stderr, " %g/%g", blk[i * fnn::MAX_S + j], d.D[(int64_t)st.S[i] * d.ld + st.S[j]]);
+                        std::fprintf(stderr, "\n");
+                    }
+                }
             }
         }
         double usx = 0.0;

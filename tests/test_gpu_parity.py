@@ -199,8 +199,8 @@ for K, target, pcap in [(-1, 0, 0), (1, 0, 0), (3, 4, 0), (8, 64, 0), (64, 1, 0)
     for n, seed, dist in [(33, 1, "uniform53"), (200, 2, "dec4"), (700, 3, "uniform53")]:
         compare_trajectory(a, O, O.synth(n, seed, dist), deep=(n < 300), deep_every=7, lookahead=K, lookahead_pairs=target)
 os.environ.pop("FNN_LA_PCAP", None)
-# whole runs (no per-event host round trip): window hits are served inside the persistent event
-# kernel, many events per launch, the new cluster's exact row sum computed beside the next event
+# whole runs (no per-event host round trip): batches of launch sequences, the new cluster's exact row
+# sum computed beside the next event's tracking, stalls and recoveries as in production
 def whole_run(n, seed, dist, **kw):
     D = O.synth(n, seed, dist)
     o_ref, ev_ref, se = O.run(D, threads=4)
@@ -214,18 +214,11 @@ def whole_run(n, seed, dist, **kw):
         assert (ev[f] == ev_ref[f]).all(), (f, n, seed, dist, kw)
     assert (ev["best"].view(np.int64) == ev_ref["best"].view(np.int64)).all(), (n, seed, dist, kw)
     return st
-os.environ["FNN_PERSISTENT"] = "1"   # (experimental path, off by default)
-for grid in ("1", "3", "16"):
-    os.environ["FNN_EVENTS_GRID"] = grid
-    for K, target in [(0, 0), (5, 16), (64, 60000), (300, 0)]:
-        for n, seed, dist in [(33, 1, "uniform53"), (130, 2, "dec4"), (700, 3, "uniform53"), (1500, 4, "uniform53")]:
-            whole_run(n, seed, dist, lookahead=K, lookahead_pairs=target)
-os.environ.pop("FNN_EVENTS_GRID", None)
+for K, target in [(0, 0), (5, 16), (64, 60000), (300, 0)]:
+    for n, seed, dist in [(33, 1, "uniform53"), (130, 2, "dec4"), (700, 3, "uniform53"), (1500, 4, "uniform53")]:
+        whole_run(n, seed, dist, lookahead=K, lookahead_pairs=target)
 st = whole_run(2500, 5, "uniform53")
-assert st.n_window_hits > 1500 and st.n_events_persistent > 1500
-os.environ.pop("FNN_PERSISTENT", None)
-st = whole_run(2500, 5, "uniform53")
-assert st.n_window_hits > 1500 and st.n_events_persistent == 0
+assert st.n_window_hits > 1500
 rng = np.random.default_rng(5)
 A = rng.integers(1, 3, size=(400, 400)).astype(np.float64); A = np.triu(A, 1); A = A + A.T
 with Handle(a, 400) as h:

@@ -17,9 +17,9 @@ for n in sizes:
         tk = (C.c_int64 * 8)()
         a._fn("debug_event_ticks", C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)])
         a.debug_event_ticks(h._h, tk)
-        if st.n_events_persistent:
-            print("k_events us/event: " + " ".join(f"{nm}={tk[i] / 100.0 / st.n_events_persistent:.1f}" for i, nm in
-                  enumerate(["A_track", "B_rx", "C_decide", "wait_chain", "D_update", "barriers"])), flush=True)
+        if st.n_window_hits:
+            print("k_track us/window event (last workgroup, thread 0): " + " ".join(f"{nm}={tk[i] / 100.0 / st.n_window_hits:.2f}" for i, nm in
+                  enumerate(["prologue", "pairs", "sweep", "reduce", "arrive", "records", "verdict", "tail"])), flush=True)
         gb = st.scan_bytes / 1e9
         print(f"n={n} total={st.t_total_s:.3f}s init={st.t_init_s:.4f} agglom={st.t_agglom_s:.3f} "
               f"scan={st.t_scan_s:.3f}s events={st.n_events} sumE/n^3={st.sum_entries / n**3:.4f} "
@@ -29,4 +29,4 @@ for n in sizes:
               f"rescan_units_per_event={st.n_rescan_units / max(st.n_screen_events, 1):.1f} "
               f"base_scans={st.n_base_scans} window_hits={st.n_window_hits} window_fails={st.n_window_fails} "
               f"pairs_per_window={st.window_pairs / max(st.n_base_scans, 1):.0f} bytes_total={st.bytes_total / 1e12:.3f}TB "
-              f"timed_launches={st.scan_launches} timed_screen_bytes={st.scan_bytes} plain_launches={st.plain_launches} persistent_events={st.n_events_persistent} exact_sweeps={st.n_sweeps_exact} stalled={st.n_stalled_events}", flush=True)
+              f"timed_launches={st.scan_launches} timed_screen_bytes={st.scan_bytes} plain_launches={st.plain_launches} exact_sweeps={st.n_sweeps_exact} stalled={st.n_stalled_events}", flush=True)
