@@ -143,7 +143,7 @@ struct State {
     int32_t stall, pad_stall;
     int64_t n_stalled;        // events skipped that way
     int64_t n_sweep_waits;    // k_track: sweeps that had to wait for the exact row sum
-    int64_t ev_ticks[8];      // k_track phase split in 100 MHz ticks, summed over window events (see k_track: TRK_TICK)
+    int64_t ev_ticks[8];      // (unused; the phase-split diagnostics live in Dev::ticks)
     // ---- current event ----
     int32_t ev_active, ev_finish, need_rx;
     int32_t sa, sap, sb, sbp;  // slots of Cx, Cx.nbr, Cy, Cy.nbr (-1: none)
@@ -182,9 +182,10 @@ struct Dev {
     int32_t* clist;  // screening: units that may hold the true minimum
     int32_t* islot;  // lookahead: node id -> slot (-1: dead); 3n + 8 entries
     int32_t* cstamp; // lookahead: node id -> n_events + 1 when its current cluster was formed (0: initial)
-    int32_t* tpairs; // lookahead: tracked pairs {id a, id b, cstamp a, cstamp b} (LA_PCAP records)
-    int32_t* fresh;  // lookahead: per fresh cluster {representative id, stamp} (LA_KMAX entries)
+    int32_t* tpairs; // lookahead: tracked pairs {id a | paired bit, id b | paired bit, slot hint a, slot hint b} (LA_PCAP records)
+    int32_t* fresh;  // lookahead: per fresh cluster {representative id, stamp, slot} (LA_KMAX entries)
     uint32_t* ticket; // lookahead: arrival counter of k_track's workgroups
+    int64_t* ticks;  // diagnostics (FNN_TICKS=1), 100 MHz ticks summed over events: [0..7] k_track's last workgroup, [8..15] k_update
     int32_t* lacnt;  // lookahead: append counter of the tracked list (its own word: the control block may be
                      // cached in LDS by a workgroup while every thread appends)
     double* upart;   // per workgroup of k_update, 4 doubles: {sum, sum of magnitudes} of the new cluster's exact row-sum
@@ -569,14 +570,23 @@ FNN_HD void la_close_base(State& st, double* lalog, const int32_t* lacnt) {
     if (st.la_W > wmax) st.la_W = wmax;
 }
 
-// append a pair (representatives' node ids) to the window's tracked list
-FNN_HD void la_append(const Dev& d, int32_t ia, int32_t ib) {
+// A tracked pair: the two representatives' node ids with their "paired" status in the top bit, and the slots
+// they sat in when the pair was recorded (hints: the tracking pass fetches the pair's matrix block at the
+// hinted slots while it checks that the ids still sit there; only a moved node costs a look-up in islot).
+// A live node's cluster changes in one way only - a singleton becomes paired - so "same id, same paired
+// status" means "same cluster" (a paired node keeps its partner until both disappear in a merge).
+constexpr int32_t LA_PAIRED_BIT = (int32_t)0x80000000u;
+FNN_HD void la_record(const Dev& d, int32_t* t, int32_t rs, int32_t cs, int32_t twoP) {
+    t[0] = d.sid[rs] | (rs < twoP ? LA_PAIRED_BIT : 0);
+    t[1] = d.sid[cs] | (cs < twoP ? LA_PAIRED_BIT : 0);
+    t[2] = rs;
+    t[3] = cs;
+}
+// append the pair of the representatives in slots rs, cs to the window's tracked list
+FNN_HD void la_append(const Dev& d, int32_t rs, int32_t cs, int32_t twoP) {
     State& st = *d.st;
     const int32_t i = FNN_ATOMIC_INC(d.lacnt);
-    if (i < st.la_pcap) {
-        int32_t* t = d.tpairs + 4 * (int64_t)i;
-        t[0] = ia; t[1] = ib; t[2] = d.cstamp[ia]; t[3] = d.cstamp[ib];
-    }
+    if (i < st.la_pcap) la_record(d, d.tpairs + 4 * (int64_t)i, rs, cs, twoP);
 }
 
 // a new two-node cluster with representative id `rep` exists from the next event on
@@ -586,19 +596,29 @@ FNN_HD void la_note_cluster(const Dev& d, State& st, int32_t rep, int32_t partne
     d.cstamp[rep] = stamp;
     d.cstamp[partner] = stamp;
     if (st.la_valid) {
-        if (st.la_nf < LA_KMAX) { d.fresh[2 * st.la_nf] = rep; d.fresh[2 * st.la_nf + 1] = stamp; }
+        if (st.la_nf < LA_KMAX) { d.fresh[3 * st.la_nf] = rep; d.fresh[3 * st.la_nf + 1] = stamp; d.fresh[3 * st.la_nf + 2] = st.U; }
         st.la_nf++;  // beyond LA_KMAX the window is no longer served (la_active)
     }
 }
 
 // exact evaluation of the micro-tile that holds the pair of the nodes in slots sa, sb: the scan's
 // own body on the same entries (the tile may hold up to three more live pairs: harmless extras)
-FNN_HD void pair_eval(const Dev& d, int32_t sa, int32_t sb, int32_t m, int32_t twoP, double cm2, Cand& best) {
-    const int32_t r0 = (sa > sb ? sa : sb) & ~1, c0 = (sa > sb ? sb : sa) & ~1;
-    const double* R0 = d.D + (int64_t)r0 * d.ld + c0;
+struct PairOps {
+    int32_t r0, c0;
+    double e00, e01, e10, e11, sxr0, sxr1, sxc0, sxc1;
+    int32_t pr0, pr1, pc0, pc1;
+};
+FNN_HD void pair_load(const Dev& d, int32_t sa, int32_t sb, PairOps& o) {
+    o.r0 = (sa > sb ? sa : sb) & ~1; o.c0 = (sa > sb ? sb : sa) & ~1;
+    const double* R0 = d.D + (int64_t)o.r0 * d.ld + o.c0;
     const double* R1 = R0 + d.ld;  // rows are padded to an even count: r0 + 1 is always in bounds
-    scan_micro(r0, c0, m, twoP, cm2, R0[0], R0[1], R1[0], R1[1], d.Sx[r0], d.Sx[r0 + 1], d.spos[r0], d.spos[r0 + 1],
-               d.Sx[c0], d.Sx[c0 + 1], d.spos[c0], d.spos[c0 + 1], best);
+    o.e00 = R0[0]; o.e01 = R0[1]; o.e10 = R1[0]; o.e11 = R1[1];
+    o.sxr0 = d.Sx[o.r0]; o.sxr1 = d.Sx[o.r0 + 1]; o.sxc0 = d.Sx[o.c0]; o.sxc1 = d.Sx[o.c0 + 1];
+    o.pr0 = d.spos[o.r0]; o.pr1 = d.spos[o.r0 + 1]; o.pc0 = d.spos[o.c0]; o.pc1 = d.spos[o.c0 + 1];
+}
+FNN_HD void pair_eval(const PairOps& o, int32_t m, int32_t twoP, double cm2, Cand& best) {
+    scan_micro(o.r0, o.c0, m, twoP, cm2, o.e00, o.e01, o.e10, o.e11, o.sxr0, o.sxr1, o.pr0, o.pr1,
+               o.sxc0, o.sxc1, o.pc0, o.pc1, best);
 }
 
 // all pairs between the fresh two-node cluster in slots (f0, f0 + 1) and the node(s) in slots
@@ -610,10 +630,11 @@ struct SweepSink {
     const Dev& d;
     Cand& best;
     double coef, th;
+    int32_t twoP;
     FNN_HD void operator()(double q, double dpq, double sxa, double sxb, int32_t pa, int32_t pb, int32_t rs, int32_t cs) const {
         consider(q, pa, pb, best);
         const double lbf = (coef * dpq - sxa) - sxb;
-        if (lbf <= th) la_append(d, d.sid[rs], d.sid[cs]);
+        if (lbf <= th) la_append(d, rs, cs, twoP);
     }
 };
 FNN_HD void fresh_eval(const Dev& d, int32_t f0, int32_t s, int32_t m, int32_t twoP, double cm2, double coef, double th,
@@ -622,7 +643,7 @@ FNN_HD void fresh_eval(const Dev& d, int32_t f0, int32_t s, int32_t m, int32_t t
     const double* F0 = d.D + (int64_t)f0 * d.ld + s;
     const double* F1 = F0 + d.ld;
     const double a0 = F0[0], a1 = F0[1], b0 = F1[0], b1 = F1[1];
-    const SweepSink sink{d, best, coef, th};
+    const SweepSink sink{d, best, coef, th, twoP};
     if (f0 > s)
         scan_micro_t(f0, s, m, twoP, cm2, a0, a1, b0, b1, sxf0, sxf1, d.spos[f0], d.spos[f0 + 1],
                      d.Sx[s], d.Sx[s + 1], d.spos[s], d.spos[s + 1], sink);
@@ -660,10 +681,29 @@ FNN_HD int64_t track_item_count(const TrackArgs& a) { return (int64_t)a.np + (in
 // a tracked pair: evaluated exactly if both clusters still exist unchanged
 FNN_HD void track_pair_item(const Dev& d, int64_t item, const TrackArgs& a, Cand& best) {
     const int32_t* t = d.tpairs + 4 * item;
-    const int32_t ia = t[0], ib = t[1];
-    const int32_t sa = d.islot[ia], sb = d.islot[ib];
-    if (sa < 0 || sb < 0 || d.cstamp[ia] != t[2] || d.cstamp[ib] != t[3]) return;  // a cluster is gone or was re-formed
-    pair_eval(d, sa, sb, a.m, a.twoP, a.cm2, best);
+    const int32_t wa = t[0], wb = t[1];
+    const int32_t ia = wa & ~LA_PAIRED_BIT, ib = wb & ~LA_PAIRED_BIT;
+    int32_t sa = t[2], sb = t[3];
+    PairOps o;
+    pair_load(d, sa, sb, o);  // (at the hinted slots, beside the check that the nodes still sit there)
+    // (a slot beyond the live range may still carry the id of a node that was moved out of it)
+    if (sa >= a.m || sb >= a.m || d.sid[sa] != ia || d.sid[sb] != ib) {
+        sa = d.islot[ia]; sb = d.islot[ib];
+        if (sa < 0 || sb < 0) return;  // a cluster is gone
+        pair_load(d, sa, sb, o);
+    }
+    if ((sa < a.twoP) != (wa < 0) || (sb < a.twoP) != (wb < 0)) return;  // a singleton has become half of a new cluster
+    pair_eval(o, a.m, a.twoP, a.cm2, best);
+}
+// the slot of the fi-th fresh cluster's representative, -1 if the cluster has been consumed by a later event
+FNN_HD int32_t fresh_slot(const Dev& d, int32_t fi, int32_t m) {
+    const int32_t id = d.fresh[3 * fi], stamp = d.fresh[3 * fi + 1];
+    int32_t f0 = d.fresh[3 * fi + 2];
+    if (f0 >= m || d.sid[f0] != id) {
+        f0 = d.islot[id];
+        if (f0 < 0 || d.cstamp[id] != stamp) return -1;
+    }
+    return f0;
 }
 // item r of the sweep of the new clusters' rows.  `bestu` receives the swept pairs when the sweep runs
 // on an approximate row sum (a.approx); false: the swept cluster is not the one whose sum a.sxu is.
@@ -671,9 +711,8 @@ FNN_HD bool track_sweep_item(const Dev& d, int64_t r, const TrackArgs& a, Cand& 
     const int32_t half = (a.m + 1) / 2;
     const int32_t fi = a.nf0 + (int32_t)(r / half), cp = (int32_t)(r % half);
     if (fi >= a.nf) return true;
-    const int32_t id = d.fresh[2 * fi], stamp = d.fresh[2 * fi + 1];
-    const int32_t f0 = d.islot[id];
-    if (f0 < 0 || d.cstamp[id] != stamp) return true;  // already consumed by a later event
+    const int32_t f0 = fresh_slot(d, fi, a.m);
+    if (f0 < 0) return true;
     // (insertion with the approximate sum: its error, ~1e-16 m n Dmax, is far inside the gap la_delta ~ 1e-6 n Dmax
     //  between the insertion threshold theta_pred and the acceptance threshold theta_eff)
     if (a.approx) {
@@ -1383,18 +1422,52 @@ FNN_HD double tgt_compute(const Tgt& t, const double v[4]) {
 // Reads only rows of involved slots at its own column(s) and writes only entries with
 // exactly one index equal to its own column(s), so it cannot conflict with any other thread;
 // the involved slots themselves are handled by update_special_*.
+// The part of the control block the column threads of the update read, BY VALUE: on the GPU every field
+// is wave-uniform and sits in scalar registers (fetched once; a `const State&` in memory costs one
+// dependent round trip of ~1.7 us each time the compiler reaches a field it has not loaded yet).
+struct PlanView {
+    int32_t m_old, P_old, ev_finish, xs, ys, nS, ntgt, tU, tV;
+    int32_t S[MAX_S];
+    Tgt tgt[MAX_TGT];
+};
+template <class Uni>
+FNN_HD PlanView plan_view(const State& st, Uni uni) {  // uni(x): x as a wave-uniform value
+    PlanView v;
+    v.m_old = uni(st.m_old); v.P_old = uni(st.P_old); v.ev_finish = uni(st.ev_finish);
+    v.xs = uni(st.xs); v.ys = uni(st.ys); v.nS = uni(st.nS); v.ntgt = uni(st.ntgt); v.tU = uni(st.tU); v.tV = uni(st.tV);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < MAX_S; i++) v.S[i] = uni(st.S[i]);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < MAX_TGT; i++) {
+        v.tgt[i].dst = uni(st.tgt[i].dst); v.tgt[i].kind = uni(st.tgt[i].kind); v.tgt[i].a = uni(st.tgt[i].a);
+        v.tgt[i].b = uni(st.tgt[i].b); v.tgt[i].c = uni(st.tgt[i].c); v.tgt[i].d = uni(st.tgt[i].d);
+    }
+    return v;
+}
+struct UniId { FNN_HD int32_t operator()(int32_t x) const { return x; } };
+
 // tuv[0..1] receive this cluster's terms of T of the new cluster's two nodes.
-FNN_HD double update_bulk(const Dev& d, int32_t k, double tuv[2]) {
-    const State& st = *d.st;
+FNN_HD double update_bulk(const Dev& d, const PlanView& st, int32_t k, double tuv[2]) {
     tuv[0] = tuv[1] = 0.0;
     if (k >= st.m_old) return 0.0;
     const int32_t twoP = 2 * st.P_old;
     const bool paired = k < twoP;
     if (paired && (k & 1)) return 0.0;  // the even thread of a two-node cluster does both columns
-    for (int i = 0; i < st.nS; i++) if (st.S[i] == k) return 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < MAX_S; i++) if (i < st.nS && st.S[i] == k) return 0.0;
     double* D = d.D; const int64_t ld = d.ld;
     double sx0 = 0.0, sx1 = 0.0;
     double told0 = 0.0, told1 = 0.0;  // what the merging nodes contributed to T of node k (k + 1)
+    // (everything this thread reads besides the matrix is fetched up front: a load that the compiler meets only
+    //  after the matrix stores would be one more dependent round trip)
+    const double t0_old = d.T[k], t1_old = paired ? d.T[k + 1] : 0.0;
+    const int32_t pos0 = d.spos[k], pos1 = paired ? d.spos[k + 1] : 0;
     if (!st.ev_finish) {
         // subtractClusterDistance(p, x); subtractClusterDistance(p, y) (:455-461, 681-696)
         sx0 = d.Sx[k];
@@ -1460,13 +1533,13 @@ FNN_HD double update_bulk(const Dev& d, int32_t k, double tuv[2]) {
         if (!paired) dpu = (u0 + v0) / 2.0;
         else dpu = (((u0 + v0) + u1) + v1) / 4.0;
         d.Sx[k] = sx0 + dpu;
-        d.chain[chain_addr(d.spos[k])] = dpu;
+        d.chain[chain_addr(pos0)] = dpu;
         // approximate weighted row sums: the merged nodes go, the new cluster's two nodes come (weight 1/2 each)
-        d.T[k] = (d.T[k] - told0) + 0.5 * (u0 + v0);
+        d.T[k] = (t0_old - told0) + 0.5 * (u0 + v0);
         if (paired) {
             d.Sx[k + 1] = sx1 + dpu;
-            d.chain[chain_addr(d.spos[k + 1])] = 0.0;
-            d.T[k + 1] = (d.T[k + 1] - told1) + 0.5 * (u1 + v1);
+            d.chain[chain_addr(pos1)] = 0.0;
+            d.T[k + 1] = (t1_old - told1) + 0.5 * (u1 + v1);
             tuv[0] = 0.5 * (u0 + u1); tuv[1] = 0.5 * (v0 + v1);
         } else { tuv[0] = u0; tuv[1] = v0; }
         return dpu;  // (this cluster's addend of the new cluster's row sum)

@@ -92,9 +92,10 @@ class Engine {
             !(dev.islot = (int32_t*)be.alloc(sizeof(int32_t) * (3 * nn + 8))) ||
             !(dev.cstamp = (int32_t*)be.alloc(sizeof(int32_t) * (3 * nn + 8))) ||
             !(dev.tpairs = (int32_t*)be.alloc(sizeof(int32_t) * 4 * LA_PCAP)) ||
-            !(dev.fresh = (int32_t*)be.alloc(sizeof(int32_t) * 2 * LA_KMAX)) ||
+            !(dev.fresh = (int32_t*)be.alloc(sizeof(int32_t) * 3 * LA_KMAX)) ||
             !(dev.ticket = (uint32_t*)be.alloc(sizeof(uint32_t) * 32 * 72)) ||
             !(dev.lacnt = (int32_t*)be.alloc(256)) ||
+            !(dev.ticks = (int64_t*)be.alloc(sizeof(int64_t) * 32)) ||
             !(dev.lalog = (double*)be.alloc(sizeof(double) * 5 * LA_LOGCAP)) ||
             // k_update (deferred close) leaves {sum, sum of magnitudes} per workgroup: ceil(m / 256) + 1 workgroups;
             // -> sized from the update grid like rxpart
@@ -118,7 +119,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.recs); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.recs); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.ticks); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }
@@ -234,7 +235,7 @@ class Engine {
             return fail(FNN_EHIP, "fnn_begin: state upload failed (" + be.err() + ")");
         if (be.memset(dev.islot, 0xFF, sizeof(int32_t) * (3 * (size_t)(n > 0 ? n : 1) + 8)) != FNN_OK ||
             be.memset(dev.cstamp, 0, sizeof(int32_t) * (3 * (size_t)(n > 0 ? n : 1) + 8)) != FNN_OK ||
-            be.memset(dev.ticket, 0, sizeof(uint32_t) * 32 * 72) != FNN_OK || be.memset(dev.lacnt, 0, 256) != FNN_OK)
+            be.memset(dev.ticket, 0, sizeof(uint32_t) * 32 * 72) != FNN_OK || be.memset(dev.lacnt, 0, 256) != FNN_OK || be.memset(dev.ticks, 0, sizeof(int64_t) * 32) != FNN_OK)
             return fail(FNN_EHIP, "fnn_begin: memset failed (" + be.err() + ")");
         if (n > 3) {
             // max |D| (error bounds of the screening pass and of the certified 4-candidate choice), the bf16 copy if wanted

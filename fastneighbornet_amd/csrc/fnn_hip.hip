@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_emit(Dev d) {
     auto emit = [&](int32_t rs, int32_t cs, float lb) {
         if (!(lb <= tp)) return;
         const int i = atomicAdd(&lcount, 1);
-        if (i < EMIT_LDS) lbuf[i] = make_int2(d.sid[rs], d.sid[cs]);
+        if (i < EMIT_LDS) lbuf[i] = make_int2(rs, cs);
     };
     // `per` units per wave and step (a power of two, 4..64: few enough that all waves of the grid get
     // some when the live matrix is small): lane l < per fetches one unit's mask; the marked 32 x 8
@@ -410,8 +410,7 @@ __global__ __launch_bounds__(256) void k_emit(Dev d) {
         const int idx = base + i;
         if (idx < pcap) {
             const int2 pr = lbuf[i];
-            int32_t* t = d.tpairs + 4 * (int64_t)idx;
-            t[0] = pr.x; t[1] = pr.y; t[2] = d.cstamp[pr.x]; t[3] = d.cstamp[pr.y];
+            la_record(d, d.tpairs + 4 * (int64_t)idx, pr.x, pr.y, twoP);
         }
     }
 }
@@ -1014,6 +1013,37 @@ __device__ __forceinline__ void build_targets_wave(State& st) {
 }
 
 
+// The cached slot-table entries in the lanes of one wave (fnn_core.h: CachedTab is the same thing on arrays):
+// lane i < TAB_NK holds key[i] with its sid / spos, lane i < TAB_NP pkey[i] with its pslot.  The whole wave runs the
+// plan with wave-uniform control; a lookup is a ballot and a readlane instead of a search through memory.
+struct WaveTab {
+    const Dev& d;
+    int lane;
+    int32_t key, vsid, vspos, pkey, vpslot;
+    int32_t misses;
+    __device__ __forceinline__ int32_t sid(int32_t s) {
+        const unsigned long long hit = __ballot(key == s);
+        if (hit) return __builtin_amdgcn_readlane(vsid, (int)__builtin_ctzll(hit));
+        misses++;
+        return d.sid[s];
+    }
+    __device__ __forceinline__ int32_t spos(int32_t s) {
+        const unsigned long long hit = __ballot(key == s);
+        if (hit) return __builtin_amdgcn_readlane(vspos, (int)__builtin_ctzll(hit));
+        misses++;
+        return d.spos[s];
+    }
+    __device__ __forceinline__ int32_t pslot(int32_t p) {
+        const unsigned long long hit = __ballot(pkey == p);
+        if (hit) return __builtin_amdgcn_readlane(vpslot, (int)__builtin_ctzll(hit));
+        misses++;
+        return d.pslot[p];
+    }
+    __device__ __forceinline__ void set_sid(int32_t s, int32_t v) { if (key == s) vsid = v; if (lane == 0) d.sid[s] = v; }
+    __device__ __forceinline__ void set_spos(int32_t s, int32_t v) { if (key == s) vspos = v; if (lane == 0) d.spos[s] = v; }
+    __device__ __forceinline__ void set_pslot(int32_t p, int32_t v) { if (pkey == p) vpslot = v; if (lane == 0) d.pslot[p] = v; }
+};
+
 struct DecideLds {
     State lst;                 // the control block while the workgroup works on it
     int32_t key[TAB_NK], vsid[TAB_NK], vspos[TAB_NK];
@@ -1039,6 +1069,13 @@ __device__ __forceinline__ void state_out(State* gst, const State& lst) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(&lst);
     uint32_t* dst = reinterpret_cast<uint32_t*>(gst);
     for (int i = threadIdx.x; i < ST_NW; i += blockDim.x) dst[i] = src[i];
+}
+
+__device__ __forceinline__ Cand best_bcast(Cand b) {  // lane 0's candidate to the whole wave
+    Cand r;
+    r.q = __shfl(b.q, 0, 64);
+    r.key = (uint64_t)__shfl((unsigned long long)b.key, 0, 64);
+    return r;
 }
 
 // All threads of a 1024-thread workgroup call this; S.lst holds the control block (visible to the whole
@@ -1115,11 +1152,11 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
         }
     }
     __syncthreads();
-    // Cx / Cy, then the certified choice
+    // Cx / Cy, then the certified choice: by wave 0, every lane computing the same (wave-uniform control)
     Quad& qd = S.qd;
-    if (tid == 0) {
+    if (wv == 0) {
         const int32_t a = need ? S.ab[0] : 0, b = need ? S.ab[1] : 0;
-        pick(dl, best, a, b, need ? S.vsid[0] : 0, need ? S.vsid[2] : 0);
+        pick(dl, best_bcast(best), a, b, need ? S.vsid[0] : 0, need ? S.vsid[2] : 0);
         if (lst.ev_active && !lst.ev_finish) {
             // (pick may have exchanged the two nodes: Cx is the one with the smaller id)
             const int oa = lst.sa == a ? 0 : 2, ob = 2 - oa;
@@ -1163,11 +1200,12 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
             __syncthreads();
         }
     }
-    if (tid == 0) {
-        S.misses = 0;
-        CachedTab T{d, S.key, S.vsid, S.vspos, S.pkey, S.vpslot, &S.misses};
+    if (wv == 0) {
+        WaveTab T{d, lane, lane < TAB_NK ? S.key[lane] : -1, lane < TAB_NK ? S.vsid[lane] : 0, lane < TAB_NK ? S.vspos[lane] : 0,
+                  lane < TAB_NP ? S.pkey[lane] : -1, lane < TAB_NP ? S.vpslot[lane] : 0, 0};
         const double rx[4] = {S.rx[0], S.rx[1], S.rx[2], S.rx[3]};
         decide_plan(dl, T, qd, rx);
+        if (lane == 0) S.misses = T.misses;
     }
     __syncthreads();
     if (tid < 64) build_targets_wave(lst);
@@ -1231,9 +1269,8 @@ __device__ __forceinline__ void sweep_exact_item(const Dev& d, int64_t r, const 
     const int32_t half = (ta.m + 1) / 2;
     const int32_t fi = ta.nf0 + (int32_t)(r / half), cp = (int32_t)(r % half);
     if (fi >= ta.nf) return;
-    const int32_t id = d.fresh[2 * fi], stamp = d.fresh[2 * fi + 1];
-    const int32_t f0 = d.islot[id];
-    if (f0 < 0 || d.cstamp[id] != stamp) return;
+    const int32_t f0 = fresh_slot(d, fi, ta.m);
+    if (f0 < 0) return;
     const int32_t s2 = 2 * cp;
     if (s2 >= ta.m || s2 == f0) return;
     const double* F0 = d.D + (int64_t)f0 * d.ld + s2;
@@ -1269,6 +1306,9 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         if (wg == 0 && threadIdx.x == 0) st->ev_active = 0;  // (a launch sequence without a decide kernel must not replay the last event)
         return;
     }
+    // every tracking workgroup fetches the control block now (nothing writes to it while they track): the one that
+    // arrives last continues on this LDS copy and writes it back at the end
+    state_in(S.lst, st);
     if (!has_scan && st->stall) {  // (the launch sequence has no scan kernels and the window is gone: nothing to do)
         if (wg == 0 && threadIdx.x == 0) st->n_stalled++;
         return;
@@ -1325,8 +1365,10 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         eps_u = 4.0 * ((double)ta.m + 8.0) * 1.1102230246251565e-16 * shs[1];
     }
     bool swept_ok = true;
+    // (the sweep items are dealt out from the far end of the grid: tracked pairs and sweep run side by side in
+    //  different workgroups as long as there are fewer items than threads)
     if (!giveup)
-        for (int64_t r = start; r < items - ta.np; r += stride) swept_ok = track_sweep_item(d, r, ta, best, bestu) && swept_ok;
+        for (int64_t r = stride - 1 - start; r < items - ta.np; r += stride) swept_ok = track_sweep_item(d, r, ta, best, bestu) && swept_ok;
     if (!swept_ok) atomicOr(d.ticket + TRK_BAD, 1u);  // (not expected: the swept cluster is not the chain's)
     TRK_TICK(2);
     // both minima in one pass: wave reduction, one barrier, thread 0 folds the waves
@@ -1366,9 +1408,8 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     if (!lastflag) return;
     __threadfence();
     TRK_TICK(4);
-    // from here on this workgroup works on an LDS copy of the control block (no other workgroup writes to it
+    // from here on this workgroup works on its LDS copy of the control block (no other workgroup writes to it
     // during this launch); the copy goes back at the end
-    state_in(S.lst, st);
     State& lst = S.lst;
     Dev dl = d;
     dl.st = &lst;
@@ -1453,7 +1494,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     if (lst.la_hit) decide_step(d, S, L, best);
     TRK_TICK(7);
     if (prof) {
-        for (int q = 0; q < 8; q++) lst.ev_ticks[q] += S.tk[q + 1] - S.tk[q];
+        for (int q = 0; q < 8; q++) d.ticks[q] += S.tk[q + 1] - S.tk[q];
     }
     __syncthreads();
     state_out(st, lst);
@@ -1463,55 +1504,234 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
 // ------------------------------------------------------------------ k_update
 // subtract + every micro-op + add of one event in ONE launch (fnn_core.h: update_bulk /
 // update_special).  The last workgroup handles the <= 8 involved slots in phases.
-__global__ __launch_bounds__(256) void k_update(Dev d, int defer) {
+// The involved slots' phases (fnn_core.h: subtract_thread / op_thread / add_thread on the S x S block) by ONE wave:
+// lane i < nS owns involved slot S[i] and column i of the block in LDS.  The generic bodies address the block through
+// slot numbers (a search per access: ~1000 instructions per phase for a lone wave); here every operand of a phase is
+// resolved once - slots that are the same for all lanes by a ballot, a lane's own partner by eight readlanes up front -
+// so a phase is a few dozen instructions.  Same operations, same order, same roundings as the generic bodies (which
+// the CPU emulation runs against the oracle); the GPU parity tests compare Sx, T's consumers and the live matrix
+// after every event.  Returns this lane's addends {row-sum addend, T terms of u, v} of the add phase.
+struct SpecialOut { double val, tu, tv; };
+__device__ __forceinline__ SpecialOut special_wave(const Dev& d, const State& lst, double* blk, double* sxl, double* tl, int32_t* berr) {
+    const int lane = threadIdx.x & 63;
+    const int nS = __builtin_amdgcn_readfirstlane(lst.nS);
+    const int32_t Sl = lane < nS ? lst.S[lane < MAX_S ? lane : 0] : -1;
+    const int m_old = __builtin_amdgcn_readfirstlane(lst.m_old), twoP_old = 2 * __builtin_amdgcn_readfirstlane(lst.P_old);
+    const int m = __builtin_amdgcn_readfirstlane(lst.m), twoP = 2 * __builtin_amdgcn_readfirstlane(lst.P);
+    const int xs = __builtin_amdgcn_readfirstlane(lst.xs), ys = __builtin_amdgcn_readfirstlane(lst.ys);
+    const int U = __builtin_amdgcn_readfirstlane(lst.U), V = U + 1;
+    const int nops = __builtin_amdgcn_readfirstlane(lst.nops), ev_finish = __builtin_amdgcn_readfirstlane(lst.ev_finish);
+    const int32_t myspos = (Sl >= 0 && Sl < m) ? d.spos[Sl] : 0;  // (new layout; for the chain addend of the add phase)
+    auto ixu = [&](int slot) -> int {  // local index of a slot that is the same for all lanes (-1: not involved)
+        const unsigned long long b = __ballot(Sl == slot && Sl >= 0);
+        return b ? (int)__builtin_ctzll(b) : -1;
+    };
+    auto ixl = [&](int32_t slot) -> int {  // local index of a per-lane slot
+        int r = -1;
+#pragma unroll
+        for (int j = 0; j < MAX_S; j++) if (__builtin_amdgcn_readlane(Sl, j) == slot && slot >= 0) r = j;
+        return r;
+    };
+    const int me = lane;
+    const int pold = (Sl >= 0 && Sl < twoP_old) ? ixl(Sl ^ 1) : -1;         // partner's column, old layout
+    const int pnew = (Sl >= 0 && Sl < twoP && !(Sl & 1)) ? ixl(Sl + 1) : -1;  // ... of a representative, new layout
+    auto B = [&](int r, int c) -> double& { return blk[r * MAX_S + c]; };
+    auto bad = [&]() { *berr = 13; };
+    SpecialOut out{0.0, 0.0, 0.0};
+    // ---- subtract (old layout), NetMakerOriginal.java:455-461, 681-696
+    if (!ev_finish) {
+        const bool sp = Sl >= 0 && Sl < twoP_old;
+        const bool act = Sl >= 0 && Sl < m_old && Sl != xs && Sl != ys && !(sp && (Sl & 1));
+        double sx = 0.0, sxn = 0.0, told0 = 0.0, told1 = 0.0;
+        bool bystander = true;
+        if (act) { sx = sxl[me]; if (sp) { if (pold < 0) bad(); else sxn = sxl[pold]; } }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int t = q == 0 ? xs : ys;
+            const int tn = t < twoP_old ? (t ^ 1) : -1;
+            const int it = ixu(t), itn = tn >= 0 ? ixu(tn) : -1;
+            if (it < 0 || (tn >= 0 && itn < 0)) { bad(); continue; }
+            if (!act) continue;
+            if (Sl == t || Sl == tn) { bystander = false; continue; }
+            double v;
+            if (!sp && tn < 0) { const double e = B(it, me); v = e; told0 += e; }
+            else if (sp && tn < 0) { const double e0 = B(it, me), e1 = B(it, pold); v = (e0 + e1) / 2.0; told0 += e0; told1 += e1; }
+            else if (!sp && tn >= 0) { const double e0 = B(it, me), f0 = B(itn, me); v = (e0 + f0) / 2.0; told0 += 0.5 * (e0 + f0); }
+            else {
+                const double e0 = B(it, me), f0 = B(itn, me), e1 = B(it, pold), f1 = B(itn, pold);
+                v = (((e0 + f0) + e1) + f1) / 4.0;
+                told0 += 0.5 * (e0 + f0); told1 += 0.5 * (e1 + f1);
+            }
+            sx -= v;
+            sxn -= v;
+        }
+        if (act) {
+            sxl[me] = sx;
+            if (sp && pold >= 0) sxl[pold] = sxn;
+            if (bystander) {
+                tl[me] = tl[me] - told0;
+                if (sp && pold >= 0) tl[pold] = tl[pold] - told1;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the micro-ops, one phase each (fnn_core.h: op_thread)
+    for (int ph = 0; ph < nops; ph++) {
+        const int kind = __builtin_amdgcn_readfirstlane(lst.ops[ph].kind), mcur = __builtin_amdgcn_readfirstlane(lst.ops[ph].mcur);
+        const int oa = __builtin_amdgcn_readfirstlane(lst.ops[ph].a), ob = __builtin_amdgcn_readfirstlane(lst.ops[ph].b);
+        const bool in = Sl >= 0 && Sl < mcur;
+        if (kind == OP_SWAP) {
+            const int ia = ixu(oa), ib = ixu(ob);
+            if (ia < 0 || ib < 0) bad();
+            else if (in) {
+                if (me == ia) {
+                    double t = sxl[ia]; sxl[ia] = sxl[ib]; sxl[ib] = t;
+                    t = tl[ia]; tl[ia] = tl[ib]; tl[ib] = t;
+                } else if (me != ib) {
+                    const double ta = B(ia, me), tb = B(ib, me);
+                    B(ia, me) = tb; B(me, ia) = tb;
+                    B(ib, me) = ta; B(me, ib) = ta;
+                }
+            }
+        } else if (kind == OP_MOVE) {
+            const int is = ixu(oa), id = ixu(ob);
+            if (is < 0 || id < 0) bad();
+            else if (in) {
+                if (me == is) { B(id, id) = 0.0; sxl[id] = sxl[is]; tl[id] = tl[is]; }
+                else if (me != id) { const double t = B(is, me); B(id, me) = t; B(me, id) = t; }
+            }
+        } else if (kind == OP_AGG3) {
+            const int oc = __builtin_amdgcn_readfirstlane(lst.ops[ph].c), od = __builtin_amdgcn_readfirstlane(lst.ops[ph].d),
+                      oe = __builtin_amdgcn_readfirstlane(lst.ops[ph].e), flag = __builtin_amdgcn_readfirstlane(lst.ops[ph].flag);
+            const int iX = ixu(oa), iY = ixu(ob), iZ = ixu(oc), iU = ixu(od), iV = ixu(oe);
+            if (iX < 0 || iY < 0 || iZ < 0 || iU < 0 || iV < 0) bad();
+            else if (in) {
+                if (me == iX) {
+                    // the aliased entry D[u][v] and the diagonal (NetMakerOriginal.java:653-656, 670)
+                    const double dxz = B(iX, iZ), dyx = B(iY, iX), dyz = B(iY, iZ);
+                    double uv;
+                    if (flag) uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + dyx / 3.0) + dyz / 3.0;
+                    else uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + dyz / 3.0) + dyx / 3.0;
+                    B(iU, iU) = 0.0; B(iV, iV) = 0.0;
+                    B(iU, iV) = uv; B(iV, iU) = uv;
+                } else if (me != iY && me != iZ) {
+                    const double dx = B(iX, me), dy = B(iY, me), dz = B(iZ, me);
+                    const double nu = (2.0 / 3.0) * dx + dy / 3.0;
+                    const double nv = (2.0 / 3.0) * dz + dy / 3.0;
+                    B(iU, me) = nu; B(me, iU) = nu;
+                    B(iV, me) = nv; B(me, iV) = nv;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- add (new layout), NetMakerOriginal.java:520-533
+    if (!ev_finish) {
+        const int iU = ixu(U), iV = ixu(V);
+        if (iU < 0 || iV < 0) bad();
+        else if (Sl >= 0 && Sl < m) {
+            const bool sp = Sl < twoP;
+            const bool rep = !sp || !(Sl & 1);
+            double val = 0.0;
+            if (rep && Sl != U) {
+                const double u0 = B(iU, me), v0 = B(iV, me);
+                double dpu;
+                if (!sp) {
+                    dpu = (u0 + v0) / 2.0;
+                    tl[me] = tl[me] + 0.5 * (u0 + v0);
+                    out.tu = u0; out.tv = v0;
+                } else if (pnew < 0) { bad(); dpu = 0.0; }
+                else {
+                    const double u1 = B(iU, pnew), v1 = B(iV, pnew);
+                    dpu = (((u0 + v0) + u1) + v1) / 4.0;
+                    tl[me] = tl[me] + 0.5 * (u0 + v0);
+                    tl[pnew] = tl[pnew] + 0.5 * (u1 + v1);
+                    out.tu = 0.5 * (u0 + u1); out.tv = 0.5 * (v0 + v1);
+                    sxl[pnew] = sxl[pnew] + dpu;
+                }
+                sxl[me] = sxl[me] + dpu;
+                val = dpu;
+            } else if (Sl == U) {
+                const double uv = B(iU, iV);
+                out.tu = 0.5 * uv; out.tv = 0.5 * uv;
+            }
+            d.chain[chain_addr(myspos)] = val;
+            out.val = val;
+        }
+    }
+    __syncthreads();
+    return out;
+}
+
+struct UniLane { __device__ __forceinline__ int32_t operator()(int32_t x) const { return __builtin_amdgcn_readfirstlane(x); } };
+
+__global__ __launch_bounds__(256) void k_update(Dev d, int defer, int ticks) {
     __shared__ double shp[4][4];
+    __shared__ State lst;  // every workgroup fetches the control block ONCE, with one coalesced load
     State* st = d.st;
-    if (!st->ev_active || st->stall) return;
+    // diagnostic (FNN_TICKS=1): 100 MHz stamps of thread 0 of the special workgroup (slots 0-3) and of bulk workgroup 0 (4-7)
+    long long tk0 = 0;
+    const bool prof = ticks != 0 && threadIdx.x == 0 && (blockIdx.x == gridDim.x - 1 || blockIdx.x == 0);
+    const int tkb = blockIdx.x == gridDim.x - 1 ? 0 : 4;
+#define UPD_TICK(slot) do { if (prof) { const long long now_ = (long long)wall_clock64(); d.ticks[8 + tkb + (slot)] += now_ - tk0; tk0 = now_; } } while (0)
+    if (prof) tk0 = (long long)wall_clock64();
+    state_in(lst, st);
+    __syncthreads();
+    if (!lst.ev_active || lst.stall) return;
+    UPD_TICK(0);
     double dsum = 0.0, dabs = 0.0, tu = 0.0, tv = 0.0;
     const bool special = blockIdx.x == gridDim.x - 1;
     if (special) {
         // the <= 8 involved slots: their S x S block of the matrix, their row sums and their T are copied to LDS,
         // the reference's per-node bodies run on the copy in phases (subtract, one per micro-op, add: up to 8
-        // dependent steps at LDS instead of global-memory latency), and the block goes back in one sweep
+        // dependent steps at LDS latency), and the block goes back in one sweep.  The control block is worked on
+        // in LDS too (the phases read the plan from it; the last wave closes the event on it) and goes back whole:
+        // the bulk workgroups only read fields that this workgroup does not change.
         __shared__ double blk[MAX_S * MAX_S], sxl[MAX_S], tl[MAX_S];
         __shared__ int32_t berr;
+        Dev dl = d;
+        dl.st = &lst;
         if (threadIdx.x == 0) berr = 0;
-        if (threadIdx.x < MAX_S * MAX_S) special_block_load(d, blk, sxl, tl, (int32_t)threadIdx.x);
-        // the close of the event does not depend on the update (and nothing in the update reads what it
-        // writes): its round trips run beside the phases, in the last wave
-        if (threadIdx.x == 255) {
-            st->tp_n = st->ev_finish ? 0 : (int)gridDim.x;  // partial sums of T of the new cluster's nodes: the next decide step adds them up
-            st->tp_U = st->U;
-            if (defer) {
-                st->upart_n = (int)gridDim.x;
-                st->chain_m = st->m;
-                st->chain_U = st->U;
-                if (!st->ev_finish) st->chain_pending = 1;
-                close_event(d);
-            }
-        }
-        int32_t Sl[MAX_S];
-#pragma unroll
-        for (int i = 0; i < MAX_S; i++) Sl[i] = st->S[i];
-        const BlockAcc A{blk, sxl, tl, Sl, st->nS, &berr};
-        const int nph = update_special_phases(*st);
+        if (threadIdx.x < MAX_S * MAX_S) special_block_load(dl, blk, sxl, tl, (int32_t)threadIdx.x);
         __syncthreads();
-        for (int ph = 0; ph < nph; ph++) {
-            if (threadIdx.x < MAX_S) {
-                double tuv[2];
-                const double v = update_special_acc(A, d, ph, (int)threadIdx.x, tuv);
-                dsum += v;
-                dabs += v < 0.0 ? -v : v;
-                tu += tuv[0];
-                tv += tuv[1];
-            }
-            __syncthreads();  // a phase's LDS stores are visible to the next phase
+        UPD_TICK(1);
+        if (threadIdx.x < 64) {  // (the other waves only keep the barriers company)
+            const SpecialOut o = special_wave(d, lst, blk, sxl, tl, &berr);
+            dsum = o.val;
+            dabs = o.val < 0.0 ? -o.val : o.val;
+            tu = o.tu;
+            tv = o.tv;
+        } else {
+            const int nb = 2 + lst.nops;
+            for (int q = 0; q < nb; q++) __syncthreads();
         }
-        if (threadIdx.x < MAX_S * MAX_S) special_block_store(d, blk, sxl, tl, (int32_t)threadIdx.x);
-        if (threadIdx.x == 0 && berr) st->error = berr;
+        UPD_TICK(2);
+        if (threadIdx.x < MAX_S * MAX_S) special_block_store(dl, blk, sxl, tl, (int32_t)threadIdx.x);
+        // the close of the event (nothing in the update reads what it writes)
+        if (threadIdx.x == 255) {
+            lst.tp_n = lst.ev_finish ? 0 : (int)gridDim.x;  // partial sums of T of the new cluster's nodes: the next decide step adds them up
+            lst.tp_U = lst.U;
+            if (berr) lst.error = berr;
+            if (defer) {
+                lst.upart_n = (int)gridDim.x;
+                lst.chain_m = lst.m;
+                lst.chain_U = lst.U;
+                lst.chain_pending = lst.ev_finish ? 0 : 1;
+                close_event(dl);
+                if (lst.ev_finish) {  // special finish: u, v keep the default Sx (NetNode.java:15); nothing to sum
+                    d.Sx[lst.U] = 0.0;
+                    d.Sx[lst.U + 1] = 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        state_out(st, lst);
     } else {
         double tuv[2];
-        const double v = update_bulk(d, blockIdx.x * 256 + threadIdx.x, tuv);
+        const PlanView pv = plan_view(lst, UniLane{});
+        UPD_TICK(1);
+        const double v = update_bulk(d, pv, blockIdx.x * 256 + threadIdx.x, tuv);
+        UPD_TICK(2);
         dsum = v;
         dabs = v < 0.0 ? -v : v;
         tu = tuv[0];
@@ -1532,11 +1752,8 @@ __global__ __launch_bounds__(256) void k_update(Dev d, int defer) {
         const int k = threadIdx.x;
         d.upart[4 * blockIdx.x + k] = ((shp[0][k] + shp[1][k]) + shp[2][k]) + shp[3][k];
     }
-    if (defer && threadIdx.x == 0 && special && st->ev_finish) {  // special finish: u, v keep the default Sx (NetNode.java:15); nothing to sum
-        d.Sx[st->U] = 0.0;
-        d.Sx[st->U + 1] = 0.0;
-        st->chain_pending = 0;
-    }
+    UPD_TICK(3);
+#undef UPD_TICK
 }
 
 // the pending exact row sum, on its own (before the host looks at the state)
@@ -1927,7 +2144,7 @@ struct HipBackend {
     void enqueue_rest(const Dev& d, int32_t m_bound, const Cand* src, int nrecs) {
         dim3 g1 = grid1(m_bound);
         if (nrecs > 0) hipLaunchKernelGGL(k_decide, dim3(1), dim3(CH_T), 0, stream, d, src, nrecs);
-        hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d, defer_chain ? 1 : 0);
+        hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d, defer_chain ? 1 : 0, ticks ? 1 : 0);
         if (!defer_chain) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d);
     }
     // single GPU: the whole event
@@ -2081,8 +2298,13 @@ int64_t fnn_debug_window_log(fnn_handle* h, double* out, int64_t max_records) {
 int32_t fnn_debug_event_ticks(fnn_handle* h, int64_t* out8) {
     FNN_NEED(h);
     if (!out8) return fnn::fail(FNN_EINVAL, "fnn_debug_event_ticks: out8 is NULL");
-    if (h->eng.pull_state() != FNN_OK) return FNN_EHIP;
-    for (int q = 0; q < 8; q++) out8[q] = h->eng.hst.ev_ticks[q];
+    if (h->eng.be.d2h(out8, h->eng.dev.ticks, sizeof(int64_t) * 8) != FNN_OK) return FNN_EHIP;
+    return FNN_OK;
+}
+int32_t fnn_debug_update_ticks(fnn_handle* h, int64_t* out8) {
+    FNN_NEED(h);
+    if (!out8) return fnn::fail(FNN_EINVAL, "fnn_debug_update_ticks: out8 is NULL");
+    if (h->eng.be.d2h(out8, h->eng.dev.ticks + 8, sizeof(int64_t) * 8) != FNN_OK) return FNN_EHIP;
     return FNN_OK;
 }
 int32_t fnn_set_scan_timing(fnn_handle* h, int32_t enable) {

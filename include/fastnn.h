@@ -174,6 +174,9 @@ int64_t fnn_debug_window_log(fnn_handle* h, double* out, int64_t max_records);
  * pairs, sweep of the newest cluster's rows, workgroup reduction, arrival tickets, reading all workgroups'
  * records, the window's verdict, the decision tail (Cx/Cy, 4-candidate choice, merge plan)}. */
 int32_t fnn_debug_event_ticks(fnn_handle* h, int64_t* out8);
+/* Diagnostic (FNN_TICKS=1): the same for k_update, summed over all events: thread 0 of the workgroup of the involved
+ * slots {control block, block load, phases, tail} and of the first bulk workgroup {control block, -, columns, tail}. */
+int32_t fnn_debug_update_ticks(fnn_handle* h, int64_t* out8);
 
 /* Enable per-launch HIP-event timing of the scan kernel (bench.py's roofline
  * figure).  Adds two event records per scan launch. */

@@ -167,7 +167,7 @@ struct EmuBackend {
         float* lbrec = d.srec;
         float* ubrec = d.srec + nunits;
         auto emit = [&](int32_t rs, int32_t cs, float lb) {
-            if (st.la_emit && lb <= st.la_theta_pred) fnn::la_append(d, d.sid[rs], d.sid[cs]);
+            if (st.la_emit && lb <= st.la_theta_pred) fnn::la_append(d, rs, cs, twoP);
         };
         for (int32_t u : thread_order(nunits)) {
             fnn::Brk b{finf, finf};
@@ -385,7 +385,8 @@ struct EmuBackend {
                 for (int32_t ph = 0; ph < nph; ph++)
                     for (int32_t i : thread_order(fnn::MAX_S)) { fnn::update_special_acc(A, d, ph, i, tuv); tub += tuv[0]; tvb += tuv[1]; }
             }
-            auto bulk1 = [&](int32_t k) { fnn::update_bulk(d, k, tuv); tu += tuv[0]; tv += tuv[1]; };
+            const fnn::PlanView pv = fnn::plan_view(st, fnn::UniId{});
+            auto bulk1 = [&](int32_t k) { fnn::update_bulk(d, pv, k, tuv); tu += tuv[0]; tv += tuv[1]; };
             auto bulk = [&]() { for (int32_t k : thread_order(m_bound)) bulk1(k); };
             auto special = [&](int32_t ph) { for (int32_t i : thread_order(fnn::MAX_S)) { fnn::update_special(d, ph, i, tuv); tu += tuv[0]; tv += tuv[1]; } };
             if (g_update_mode == 0) { bulk(); for (int32_t ph = 0; ph < nph; ph++) special(ph); }

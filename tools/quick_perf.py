@@ -20,6 +20,11 @@ for n in sizes:
         if st.n_window_hits:
             print("k_track us/window event (last workgroup, thread 0): " + " ".join(f"{nm}={tk[i] / 100.0 / st.n_window_hits:.2f}" for i, nm in
                   enumerate(["prologue", "pairs", "sweep", "reduce", "arrive", "records", "verdict", "tail"])), flush=True)
+        a._fn("debug_update_ticks", C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)])
+        a.debug_update_ticks(h._h, tk)
+        if tk[0] or tk[4]:
+            print("k_update us/event: " + " ".join(f"{nm}={tk[i] / 100.0 / st.n_events:.2f}" for i, nm in
+                  enumerate(["sp_state", "sp_load", "sp_phases", "sp_tail", "bulk_state", "bulk_-", "bulk_columns", "bulk_tail"])), flush=True)
         gb = st.scan_bytes / 1e9
         print(f"n={n} total={st.t_total_s:.3f}s init={st.t_init_s:.4f} agglom={st.t_agglom_s:.3f} "
               f"scan={st.t_scan_s:.3f}s events={st.n_events} sumE/n^3={st.sum_entries / n**3:.4f} "
