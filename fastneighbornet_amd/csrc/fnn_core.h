@@ -72,11 +72,20 @@ struct Op {
     int32_t flag;  // AGG3: 1 if pos(u) < pos(v) (aliasing rule, see agg3_special)
 };
 
-// scan candidate: q = +inf means "none"; key = (i << 32) | j, i > j reference positions
+// scan candidate: q = +inf means "none"; key = (i << 32) | j, i > j reference positions; si, sj: the slots of the
+// nodes at positions i, j (so that the decide step need not look them up: one dependent round trip less)
 struct Cand {
     double q;
     uint64_t key;
+    int32_t si, sj;
 };
+FNN_HD Cand cand_none() {
+    Cand c;
+    c.q = __builtin_bit_cast(double, (uint64_t)0x7FF0000000000000ULL);
+    c.key = ~0ULL;
+    c.si = c.sj = -1;
+    return c;
+}
 
 struct Event {  // == fnn_event / nno_event
     int32_t m_before, c_before, cx_id, cy_id, x_id, y_id, kind, u_id;
@@ -222,17 +231,35 @@ FNN_HD double inf_f64() {
     return v.d;
 }
 
+// x / 3.0, correctly rounded - bit for bit the IEEE quotient the reference's `D[y][p] / 3.0` produces - in three
+// operations instead of the ~35-instruction division expansion (a column thread of the update divides up to 48 times
+// and runs alone on its SIMD: nothing hides that latency).  Markstein's correction step: with z = RN(1/3) the product
+// q = RN(x z) is within one ulp of x / 3, the residual r = x - 3 q is exact in an FMA, and RN(q + r z) is the correctly
+// rounded quotient (3's significand is not all ones; a quotient is never a rounding midpoint).  Outside a generous
+// exponent range (where r could underflow or 3 q overflow) the plain division is used.  Checked against `/ 3.0` on
+// 5e9 random and structured operands (tests/tools/div3_check.c) and, through the oracle, by every parity test.
+FNN_HD double div3(double x) {
+    const double ax = __builtin_fabs(x);
+    if (!(ax >= 0x1p-900 && ax <= 0x1p900)) return x / 3.0;  // zero, tiny, huge, inf, NaN
+    const double z = 0x1.5555555555555p-2;
+    const double q = x * z;
+    const double r = __builtin_fma(-3.0, q, x);
+    return __builtin_fma(r, z, q);
+}
+
 FNN_HD bool cand_better(const Cand& a, const Cand& b) {
     // total order (Q, i, j): the reference keeps the FIRST strict minimum of its
     // (i asc, j asc) scan (NeighborNetCanonical.java:173), i.e. the argmin on this order
     return a.q < b.q || (a.q == b.q && a.key < b.key);
 }
 
-FNN_HD void consider(double q, int32_t pa, int32_t pb, Cand& best) {
+FNN_HD void consider(double q, int32_t pa, int32_t pb, int32_t sa, int32_t sb, Cand& best) {
     uint32_t i = (uint32_t)(pa > pb ? pa : pb), j = (uint32_t)(pa > pb ? pb : pa);
     Cand c;
     c.q = q;
     c.key = ((uint64_t)i << 32) | (uint64_t)j;
+    c.si = pa > pb ? sa : sb;
+    c.sj = pa > pb ? sb : sa;
     if (cand_better(c, best)) best = c;
 }
 
@@ -290,7 +317,7 @@ FNN_HD void scan_micro_t(int32_t r0, int32_t c0, int32_t m, int32_t twoP, double
 }
 struct BestSink {
     Cand& best;
-    FNN_HD void operator()(double q, double, double, double, int32_t pa, int32_t pb, int32_t, int32_t) const { consider(q, pa, pb, best); }
+    FNN_HD void operator()(double q, double, double, double, int32_t pa, int32_t pb, int32_t rs, int32_t cs) const { consider(q, pa, pb, rs, cs, best); }
 };
 FNN_HD void scan_micro(int32_t r0, int32_t c0, int32_t m, int32_t twoP, double cm2,
                        double e00, double e01, double e10, double e11,
@@ -632,7 +659,7 @@ struct SweepSink {
     double coef, th;
     int32_t twoP;
     FNN_HD void operator()(double q, double dpq, double sxa, double sxb, int32_t pa, int32_t pb, int32_t rs, int32_t cs) const {
-        consider(q, pa, pb, best);
+        consider(q, pa, pb, rs, cs, best);
         const double lbf = (coef * dpq - sxa) - sxb;
         if (lbf <= th) la_append(d, rs, cs, twoP);
     }
@@ -679,21 +706,31 @@ FNN_HD TrackArgs track_args(const State& st) {
 }
 FNN_HD int64_t track_item_count(const TrackArgs& a) { return (int64_t)a.np + (int64_t)(a.nf - a.nf0) * ((a.m + 1) / 2); }
 // a tracked pair: evaluated exactly if both clusters still exist unchanged
-FNN_HD void track_pair_item(const Dev& d, int64_t item, const TrackArgs& a, Cand& best) {
+struct PairRec { int32_t wa, wb, sa, sb; };
+FNN_HD PairRec track_pair_load(const Dev& d, int64_t item) {
     const int32_t* t = d.tpairs + 4 * item;
-    const int32_t wa = t[0], wb = t[1];
+    PairRec r;
+    r.wa = t[0]; r.wb = t[1]; r.sa = t[2]; r.sb = t[3];
+    return r;
+}
+FNN_HD void track_pair_rec(const Dev& d, const PairRec& r, const TrackArgs& a, Cand& best) {
+    const int32_t wa = r.wa, wb = r.wb;
     const int32_t ia = wa & ~LA_PAIRED_BIT, ib = wb & ~LA_PAIRED_BIT;
-    int32_t sa = t[2], sb = t[3];
+    int32_t sa = r.sa, sb = r.sb;
     PairOps o;
-    pair_load(d, sa, sb, o);  // (at the hinted slots, beside the check that the nodes still sit there)
     // (a slot beyond the live range may still carry the id of a node that was moved out of it)
-    if (sa >= a.m || sb >= a.m || d.sid[sa] != ia || d.sid[sb] != ib) {
+    const bool inr = sa >= 0 && sb >= 0 && sa < a.m && sb < a.m;
+    if (inr) pair_load(d, sa, sb, o);  // (at the hinted slots, beside the check that the nodes still sit there)
+    if (!inr || d.sid[sa] != ia || d.sid[sb] != ib) {
         sa = d.islot[ia]; sb = d.islot[ib];
         if (sa < 0 || sb < 0) return;  // a cluster is gone
         pair_load(d, sa, sb, o);
     }
     if ((sa < a.twoP) != (wa < 0) || (sb < a.twoP) != (wb < 0)) return;  // a singleton has become half of a new cluster
     pair_eval(o, a.m, a.twoP, a.cm2, best);
+}
+FNN_HD void track_pair_item(const Dev& d, int64_t item, const TrackArgs& a, Cand& best) {
+    track_pair_rec(d, track_pair_load(d, item), a, best);
 }
 // the slot of the fi-th fresh cluster's representative, -1 if the cluster has been consumed by a later event
 FNN_HD int32_t fresh_slot(const Dev& d, int32_t fi, int32_t m) {
@@ -1335,14 +1372,15 @@ FNN_HD void op_thread(const Acc& A, const Op& op, int32_t k) {
             // second write reading the first
             double dxz = A.get(X, Z), dyx = A.get(Y, X), dyz = A.get(Y, Z);
             double uv;
-            if (op.flag) uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + dyx / 3.0) + dyz / 3.0;
-            else uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + dyz / 3.0) + dyx / 3.0;
+            if (op.flag) uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + div3(dyx)) + div3(dyz);
+            else uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + div3(dyz)) + div3(dyx);
             A.put(U, U, 0.0); A.put(V, V, 0.0);
             A.put(U, V, uv); A.put(V, U, uv);
         } else if (k != Y && k != Z) {
             double dx = A.get(X, k), dy = A.get(Y, k), dz = A.get(Z, k);
-            double nu = (2.0 / 3.0) * dx + dy / 3.0;
-            double nv = (2.0 / 3.0) * dz + dy / 3.0;
+            const double dy3 = div3(dy);
+            double nu = (2.0 / 3.0) * dx + dy3;
+            double nv = (2.0 / 3.0) * dz + dy3;
             A.put(U, k, nu); A.put(k, U, nu);
             A.put(V, k, nv); A.put(k, V, nv);
         }
@@ -1386,35 +1424,61 @@ FNN_HD double add_thread(const Acc& A, const Dev& d, const State& st, int32_t s,
     return val;  // (this node's addend of the new cluster's row sum)
 }
 
-FNN_HD double tgt_value(const Tgt& t, const double* D, int64_t ld, int32_t c) {
-    if (t.kind == T_COPY) return D[t.a * ld + c];
-    if (t.kind == T_L1) return (2.0 / 3.0) * D[t.a * ld + c] + D[t.b * ld + c] / 3.0;
-    const double v1 = (2.0 / 3.0) * D[t.c * ld + c] + D[t.b * ld + c] / 3.0;
-    if (t.kind == T_L2U) {
-        const double u1 = (2.0 / 3.0) * D[t.a * ld + c] + D[t.b * ld + c] / 3.0;
-        return (2.0 / 3.0) * u1 + v1 / 3.0;
+// The part of the control block the column threads of the update read, BY VALUE: on the GPU every field
+// is wave-uniform and sits in scalar registers (fetched once; a `const State&` in memory costs one
+// dependent round trip of ~1.7 us each time the compiler reaches a field it has not loaded yet).
+struct PlanView {
+    int32_t m_old, P_old, ev_finish, nS, ntgt, tU, tV;
+    int32_t S[MAX_S];
+    // the rows a column thread reads are rows of involved slots: everything below is an INDEX into S
+    int32_t ix, ixn, iy, iyn;  // x, x.nbr, y, y.nbr (the merging nodes; -1: no partner)
+    int32_t tdst[MAX_TGT], tkind[MAX_TGT], ta[MAX_TGT], tb[MAX_TGT], tc[MAX_TGT], td[MAX_TGT];  // the recipes (Tgt), sources as indices
+};
+template <class Uni>
+FNN_HD PlanView plan_view(const State& st, Uni uni) {  // uni(x): x as a wave-uniform value
+    PlanView v;
+    v.m_old = uni(st.m_old); v.P_old = uni(st.P_old); v.ev_finish = uni(st.ev_finish);
+    v.nS = uni(st.nS); v.ntgt = uni(st.ntgt); v.tU = uni(st.tU); v.tV = uni(st.tV);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < MAX_S; i++) v.S[i] = uni(st.S[i]);
+    auto idx = [&](int32_t slot) {
+        int32_t r = -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int i = 0; i < MAX_S; i++) if (i < v.nS && v.S[i] == slot && slot >= 0) r = i;
+        return r;
+    };
+    const int32_t xs = uni(st.xs), ys = uni(st.ys), twoP = 2 * v.P_old;
+    v.ix = idx(xs); v.ixn = xs < twoP ? idx(xs ^ 1) : -1;
+    v.iy = idx(ys); v.iyn = ys < twoP ? idx(ys ^ 1) : -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < MAX_TGT; i++) {
+        v.tdst[i] = uni(st.tgt[i].dst); v.tkind[i] = uni(st.tgt[i].kind);
+        v.ta[i] = idx(uni(st.tgt[i].a)); v.tb[i] = idx(uni(st.tgt[i].b));
+        v.tc[i] = idx(uni(st.tgt[i].c)); v.td[i] = idx(uni(st.tgt[i].d));
     }
-    return (2.0 / 3.0) * D[t.d * ld + c] + v1 / 3.0;  // T_L2V
+    return v;
 }
+struct UniId { FNN_HD int32_t operator()(int32_t x) const { return x; } };
 
-// tgt_value in two steps, so that the loads of several recipes can be in flight together (a recipe's
-// kind is uniform over the threads: branching on it between load and use would serialise the rounds)
-FNN_HD void tgt_load(const Tgt& t, const double* D, int64_t ld, int32_t c, double v[4]) {
-    v[0] = v[1] = v[2] = v[3] = 0.0;
-    if (t.kind != T_L2V) v[0] = D[t.a * ld + c];
-    if (t.kind != T_COPY) v[1] = D[t.b * ld + c];
-    if (t.kind == T_L2U || t.kind == T_L2V) v[2] = D[t.c * ld + c];
-    if (t.kind == T_L2V) v[3] = D[t.d * ld + c];
-}
-FNN_HD double tgt_compute(const Tgt& t, const double v[4]) {
-    if (t.kind == T_COPY) return v[0];
-    if (t.kind == T_L1) return (2.0 / 3.0) * v[0] + v[1] / 3.0;
-    const double v1 = (2.0 / 3.0) * v[2] + v[1] / 3.0;
-    if (t.kind == T_L2U) {
-        const double u1 = (2.0 / 3.0) * v[0] + v[1] / 3.0;
-        return (2.0 / 3.0) * u1 + v1 / 3.0;
+// the value of recipe t at the column whose involved-row entries R(i) returns (i: index into S)
+template <class RowVal>
+FNN_HD double tgt_eval(const PlanView& st, int t, RowVal&& R) {
+    const int32_t kind = st.tkind[t];
+    if (kind == T_COPY) return R(st.ta[t]);
+    if (kind == T_L1) return (2.0 / 3.0) * R(st.ta[t]) + div3(R(st.tb[t]));
+    const double b3 = div3(R(st.tb[t]));
+    const double v1 = (2.0 / 3.0) * R(st.tc[t]) + b3;
+    if (kind == T_L2U) {
+        const double u1 = (2.0 / 3.0) * R(st.ta[t]) + b3;
+        return (2.0 / 3.0) * u1 + div3(v1);
     }
-    return (2.0 / 3.0) * v[3] + v1 / 3.0;  // T_L2V
+    return (2.0 / 3.0) * R(st.td[t]) + div3(v1);  // T_L2V
 }
 
 // Fused per-event update for a cluster whose slot(s) k (and k+1) are NOT involved in the
@@ -1422,65 +1486,24 @@ FNN_HD double tgt_compute(const Tgt& t, const double v[4]) {
 // Reads only rows of involved slots at its own column(s) and writes only entries with
 // exactly one index equal to its own column(s), so it cannot conflict with any other thread;
 // the involved slots themselves are handled by update_special_*.
-// The part of the control block the column threads of the update read, BY VALUE: on the GPU every field
-// is wave-uniform and sits in scalar registers (fetched once; a `const State&` in memory costs one
-// dependent round trip of ~1.7 us each time the compiler reaches a field it has not loaded yet).
-struct PlanView {
-    int32_t m_old, P_old, ev_finish, xs, ys, nS, ntgt, tU, tV;
-    int32_t S[MAX_S];
-    Tgt tgt[MAX_TGT];
-};
-template <class Uni>
-FNN_HD PlanView plan_view(const State& st, Uni uni) {  // uni(x): x as a wave-uniform value
-    PlanView v;
-    v.m_old = uni(st.m_old); v.P_old = uni(st.P_old); v.ev_finish = uni(st.ev_finish);
-    v.xs = uni(st.xs); v.ys = uni(st.ys); v.nS = uni(st.nS); v.ntgt = uni(st.ntgt); v.tU = uni(st.tU); v.tV = uni(st.tV);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int i = 0; i < MAX_S; i++) v.S[i] = uni(st.S[i]);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int i = 0; i < MAX_TGT; i++) {
-        v.tgt[i].dst = uni(st.tgt[i].dst); v.tgt[i].kind = uni(st.tgt[i].kind); v.tgt[i].a = uni(st.tgt[i].a);
-        v.tgt[i].b = uni(st.tgt[i].b); v.tgt[i].c = uni(st.tgt[i].c); v.tgt[i].d = uni(st.tgt[i].d);
-    }
-    return v;
-}
-struct UniId { FNN_HD int32_t operator()(int32_t x) const { return x; } };
-
+// R(i, c): the matrix entry D[S[i]][k + c] BEFORE the event (c = 0, 1).  The CPU emulation reads memory;
+// the GPU fetches the <= 8 (x 2) entries of its column up front in ONE round trip and serves R from LDS.
 // tuv[0..1] receive this cluster's terms of T of the new cluster's two nodes.
-FNN_HD double update_bulk(const Dev& d, const PlanView& st, int32_t k, double tuv[2]) {
-    tuv[0] = tuv[1] = 0.0;
-    if (k >= st.m_old) return 0.0;
-    const int32_t twoP = 2 * st.P_old;
-    const bool paired = k < twoP;
-    if (paired && (k & 1)) return 0.0;  // the even thread of a two-node cluster does both columns
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int i = 0; i < MAX_S; i++) if (i < st.nS && st.S[i] == k) return 0.0;
-    double* D = d.D; const int64_t ld = d.ld;
-    double sx0 = 0.0, sx1 = 0.0;
+template <class RowVal>
+FNN_HD double update_bulk(const Dev& d, const PlanView& st, int32_t k, bool paired, double sx0, double sx1, double t0_old,
+                          double t1_old, int32_t pos0, int32_t pos1, double tuv[2], RowVal&& R) {
     double told0 = 0.0, told1 = 0.0;  // what the merging nodes contributed to T of node k (k + 1)
-    // (everything this thread reads besides the matrix is fetched up front: a load that the compiler meets only
-    //  after the matrix stores would be one more dependent round trip)
-    const double t0_old = d.T[k], t1_old = paired ? d.T[k + 1] : 0.0;
-    const int32_t pos0 = d.spos[k], pos1 = paired ? d.spos[k + 1] : 0;
     if (!st.ev_finish) {
         // subtractClusterDistance(p, x); subtractClusterDistance(p, y) (:455-461, 681-696)
-        sx0 = d.Sx[k];
-        sx1 = paired ? d.Sx[k + 1] : 0.0;
         for (int q = 0; q < 2; q++) {
-            const int32_t t = q == 0 ? st.xs : st.ys;
-            const int32_t tn = t < twoP ? (t ^ 1) : -1;
+            const int32_t it = q == 0 ? st.ix : st.iy;
+            const int32_t itn = q == 0 ? st.ixn : st.iyn;
             double v;
-            if (!paired && tn < 0) { const double e = D[t * ld + k]; v = e; told0 += e; }
-            else if (paired && tn < 0) { const double e0 = D[t * ld + k], e1 = D[t * ld + k + 1]; v = (e0 + e1) / 2.0; told0 += e0; told1 += e1; }
-            else if (!paired && tn >= 0) { const double e0 = D[t * ld + k], f0 = D[tn * ld + k]; v = (e0 + f0) / 2.0; told0 += 0.5 * (e0 + f0); }
+            if (!paired && itn < 0) { const double e = R(it, 0); v = e; told0 += e; }
+            else if (paired && itn < 0) { const double e0 = R(it, 0), e1 = R(it, 1); v = (e0 + e1) / 2.0; told0 += e0; told1 += e1; }
+            else if (!paired && itn >= 0) { const double e0 = R(it, 0), f0 = R(itn, 0); v = (e0 + f0) / 2.0; told0 += 0.5 * (e0 + f0); }
             else {
-                const double e0 = D[t * ld + k], f0 = D[tn * ld + k], e1 = D[t * ld + k + 1], f1 = D[tn * ld + k + 1];
+                const double e0 = R(it, 0), f0 = R(itn, 0), e1 = R(it, 1), f1 = R(itn, 1);
                 v = (((e0 + f0) + e1) + f1) / 4.0;
                 told0 += 0.5 * (e0 + f0); told1 += 0.5 * (e1 + f1);
             }
@@ -1488,45 +1511,41 @@ FNN_HD double update_bulk(const Dev& d, const PlanView& st, int32_t k, double tu
             sx1 -= v;
         }
     }
-    // all new values first (a changed row may be the source of another), then the stores;
-    // fully unrolled so that tv[][] stays in registers
+    // all new values first (a changed row may be the source of another), then the stores
     double tv[MAX_TGT][2];
     double u0 = 0.0, u1 = 0.0, v0 = 0.0, v1 = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int t0 = 0; t0 < MAX_TGT; t0 += 4) {  // four recipes' loads in flight, then their values
-        double lv[4][2][4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int t = t0 + q;
-            if (t < st.ntgt) {
-                tgt_load(st.tgt[t], D, ld, k, lv[q][0]);
-                if (paired) tgt_load(st.tgt[t], D, ld, k + 1, lv[q][1]);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int t = t0 + q;
-            tv[t][0] = 0.0; tv[t][1] = 0.0;
-            if (t < st.ntgt) {
-                tv[t][0] = tgt_compute(st.tgt[t], lv[q][0]);
-                if (paired) tv[t][1] = tgt_compute(st.tgt[t], lv[q][1]);
-                if (t == st.tU) { u0 = tv[t][0]; u1 = tv[t][1]; }
-                if (t == st.tV) { v0 = tv[t][0]; v1 = tv[t][1]; }
-            }
+#endif
+    for (int t = 0; t < MAX_TGT; t++) {
+        tv[t][0] = 0.0; tv[t][1] = 0.0;
+        if (t < st.ntgt) {
+            tv[t][0] = tgt_eval(st, t, [&](int32_t i) { return R(i, 0); });
+            if (paired) tv[t][1] = tgt_eval(st, t, [&](int32_t i) { return R(i, 1); });
+            if (t == st.tU) { u0 = tv[t][0]; u1 = tv[t][1]; }
+            if (t == st.tV) { v0 = tv[t][0]; v1 = tv[t][1]; }
         }
     }
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
+#endif
     for (int t = 0; t < MAX_TGT; t++) {
         if (t < st.ntgt) {
-            const int32_t dst = st.tgt[t].dst;
-            store_d(d, dst, k, tv[t][0]);
-            store_d(d, k, dst, tv[t][0]);
+            // the entry and its mirror; of the two only the one at or below the diagonal has a bf16 copy (k is not
+            // an involved slot, so k != dst): one conversion, one 2-byte store
+            const int32_t dst = st.tdst[t];
+            const int64_t rb = (int64_t)dst * d.ld, rk = (int64_t)k * d.ld;
+            d.D[rb + k] = tv[t][0];
+            d.D[rk + dst] = tv[t][0];
+            if (d.H) d.H[k < dst ? rb + k : rk + dst] = bf16_from_double(tv[t][0]);
             if (paired) {
-                store_d(d, dst, k + 1, tv[t][1]);
-                store_d(d, k + 1, dst, tv[t][1]);
+                d.D[rb + k + 1] = tv[t][1];
+                d.D[rk + d.ld + dst] = tv[t][1];
+                if (d.H) d.H[k + 1 < dst ? rb + k + 1 : rk + d.ld + dst] = bf16_from_double(tv[t][1]);
             }
         }
     }
+    tuv[0] = tuv[1] = 0.0;
     if (!st.ev_finish) {
         // updateClusterDistances, per-node part (:520-531)
         double dpu;
@@ -1545,6 +1564,28 @@ FNN_HD double update_bulk(const Dev& d, const PlanView& st, int32_t k, double tu
         return dpu;  // (this cluster's addend of the new cluster's row sum)
     }
     return 0.0;
+}
+// which column thread works: returns false for threads without a cluster of their own; `paired`: two columns
+FNN_HD bool bulk_active(const PlanView& st, int32_t k, bool& paired) {
+    paired = false;
+    if (k >= st.m_old) return false;
+    paired = k < 2 * st.P_old;
+    if (paired && (k & 1)) return false;  // the even thread of a two-node cluster does both columns
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < MAX_S; i++) if (i < st.nS && st.S[i] == k) return false;
+    return true;
+}
+// the whole column thread with everything read straight from memory (CPU emulation)
+FNN_HD double update_bulk_mem(const Dev& d, const PlanView& st, int32_t k, double tuv[2]) {
+    tuv[0] = tuv[1] = 0.0;
+    bool paired;
+    if (!bulk_active(st, k, paired)) return 0.0;
+    const double* D = d.D; const int64_t ld = d.ld;
+    const int32_t* S = st.S;
+    return update_bulk(d, st, k, paired, d.Sx[k], paired ? d.Sx[k + 1] : 0.0, d.T[k], paired ? d.T[k + 1] : 0.0, d.spos[k],
+                       paired ? d.spos[k + 1] : 0, tuv, [&](int32_t i, int c) { return D[(int64_t)S[i] * ld + k + c]; });
 }
 
 // The involved slots (<= MAX_S columns) go through the per-column bodies above in phases:

@@ -46,15 +46,25 @@ constexpr int SCAN_TH = 32;   // rows per scan tile
 constexpr int SCAN_THREADS = 256;
 
 // ------------------------------------------------------------------ reductions
+// minimum of the wave on the total order (Q, i, j); valid in every lane.  Only (q, key) travel through the
+// shuffles; the slots of the winning pair are read from a lane that contributed it (a key names one pair).
 __device__ __forceinline__ Cand wave_reduce(Cand c) {
+    double q = c.q;
+    uint64_t key = c.key;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-        Cand o;
-        o.q = __shfl_down(c.q, off, 64);
-        o.key = (uint64_t)__shfl_down((unsigned long long)c.key, off, 64);
-        if (cand_better(o, c)) c = o;
+        const double oq = __shfl_down(q, off, 64);
+        const uint64_t ok = (uint64_t)__shfl_down((unsigned long long)key, off, 64);
+        if (oq < q || (oq == q && ok < key)) { q = oq; key = ok; }
     }
-    return c;
+    Cand r;
+    r.q = __shfl(q, 0, 64);
+    r.key = (uint64_t)__shfl((unsigned long long)key, 0, 64);
+    const unsigned long long src = __ballot(c.key == r.key);
+    const int l = src ? (int)__builtin_ctzll(src) : 0;
+    r.si = __builtin_amdgcn_readlane(c.si, l);
+    r.sj = __builtin_amdgcn_readlane(c.sj, l);
+    return r;
 }
 
 template <int NWAVES>
@@ -135,8 +145,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(Dev d) {
     __shared__ Cand sh[SCAN_THREADS / 64];
     const State* st = d.st;
     Cand best;
-    best.q = inf_f64();
-    best.key = ~0ULL;
+    best = cand_none();
     if (st->la_hit) return;  // the lookahead window already holds this event's minimum (recs[0])
     if (!st->done) {
         const int m = st->m;
@@ -565,8 +574,7 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d) {
     State* st = d.st;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     Cand best;
-    best.q = inf_f64();
-    best.key = ~0ULL;
+    best = cand_none();
     if (st->la_hit) return;  // the lookahead window already holds this event's minimum (recs[0])
     if (st->done) {  // nothing to scan: leave "no candidate" records
         if (tid == 0) (d.gather ? d.gsend : d.recs)[blockIdx.x] = best;
@@ -671,8 +679,7 @@ __global__ __launch_bounds__(256) void k_prep_screen(Dev d, int64_t nrows) {
 // ------------------------------------------------------------------ record reduction
 __device__ __forceinline__ Cand reduce_records(const Dev& d, const Cand* src, int nrecs, Cand* sh) {
     Cand best;
-    best.q = inf_f64();
-    best.key = ~0ULL;
+    best = cand_none();
     if (!d.st->done) {
         for (int i = threadIdx.x; i < nrecs; i += 1024) {
             Cand c = src[i];
@@ -1048,9 +1055,11 @@ struct DecideLds {
     State lst;                 // the control block while the workgroup works on it
     int32_t key[TAB_NK], vsid[TAB_NK], vspos[TAB_NK];
     int32_t pkey[TAB_NP], vpslot[TAB_NP];
-    int32_t ij[2], ab[2];      // reference positions and slots of the candidate's two nodes
+    int32_t ab[2];             // slots of the candidate's two nodes
     int32_t need, cert, exact, misses;
     long long tk[10];          // k_track: timestamps of the phase split (diagnostic)
+    long long dk[6];           // decide step: timestamps {entry, loads done, Cx/Cy + choice, plan, symbolic replay}
+    int32_t tkon;
     double quad[16];           // D over {a, a^1, b, b^1} x {a, a^1, b, b^1}
     double tz[4];              // T of a, a^1, b, b^1
     double tfin[2];            // T of the previous event's new cluster, just summed
@@ -1075,6 +1084,8 @@ __device__ __forceinline__ Cand best_bcast(Cand b) {  // lane 0's candidate to t
     Cand r;
     r.q = __shfl(b.q, 0, 64);
     r.key = (uint64_t)__shfl((unsigned long long)b.key, 0, 64);
+    r.si = __shfl(b.si, 0, 64);
+    r.sj = __shfl(b.sj, 0, 64);
     return r;
 }
 
@@ -1085,23 +1096,52 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
     Dev dl = d;
     dl.st = &lst;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#define DEC_TICK(slot) do { if (tid == 0 && S.tkon) S.dk[slot] = (long long)wall_clock64(); } while (0)
+    DEC_TICK(0);
     if (tid == 0) {
         S.need = pick_needs_candidate(lst) ? 1 : 0;
-        S.ij[0] = (int32_t)(best.key >> 32);
-        S.ij[1] = (int32_t)(best.key & 0xFFFFFFFFu);
+        S.ab[0] = best.si;   // the slots of the candidate's two nodes travel with the candidate
+        S.ab[1] = best.sj;
         S.cert = 1;
         S.exact = 0;
     }
     __syncthreads();
     const bool need = S.need != 0;
     const int32_t m = lst.m, P = lst.P;
-    // round trip 1: the candidate's slots, pslot of the last two positions; T of the newest cluster
+    const int32_t tpU = lst.tp_n > 0 ? lst.tp_U : -2;
+    // ONE round trip: wave 0 fetches the table entries the plan can touch, the 4 x 4 block of the matrix over the two
+    // clusters' nodes and their T; wave 1 sums the partial sums of T of the previous event's new cluster
     if (wv == 0) {
-        if (lane < 2 && need) S.ab[lane] = d.pslot[S.ij[lane]];
-        if (lane >= 2 && lane < 2 + TAB_NP) {
-            const int32_t pk = m - 1 - (lane - 2);
-            S.pkey[lane - 2] = pk >= 0 ? pk : -1;
-            S.vpslot[lane - 2] = pk >= 0 ? d.pslot[pk] : 0;
+        if (lane >= 40 && lane < 40 + TAB_NP) {
+            const int32_t pk = m - 1 - (lane - 40);
+            S.pkey[lane - 40] = pk >= 0 ? pk : -1;
+            S.vpslot[lane - 40] = pk >= 0 ? d.pslot[pk] : 0;
+        }
+        if (need) {
+            const int32_t a = S.ab[0], b = S.ab[1];
+            int32_t key[TAB_NK], pkey[TAB_NP];
+            tab_keys(a, b, P, m, key, pkey);
+            const int32_t s4[4] = {a, a ^ 1, b, b ^ 1};
+            if (lane < TAB_NK) {
+                int32_t k = -1;
+#pragma unroll
+                for (int q = 0; q < TAB_NK; q++) if (q == lane) k = key[q];
+                if (k < 0 || k >= d.n) k = -1;
+                S.key[lane] = k;
+                S.vsid[lane] = k >= 0 ? d.sid[k] : 0;
+                S.vspos[lane] = k >= 0 ? d.spos[k] : 0;
+            } else if (lane >= 16 && lane < 32) {
+                const int r = (lane - 16) >> 2, c = (lane - 16) & 3;
+                int32_t sr = 0, sc = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { if (q == r) sr = s4[q]; if (q == c) sc = s4[q]; }
+                S.quad[lane - 16] = d.D[(int64_t)sr * d.ld + sc];
+            } else if (lane >= 32 && lane < 36) {
+                int32_t sl = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (q == lane - 32) sl = s4[q];
+                S.tz[lane - 32] = (sl == tpU || sl == tpU + 1) ? 0.0 : d.T[sl];  // (the newest cluster's T: from wave 1, below)
+            }
         }
     } else if (wv == 1) {
         const int np = lst.tp_n;
@@ -1121,37 +1161,14 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
         }
     }
     __syncthreads();
-    const int32_t tpU = lst.tp_n > 0 ? lst.tp_U : -2;
-    __syncthreads();
     if (tid == 64) lst.tp_n = 0;
-    // round trip 2: table entries, the 4 x 4 block, T
-    if (wv == 0 && need) {
-        const int32_t a = S.ab[0], b = S.ab[1];
-        int32_t key[TAB_NK], pkey[TAB_NP];
-        tab_keys(a, b, P, m, key, pkey);
-        const int32_t s4[4] = {a, a ^ 1, b, b ^ 1};
-        if (lane < TAB_NK) {
-            int32_t k = -1;
-#pragma unroll
-            for (int q = 0; q < TAB_NK; q++) if (q == lane) k = key[q];
-            if (k < 0 || k >= d.n) k = -1;
-            S.key[lane] = k;
-            S.vsid[lane] = k >= 0 ? d.sid[k] : 0;
-            S.vspos[lane] = k >= 0 ? d.spos[k] : 0;
-        } else if (lane >= 16 && lane < 32) {
-            const int r = (lane - 16) >> 2, c = (lane - 16) & 3;
-            int32_t sr = 0, sc = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) { if (q == r) sr = s4[q]; if (q == c) sc = s4[q]; }
-            S.quad[lane - 16] = d.D[(int64_t)sr * d.ld + sc];
-        } else if (lane >= 32 && lane < 36) {
-            int32_t sl = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) if (q == lane - 32) sl = s4[q];
-            S.tz[lane - 32] = sl == tpU ? S.tfin[0] : (sl == tpU + 1 ? S.tfin[1] : d.T[sl]);
-        }
+    if (tid < 4 && need && tpU >= 0) {  // T of the newest cluster's nodes, where they are among the four
+        const int32_t sl = (tid & 2 ? S.ab[1] : S.ab[0]) ^ (tid & 1);
+        if (sl == tpU) S.tz[tid] = S.tfin[0];
+        else if (sl == tpU + 1) S.tz[tid] = S.tfin[1];
     }
     __syncthreads();
+    DEC_TICK(1);
     // Cx / Cy, then the certified choice: by wave 0, every lane computing the same (wave-uniform control)
     Quad& qd = S.qd;
     if (wv == 0) {
@@ -1179,6 +1196,7 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
         }
     }
     __syncthreads();
+    DEC_TICK(2);
     if (!lst.ev_active) return;  // the loop has ended
     if (lst.ev_finish) {         // the special finish: planned inside pick; only the symbolic replay is left
         if (tid < 64) build_targets_wave(lst);
@@ -1208,8 +1226,14 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
         if (lane == 0) S.misses = T.misses;
     }
     __syncthreads();
+    DEC_TICK(3);
     if (tid < 64) build_targets_wave(lst);
     __syncthreads();
+    DEC_TICK(4);
+    if (tid == 0 && S.tkon) {
+        for (int q = 0; q < 4; q++) d.ticks[16 + q] += S.dk[q + 1] - S.dk[q];
+    }
+#undef DEC_TICK
 }
 
 // ------------------------------------------------------------------ k_decide
@@ -1221,6 +1245,7 @@ __global__ __launch_bounds__(CH_T) void k_decide(Dev d, const Cand* src, int nre
     State* st = d.st;
     if (st->stall || st->la_hit) return;  // (nothing to decide / the tail of k_track has decided this event already)
     state_in(S.lst, st);
+    if (threadIdx.x == 0) S.tkon = 0;
     Cand best = reduce_records(d, src, nrecs, shc);
     __syncthreads();
     decide_step(d, S, L, best);
@@ -1301,7 +1326,13 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     // phase split of the last-arriving workgroup (diagnostic, FNN_TICKS=1): thread 0 stamps the 100 MHz clock
     const bool prof = ticks != 0 && threadIdx.x == 0;
 #define TRK_TICK(slot) do { if (prof) S.tk[(slot) + 1] = (long long)wall_clock64(); } while (0)
+    if (threadIdx.x == 0) S.tkon = ticks;
     if (prof) S.tk[0] = (long long)wall_clock64();
+    // (this thread's first tracked pair is fetched beside the control block: its address depends on nothing)
+    const int64_t start = (int64_t)wg * TRK_THREADS + threadIdx.x;
+    PairRec rec0;
+    rec0.wa = rec0.wb = 0; rec0.sa = rec0.sb = -1;
+    if (start < LA_PCAP) rec0 = track_pair_load(d, start);
     if (st->done) {
         if (wg == 0 && threadIdx.x == 0) st->ev_active = 0;  // (a launch sequence without a decide kernel must not replay the last event)
         return;
@@ -1342,12 +1373,12 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         if ((int)threadIdx.x + 128 < npart) up2 = up[2 * (threadIdx.x + 128)];
     }
     Cand best, bestu;
-    best.q = inf_f64();
-    best.key = ~0ULL;
+    best = cand_none();
     bestu = best;
-    const int64_t stride = (int64_t)G * TRK_THREADS, start = (int64_t)wg * TRK_THREADS + threadIdx.x;
+    const int64_t stride = (int64_t)G * TRK_THREADS;
     TRK_TICK(0);
-    for (int64_t it = start; it < ta.np; it += stride) track_pair_item(d, it, ta, best);
+    if (start < ta.np) track_pair_rec(d, rec0, ta, best);
+    for (int64_t it = start + stride; it < ta.np; it += stride) track_pair_item(d, it, ta, best);
     TRK_TICK(1);
     if (approx) {
         if (threadIdx.x < 64) {
@@ -1380,7 +1411,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         __syncthreads();
         if (w_ == 0) {  // the waves' minima: one more wave reduction (no serial walk through LDS)
             Cand b2, bu2;
-            b2.q = inf_f64(); b2.key = ~0ULL; bu2 = b2;
+            b2 = cand_none(); bu2 = b2;
             if (lane_ < TRK_THREADS / 64) { b2 = sh[lane_]; bu2 = shu[lane_]; }
             best = wave_reduce(b2);
             if (ta.approx) bestu = wave_reduce(bu2);
@@ -1416,18 +1447,21 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     // the records of all workgroups, both sets at once, by the first wave
     if (threadIdx.x < 64) {
         Cand b, bu;
-        b.q = inf_f64();
-        b.key = ~0ULL;
+        b = cand_none();
         bu = b;
         const unsigned badword = __hip_atomic_load(d.ticket + TRK_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = threadIdx.x; i < G; i += 64) {
             Cand c;
             c.q = __builtin_nontemporal_load(&d.recs[i].q);
             c.key = __builtin_nontemporal_load(&d.recs[i].key);
+            c.si = __builtin_nontemporal_load(&d.recs[i].si);
+            c.sj = __builtin_nontemporal_load(&d.recs[i].sj);
             if (cand_better(c, b)) b = c;
             if (ta.approx) {
                 c.q = __builtin_nontemporal_load(&d.recs[TRK_REC_U + i].q);
                 c.key = __builtin_nontemporal_load(&d.recs[TRK_REC_U + i].key);
+                c.si = __builtin_nontemporal_load(&d.recs[TRK_REC_U + i].si);
+                c.sj = __builtin_nontemporal_load(&d.recs[TRK_REC_U + i].sj);
                 if (cand_better(c, bu)) bu = c;
             }
         }
@@ -1467,8 +1501,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
             }
             __syncthreads();
             Cand bx;
-            bx.q = inf_f64();
-            bx.key = ~0ULL;
+            bx = cand_none();
             for (int64_t r = threadIdx.x; r < items - ta.np; r += TRK_THREADS) sweep_exact_item(d, r, ta, bx);
             bx = block_reduce<TRK_THREADS / 64>(bx, sh);
             if (threadIdx.x == 0) sh[0] = bx;
@@ -1478,7 +1511,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         }
         // certain: every swept pair's exact Q lies strictly above best.q, so best wins as it stands
     }
-    if (giveup) { best.q = inf_f64(); best.key = ~0ULL; }
+    if (giveup) { best = cand_none(); }
     if (threadIdx.x == 0) {
         *d.ticket = 0u;
         lst.ev_timed = timed;
@@ -1610,14 +1643,15 @@ __device__ __forceinline__ SpecialOut special_wave(const Dev& d, const State& ls
                     // the aliased entry D[u][v] and the diagonal (NetMakerOriginal.java:653-656, 670)
                     const double dxz = B(iX, iZ), dyx = B(iY, iX), dyz = B(iY, iZ);
                     double uv;
-                    if (flag) uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + dyx / 3.0) + dyz / 3.0;
-                    else uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + dyz / 3.0) + dyx / 3.0;
+                    if (flag) uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + div3(dyx)) + div3(dyz);
+                    else uv = (2.0 / 3.0) * ((2.0 / 3.0) * dxz + div3(dyz)) + div3(dyx);
                     B(iU, iU) = 0.0; B(iV, iV) = 0.0;
                     B(iU, iV) = uv; B(iV, iU) = uv;
                 } else if (me != iY && me != iZ) {
                     const double dx = B(iX, me), dy = B(iY, me), dz = B(iZ, me);
-                    const double nu = (2.0 / 3.0) * dx + dy / 3.0;
-                    const double nv = (2.0 / 3.0) * dz + dy / 3.0;
+                    const double dy3 = div3(dy);
+                    const double nu = (2.0 / 3.0) * dx + dy3;
+                    const double nv = (2.0 / 3.0) * dz + dy3;
                     B(iU, me) = nu; B(me, iU) = nu;
                     B(iV, me) = nv; B(me, iV) = nv;
                 }
@@ -1727,15 +1761,87 @@ __global__ __launch_bounds__(256) void k_update(Dev d, int defer, int ticks) {
         __syncthreads();
         state_out(st, lst);
     } else {
-        double tuv[2];
+        // ONE thread per column (node) - the two columns of a paired cluster sit in adjacent lanes and exchange the two
+        // or four values the cluster distances need by shuffles.  (fnn_core.h: update_bulk is the same computation with
+        // one thread per cluster; the CPU emulation runs that one against the oracle.  A wave runs alone on its SIMD
+        // here and issues one instruction every ~4 cycles, so the length of a thread's instruction stream IS the
+        // kernel's duration: splitting the pair halves it.)
         const PlanView pv = plan_view(lst, UniLane{});
         UPD_TICK(1);
-        const double v = update_bulk(d, pv, blockIdx.x * 256 + threadIdx.x, tuv);
+        const int32_t k = (int32_t)(blockIdx.x * 256 + threadIdx.x);
+        const bool paired = k < 2 * pv.P_old;
+        bool act = k < pv.m_old;
+#pragma unroll
+        for (int i = 0; i < MAX_S; i++) if (i < pv.nS && pv.S[i] == k) act = false;
+        // everything a column reads, in one batch: its entries in the rows of all involved slots, Sx, T, position
+        double e[MAX_S];
+        const double* colp = d.D + k;
+#pragma unroll
+        for (int i = 0; i < MAX_S; i++) e[i] = (act && i < pv.nS) ? colp[(int64_t)pv.S[i] * d.ld] : 0.0;
+        double sx = act ? d.Sx[k] : 0.0;
+        const double t_old = act ? d.T[k] : 0.0;
+        const int32_t pos = act ? d.spos[k] : 0;
+        const bool odd = (k & 1) != 0;
+        double told = 0.0;
+        if (!pv.ev_finish) {
+            // subtractClusterDistance(p, x); subtractClusterDistance(p, y) (:455-461, 681-696)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int32_t it = q == 0 ? pv.ix : pv.iy, itn = q == 0 ? pv.ixn : pv.iyn;
+                const double me0 = it >= 0 ? e[it] : 0.0, mf0 = itn >= 0 ? e[itn] : 0.0;   // this column's entries towards t, t.nbr
+                const double oe = __shfl_xor(me0, 1, 64), of = __shfl_xor(mf0, 1, 64);     // ... and the partner column's
+                const double e0 = odd ? oe : me0, f0 = odd ? of : mf0, e1 = odd ? me0 : oe, f1 = odd ? mf0 : of;
+                double v;
+                if (!paired && itn < 0) { v = me0; told += me0; }
+                else if (paired && itn < 0) { v = (e0 + e1) / 2.0; told += me0; }
+                else if (!paired && itn >= 0) { v = (me0 + mf0) / 2.0; told += 0.5 * (me0 + mf0); }
+                else { v = (((e0 + f0) + e1) + f1) / 4.0; told += 0.5 * (me0 + mf0); }
+                sx -= v;
+            }
+        }
+        // the rows that change, at this column (all values first: a changed row may be the source of another)
+        double nv[MAX_TGT];
+        double um = 0.0, vm = 0.0;
+#pragma unroll
+        for (int t = 0; t < MAX_TGT; t++) {
+            nv[t] = 0.0;
+            if (t < pv.ntgt) {
+                nv[t] = tgt_eval(pv, t, [&](int32_t i) { return e[i]; });
+                if (t == pv.tU) um = nv[t];
+                if (t == pv.tV) vm = nv[t];
+            }
+        }
+        if (act) {
+            const int64_t rk = (int64_t)k * d.ld;
+#pragma unroll
+            for (int t = 0; t < MAX_TGT; t++) {
+                if (t < pv.ntgt) {
+                    // the entry and its mirror; of the two only the one at or below the diagonal has a bf16 copy
+                    const int32_t dst = pv.tdst[t];
+                    const int64_t rb = (int64_t)dst * d.ld;
+                    d.D[rb + k] = nv[t];
+                    d.D[rk + dst] = nv[t];
+                    if (d.H) d.H[k < dst ? rb + k : rk + dst] = bf16_from_double(nv[t]);
+                }
+            }
+        }
+        if (!pv.ev_finish) {
+            // updateClusterDistances, per-node part (:520-531)
+            const double uo = __shfl_xor(um, 1, 64), vo = __shfl_xor(vm, 1, 64);
+            const double u0 = odd ? uo : um, v0 = odd ? vo : vm, u1 = odd ? um : uo, v1 = odd ? vm : vo;
+            const double dpu = paired ? (((u0 + v0) + u1) + v1) / 4.0 : (um + vm) / 2.0;
+            if (act) {
+                const bool rep = !paired || !odd;
+                d.Sx[k] = sx + dpu;
+                d.chain[chain_addr(pos)] = rep ? dpu : 0.0;
+                d.T[k] = (t_old - told) + 0.5 * (um + vm);
+                dsum = rep ? dpu : 0.0;
+                dabs = dsum < 0.0 ? -dsum : dsum;
+                tu = paired ? 0.5 * um : um;
+                tv = paired ? 0.5 * vm : vm;
+            }
+        }
         UPD_TICK(2);
-        dsum = v;
-        dabs = v < 0.0 ? -v : v;
-        tu = tuv[0];
-        tv = tuv[1];
     }
     // per-workgroup partial sums (tree order): of the new cluster's row-sum addends and their magnitudes (for
     // the next event's sweep while the exact sequential sum is on its way) and of T of its two nodes
@@ -2305,6 +2411,12 @@ int32_t fnn_debug_update_ticks(fnn_handle* h, int64_t* out8) {
     FNN_NEED(h);
     if (!out8) return fnn::fail(FNN_EINVAL, "fnn_debug_update_ticks: out8 is NULL");
     if (h->eng.be.d2h(out8, h->eng.dev.ticks + 8, sizeof(int64_t) * 8) != FNN_OK) return FNN_EHIP;
+    return FNN_OK;
+}
+int32_t fnn_debug_decide_ticks(fnn_handle* h, int64_t* out4) {
+    FNN_NEED(h);
+    if (!out4) return fnn::fail(FNN_EINVAL, "fnn_debug_decide_ticks: out4 is NULL");
+    if (h->eng.be.d2h(out4, h->eng.dev.ticks + 16, sizeof(int64_t) * 4) != FNN_OK) return FNN_EHIP;
     return FNN_OK;
 }
 int32_t fnn_set_scan_timing(fnn_handle* h, int32_t enable) {

@@ -177,6 +177,9 @@ int32_t fnn_debug_event_ticks(fnn_handle* h, int64_t* out8);
 /* Diagnostic (FNN_TICKS=1): the same for k_update, summed over all events: thread 0 of the workgroup of the involved
  * slots {control block, block load, phases, tail} and of the first bulk workgroup {control block, -, columns, tail}. */
 int32_t fnn_debug_update_ticks(fnn_handle* h, int64_t* out8);
+/* ... and the decide step inside k_track's tail: {the one round trip of loads, Cx/Cy + certified choice, merge plan,
+ * symbolic replay of the micro-ops}. */
+int32_t fnn_debug_decide_ticks(fnn_handle* h, int64_t* out4);
 
 /* Enable per-launch HIP-event timing of the scan kernel (bench.py's roofline
  * figure).  Adds two event records per scan launch. */

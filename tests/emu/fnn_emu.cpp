@@ -155,8 +155,7 @@ struct EmuBackend {
     fnn::Cand scan_screened(const fnn::Dev& d) {
         fnn::State& st = *d.st;
         fnn::Cand best;
-        best.q = fnn::inf_f64();
-        best.key = ~0ULL;
+        best = fnn::cand_none();
         if (st.done) return best;
         const int32_t m = st.m, twoP = 2 * st.P;
         const float cm2 = (float)((double)st.c - 2.0), cm2k = fnn::screen_cm2k(st);
@@ -222,8 +221,7 @@ struct EmuBackend {
         // k_track: serve the event from the open lookahead window if it can certify the minimum
         if (!sched && fnn::la_active(st)) {
             fnn::Cand tb;
-            tb.q = fnn::inf_f64();
-            tb.key = ~0ULL;
+            tb = fnn::cand_none();
             const fnn::TrackArgs ta = fnn::track_args(st);
             for (int32_t it : thread_order((int32_t)fnn::track_item_count(ta))) fnn::track_item(d, it, ta, tb);
             fnn::la_track_done(d, tb, ta);
@@ -234,8 +232,7 @@ struct EmuBackend {
         }
         if (d.H && st.m >= screen_min_m) return scan_screened(d);
         fnn::Cand best;
-        best.q = fnn::inf_f64();
-        best.key = ~0ULL;
+        best = fnn::cand_none();
         if (!st.done) {
             int32_t m = st.m, twoP = 2 * st.P;
             double cm2 = (double)st.c - 2.0;
@@ -271,8 +268,7 @@ struct EmuBackend {
         if (st.stall) { st.n_stalled++; return FNN_OK; }
         if (fnn::la_active(st)) {
             fnn::Cand tb;
-            tb.q = fnn::inf_f64();
-            tb.key = ~0ULL;
+            tb = fnn::cand_none();
             const fnn::TrackArgs ta = fnn::track_args(st);
             for (int32_t it : thread_order((int32_t)fnn::track_item_count(ta))) fnn::track_item(d, it, ta, tb);
             fnn::la_track_done(d, tb, ta);
@@ -288,8 +284,7 @@ struct EmuBackend {
     int32_t launch_event_scan(const fnn::Dev& d, int32_t, int32_t* nper) {
         // contribute 3 records (the real one plus two "none") to exercise the multi-record exchange
         fnn::Cand none;
-        none.q = fnn::inf_f64();
-        none.key = ~0ULL;
+        none = fnn::cand_none();
         d.gsend[0] = none; d.gsend[1] = scan_local(d); d.gsend[2] = none;
         *nper = 3;
         return FNN_OK;
@@ -297,8 +292,7 @@ struct EmuBackend {
     int32_t allgather_on_stream(const fnn::Dev&, int32_t) { return FNN_ERCCL; }  // no RCCL in the emulation
     int32_t launch_event_rest(const fnn::Dev& d, int32_t m_bound, int32_t ntotal) {
         fnn::Cand best;
-        best.q = fnn::inf_f64();
-        best.key = ~0ULL;
+        best = fnn::cand_none();
         for (int32_t r = 0; r < ntotal; r++)
             if (fnn::cand_better(d.grecv[r], best)) best = d.grecv[r];
         return event_rest(d, m_bound, best);
@@ -386,7 +380,7 @@ struct EmuBackend {
                     for (int32_t i : thread_order(fnn::MAX_S)) { fnn::update_special_acc(A, d, ph, i, tuv); tub += tuv[0]; tvb += tuv[1]; }
             }
             const fnn::PlanView pv = fnn::plan_view(st, fnn::UniId{});
-            auto bulk1 = [&](int32_t k) { fnn::update_bulk(d, pv, k, tuv); tu += tuv[0]; tv += tuv[1]; };
+            auto bulk1 = [&](int32_t k) { fnn::update_bulk_mem(d, pv, k, tuv); tu += tuv[0]; tv += tuv[1]; };
             auto bulk = [&]() { for (int32_t k : thread_order(m_bound)) bulk1(k); };
             auto special = [&](int32_t ph) { for (int32_t i : thread_order(fnn::MAX_S)) { fnn::update_special(d, ph, i, tuv); tu += tuv[0]; tv += tuv[1]; } };
             if (g_update_mode == 0) { bulk(); for (int32_t ph = 0; ph < nph; ph++) special(ph); }

@@ -20,6 +20,11 @@ for n in sizes:
         if st.n_window_hits:
             print("k_track us/window event (last workgroup, thread 0): " + " ".join(f"{nm}={tk[i] / 100.0 / st.n_window_hits:.2f}" for i, nm in
                   enumerate(["prologue", "pairs", "sweep", "reduce", "arrive", "records", "verdict", "tail"])), flush=True)
+        a._fn("debug_decide_ticks", C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)])
+        a.debug_decide_ticks(h._h, tk)
+        if st.n_window_hits:
+            print("  decide step in the tail: " + " ".join(f"{nm}={tk[i] / 100.0 / st.n_window_hits:.2f}" for i, nm in
+                  enumerate(["loads", "pick+choice", "plan", "replay"])), flush=True)
         a._fn("debug_update_ticks", C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)])
         a.debug_update_ticks(h._h, tk)
         if tk[0] or tk[4]:
