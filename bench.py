@@ -8,15 +8,16 @@ resident in HBM when the step starts.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--taxa 32768] [--seed 1]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU).  With the
-lookahead windows a run streams the matrix only ~500 times instead of 32767 times; what is left
-is a chain of ~32767 latency-bound events that does not shard (a per-event exchange over xGMI
-costs more than the amortised scan it would split, DESIGN.md "Multi-GPU").  So N > 1 runs N
-independent replicas (rank r orders the matrix of seed + r): weak scaling, `value` = the slowest
-replica's seconds per order.  FNN_BENCH_SHARD=1 selects the sharded-scan engine instead (every
-event scans 1/N of the tiles on each rank, one all-gather per event with RCCL on the engine's
-stream; lookahead windows off): ONE problem instance, strong scaling; if its RCCL communicator
-cannot be created the ranks agree to let rank 0 compute alone (reported in config.parallelism).
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU) and orders the SAME
+matrix on all N GPUs (BASELINE.json's metric: one problem, strong scaling): every rank holds the matrix
+(8 GiB of 288) and runs the whole event chain; only the ~860 base scans of the lookahead windows - the
+part of the run that still streams the matrix, 0.19 s of it - are sharded (tile index mod N), each followed
+by ONE RCCL all-gather on the engine's stream (candidate records + the pairs every rank emitted for the
+new window).  The other ~31 900 events are a chain of latency-bound steps that no exchange can shorten
+(DESIGN.md "Multi-GPU"), so the curve is Amdahl-flat by construction.  If the RCCL communicator cannot be
+created the ranks agree to let rank 0 compute alone (reported in config.parallelism).
+FNN_BENCH_REPLICAS=1 instead runs N independent orders (seed + rank), one per GPU: that is NOT the
+BASELINE metric (it is reported under its own metric name, orders per second).
 
 Prints ONE JSON line on rank 0.
 """
@@ -108,11 +109,11 @@ def main():
     h = None
     parallelism = "single GPU"
     sharded = False
-    shard_mode = os.environ.get("FNN_BENCH_SHARD") == "1"
-    replicas = world > 1 and not shard_mode
+    replicas = world > 1 and os.environ.get("FNN_BENCH_REPLICAS") == "1"
+    shard_mode = world > 1 and not replicas
     if replicas:
-        parallelism = (f"replicas only: {world} independent orders (seed + rank), one per GPU, no data-path "
-                       f"collective; value = the slowest replica")
+        parallelism = (f"REPLICAS (not the BASELINE metric): {world} independent orders (seed + rank), one per GPU, "
+                       f"no data-path collective")
     if world > 1 and shard_mode:
         ok, why = 1, ""
         try:
@@ -127,8 +128,9 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         sharded = int(flag.item()) == 1
         if sharded:
-            parallelism = (f"scan sharded over {world} ranks (tile index mod {world}), matrix replicated, one <=1 KiB "
-                           f"all-gather per event ({'gloo host callback' if same_gpu else 'RCCL on stream'})")
+            parallelism = (f"one problem on {world} ranks: matrix and event chain replicated, the base scans of the lookahead "
+                           f"windows sharded (tile index mod {world}) with one all-gather each "
+                           f"({'gloo host callback' if same_gpu else 'RCCL on the engine stream'}): candidate records + emitted pairs")
         else:
             if h is not None:
                 h.close()

@@ -201,10 +201,13 @@ struct Dev {
                      // addends (for the sweep beside the exact chain), and the partial sums of T of its two nodes
     double* lalog;   // lookahead diagnostics: per base scan {event, m, W, pairs, events served by the previous window} (LA_LOGCAP records)
     Cand* gsend;     // multi-GPU: this rank's candidate record(s) of the event (<= GATHER_RECS)
+    uint8_t* wsend;  // multi-GPU with lookahead windows: this rank's exchange block of a base scan (wx_block_bytes)
+    uint8_t* wrecv;  // ... and all ranks' blocks after the all-gather
     Cand* grecv;     // multi-GPU: all ranks' candidate records
     int32_t la;      // lookahead windows enabled for this run (k_track is part of the launch sequence)
     int32_t rank, world;  // scan sharding: rank scans the tiles with index = rank (mod world)
     int32_t gather;       // non-zero: candidate records are exchanged between ranks (go to gsend)
+    int32_t wx;           // non-zero: several ranks WITH lookahead windows - only the base scans are sharded and exchanged
     State* st;
     Event* evlog;    // n records (if record_events)
     Agg3Rec* agglog; // n records
@@ -519,6 +522,17 @@ constexpr int LA_KMAX = 512;      // fresh clusters per window (>= K)
 constexpr int LA_PCAP = 65536;    // tracked pairs per window
 constexpr int LA_LOGCAP = 8192;   // diagnostic records (one per base scan)
 
+// Several ranks with lookahead windows: the matrix and the whole event chain are replicated; only a BASE SCAN is
+// sharded (tile index mod world: screening pass, emission, exact rescans) and followed by ONE exchange.  A rank's
+// exchange block: header {pairs emitted, rescan_all, candidate units, -}, its GATHER_RECS candidate records of the
+// exact rescans, and the pairs it emitted (tracked-pair records, fnn_core.h: la_record); every rank then builds
+// the same tracked list (rank 0's pairs, rank 1's, ...) and reduces the same candidate records.
+constexpr int WX_HDR_WORDS = 4;
+FNN_HD int32_t wx_pair_cap(int32_t world) { return LA_PCAP / (world > 0 ? world : 1); }
+FNN_HD int64_t wx_recs_off() { return (int64_t)sizeof(int32_t) * WX_HDR_WORDS; }
+FNN_HD int64_t wx_pairs_off() { return wx_recs_off() + (int64_t)sizeof(Cand) * GATHER_RECS; }
+FNN_HD int64_t wx_block_bytes(int32_t world) { return wx_pairs_off() + 16 * (int64_t)wx_pair_cap(world); }
+
 // slack between the fp32 lower bound and the true fp64 Q over the window: the screening slack
 // (screen_delta, applied twice for good measure) plus the rounding drift of the row sums
 // (3 roundings of a value <= n Dmax per event, each <= 2^-53 relative)
@@ -614,6 +628,47 @@ FNN_HD void la_append(const Dev& d, int32_t rs, int32_t cs, int32_t twoP) {
     State& st = *d.st;
     const int32_t i = FNN_ATOMIC_INC(d.lacnt);
     if (i < st.la_pcap) la_record(d, d.tpairs + 4 * (int64_t)i, rs, cs, twoP);
+}
+
+// After the exchange of a sharded base scan: the tracked list from all ranks' emitted pairs, all ranks' candidate
+// records into d.grecv, and the close of the base scan (serial form: CPU emulation; the GPU's k_merge is the same,
+// spread over a workgroup).  A rank that found more pairs than its share of the list holds, or a total beyond the
+// list's capacity, counts as an overflow: the window is not opened (la_close_base), nothing else changes.
+FNN_HD void wx_merge(const Dev& d) {
+    State& st = *d.st;
+    if (st.la_hit) return;
+    const int32_t capr = wx_pair_cap(d.world);
+    const int64_t bb = wx_block_bytes(d.world);
+    bool overflow = false;
+    int64_t total = 0, units = 0;
+    for (int32_t r = 0; r < d.world; r++) {
+        const int32_t* h = reinterpret_cast<const int32_t*>(d.wrecv + r * bb);
+        if (h[0] > capr) overflow = true;
+        total += h[0] < capr ? h[0] : capr;
+        units += h[2];
+    }
+    if (total > st.la_pcap) overflow = true;
+    if (st.la_emit && !overflow) {
+        int64_t off = 0;
+        for (int32_t r = 0; r < d.world; r++) {
+            const int32_t* h = reinterpret_cast<const int32_t*>(d.wrecv + r * bb);
+            const int32_t* src = reinterpret_cast<const int32_t*>(d.wrecv + r * bb + wx_pairs_off());
+            for (int64_t i = 0; i < 4 * (int64_t)h[0]; i++) d.tpairs[4 * off + i] = src[i];
+            off += h[0];
+        }
+    }
+    *d.lacnt = overflow ? st.la_pcap + 1 : (int32_t)total;
+    for (int32_t r = 0; r < d.world; r++) {
+        const Cand* src = reinterpret_cast<const Cand*>(d.wrecv + r * bb + wx_recs_off());
+        for (int j = 0; j < GATHER_RECS; j++) d.grecv[r * GATHER_RECS + j] = src[j];
+    }
+    const int32_t* mine = reinterpret_cast<const int32_t*>(d.wrecv + d.rank * bb);
+    st.rescan_all = mine[1];
+    st.ncand = mine[1] ? 0 : mine[2];
+    st.n_screen_events += 1;
+    st.n_rescan_units += units;
+    st.ev_screened = 1;
+    la_close_base(st, d.lalog, d.lacnt);
 }
 
 // a new two-node cluster with representative id `rep` exists from the next event on

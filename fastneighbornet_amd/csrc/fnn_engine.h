@@ -119,7 +119,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.recs); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.ticks); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.recs); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.wsend); be.free(dev.wrecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.ticks); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }
@@ -221,11 +221,13 @@ class Engine {
             if (K > LA_KMAX) K = LA_KMAX;
             if (target < 1) target = 1;
             if (target > LA_PCAP) target = LA_PCAP;
-            hst.la_on = (dev.H && K > 0 && world == 1 && comm_mode == 0) ? 1 : 0;
+            // (several ranks: windows stay on - only the base scans are sharded and exchanged, see enqueue_event)
+            hst.la_on = (dev.H && K > 0) ? 1 : 0;
             hst.la_K = K > 0 ? K : 0;
             hst.la_target = target;
             hst.la_min_m = be.screen_min_m;
             dev.la = hst.la_on;
+            dev.wx = (comm_mode != 0 && hst.la_on) ? 1 : 0;
             ev_counter = 0;
             sched_at = 0;
             hst.la_pcap = LA_PCAP;
@@ -263,6 +265,13 @@ class Engine {
         dev.world = world_;
         dev.rank = rank_;
         dev.gather = comm_mode != 0 ? 1 : 0;
+        be.free(dev.wsend); be.free(dev.wrecv);
+        dev.wsend = dev.wrecv = nullptr;
+        if (comm_mode != 0) {
+            const size_t bb = (size_t)wx_block_bytes(world_);
+            if (!(dev.wsend = (uint8_t*)be.alloc(bb)) || !(dev.wrecv = (uint8_t*)be.alloc(bb * (size_t)world_)))
+                return fail(FNN_ENOMEM, "fnn_comm_init: device allocation failed (" + be.err() + ")");
+        }
         return FNN_OK;
     }
 
@@ -284,6 +293,33 @@ class Engine {
         if (force_sched >= 0) sched = force_sched != 0;
         if (sched) sched_at = cnt + (hst.la_Kcur > 0 ? hst.la_Kcur : hst.la_K) + 1;
         if (comm_mode == 0) return be.launch_event(dev, m_bound, sched) == FNN_OK ? FNN_OK : fail(FNN_EHIP, "launch failed (" + be.err() + ")");
+        if (dev.wx) {
+            // Several ranks with lookahead windows.  Every rank holds the whole matrix and runs the whole event chain
+            // itself; the ranks stay in step because every decision is a deterministic function of identical state.
+            // Only a BASE SCAN of the screened regime is shared out (tiles by index mod world) and followed by ONE
+            // exchange: candidate records of the exact rescans + the pairs each rank emitted for the new window.
+            Dev solo = dev;
+            solo.world = 1; solo.rank = 0; solo.gather = 0; solo.wx = 0;
+            if (!sched || !be.use_screen(dev, m_bound))  // a window event, or the end game's small plain scans: no exchange
+                return be.launch_event(solo, m_bound, sched) == FNN_OK ? FNN_OK : fail(FNN_EHIP, "launch failed (" + be.err() + ")");
+            if (be.launch_wx_scan(dev, m_bound) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
+            const size_t bb = (size_t)wx_block_bytes(world);
+            if (comm_mode == 1) {
+                if (be.allgather_wx_on_stream(dev, bb) != FNN_OK) return fail(FNN_ERCCL, "all-gather failed (" + be.err() + ")");
+            } else {
+                std::vector<uint8_t> mine(bb), all(bb * (size_t)world);
+                if (be.sync() != FNN_OK || be.d2h(mine.data(), dev.wsend, bb) != FNN_OK)
+                    return fail(FNN_EHIP, "exchange block download failed (" + be.err() + ")");
+                if (!host_fn || host_fn(host_ctx, mine.data(), all.data(), (int32_t)bb) != 0)
+                    return fail(FNN_ERCCL, "host all-gather callback failed");
+                if (be.h2d(dev.wrecv, all.data(), all.size()) != FNN_OK)
+                    return fail(FNN_EHIP, "exchange block upload failed (" + be.err() + ")");
+            }
+            if (be.launch_wx_rest(dev, m_bound) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
+            return FNN_OK;
+        }
+        // Several ranks without windows (no screening copy: small problems, or lookahead off): every event scans
+        // 1/world of the tiles on each rank and exchanges the candidate records
         int32_t nper = 1;
         if (be.launch_event_scan(dev, m_bound, &nper) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
         if (comm_mode == 1) {

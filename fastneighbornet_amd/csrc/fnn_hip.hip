@@ -319,7 +319,9 @@ __global__ __launch_bounds__(256) void k_emit(Dev d) {
     __shared__ int2 lbuf[EMIT_LDS];
     State* st = d.st;
     if (st->done || st->la_hit || !st->la_emit) return;
-    const int m = st->m, twoP = 2 * st->P, pcap = st->la_pcap;
+    // (several ranks: a rank walks the units of its own tiles and collects its pairs in its exchange block)
+    const int m = st->m, twoP = 2 * st->P, pcap = d.wx ? wx_pair_cap(d.world) : st->la_pcap;
+    int32_t* const outp = d.wx ? reinterpret_cast<int32_t*>(d.wsend + wx_pairs_off()) : d.tpairs;
     const float k1 = screen_k1(*st), k2 = screen_k2(*st), tp = st->la_theta_pred;
     const int nunits = 4 * tri_tile_count(m, SCR_TH, SCR_R);
     const int lane = threadIdx.x & 63;
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256) void k_emit(Dev d) {
     for (int ub = wave * per; ub < nunits; ub += nwaves * per) {
         const int myu = ub + lane;
         unsigned long long mymask = 0;
-        if (lane < per && myu < nunits && d.srec[myu] <= tp) mymask = d.shit[myu];
+        if (lane < per && myu < nunits && (myu >> 2) % d.world == d.rank && d.srec[myu] <= tp) mymask = d.shit[myu];
         int incl = __builtin_popcountll(mymask);
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) void k_emit(Dev d) {
         const int idx = base + i;
         if (idx < pcap) {
             const int2 pr = lbuf[i];
-            la_record(d, d.tpairs + 4 * (int64_t)idx, pr.x, pr.y, twoP);
+            la_record(d, outp + 4 * (int64_t)idx, pr.x, pr.y, twoP);
         }
     }
 }
@@ -577,7 +579,10 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d) {
     best = cand_none();
     if (st->la_hit) return;  // the lookahead window already holds this event's minimum (recs[0])
     if (st->done) {  // nothing to scan: leave "no candidate" records
-        if (tid == 0) (d.gather ? d.gsend : d.recs)[blockIdx.x] = best;
+        if (tid == 0) {
+            (d.wx ? reinterpret_cast<Cand*>(d.wsend + wx_recs_off()) : d.gather ? d.gsend : d.recs)[blockIdx.x] = best;
+            if (d.wx && blockIdx.x == 0) { int32_t* h = reinterpret_cast<int32_t*>(d.wsend); h[0] = 0; h[1] = 0; h[2] = 0; h[3] = 0; }
+        }
         return;
     }
     const int m = st->m;
@@ -633,8 +638,16 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d) {
     }
     best = block_reduce<16>(best, shc);
     if (tid == 0) {
-        (d.gather ? d.gsend : d.recs)[blockIdx.x] = best;  // several GPUs: these records are all-gathered
-        if (blockIdx.x == 0) {
+        (d.wx ? reinterpret_cast<Cand*>(d.wsend + wx_recs_off()) : d.gather ? d.gsend : d.recs)[blockIdx.x] = best;  // several GPUs: these records are all-gathered
+        if (blockIdx.x == 0 && d.wx) {
+            // several ranks with windows: the base scan is closed after the exchange (k_merge); the header tells the
+            // others how many pairs this rank emitted (k_emit has run) and how many units it rescanned
+            int32_t* h = reinterpret_cast<int32_t*>(d.wsend);
+            h[0] = st->la_emit ? *d.lacnt : 0;
+            h[1] = all ? 1 : 0;
+            h[2] = all ? (4 * ntiles) / d.world : count;
+            h[3] = 0;
+        } else if (blockIdx.x == 0) {
             st->rescan_all = all ? 1 : 0;
             st->ncand = all ? 0 : count;
             st->n_screen_events += 1;
@@ -642,6 +655,58 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d) {
             st->ev_screened = 1;
             la_close_base(*st, d.lalog, d.lacnt);  // (the screening pass may have emitted the pairs of a new lookahead window)
         }
+    }
+}
+
+// After the exchange of a sharded base scan (several ranks with lookahead windows; fnn_core.h: wx_merge is the serial
+// form): every rank builds the same tracked list from all ranks' emitted pairs, copies all ranks' candidate records
+// into d.grecv for k_decide, and closes the base scan.
+__global__ __launch_bounds__(1024) void k_merge(Dev d) {
+    __shared__ int32_t cnt[64], off[65];
+    __shared__ int32_t ovf;
+    State* st = d.st;
+    if (st->la_hit) return;
+    const int tid = threadIdx.x;
+    const int32_t capr = wx_pair_cap(d.world);
+    const int64_t bb = wx_block_bytes(d.world);
+    if (tid < d.world) cnt[tid] = reinterpret_cast<const int32_t*>(d.wrecv + tid * bb)[0];
+    __syncthreads();
+    if (tid == 0) {
+        int64_t total = 0;
+        int o = 0;
+        for (int r = 0; r < d.world; r++) {
+            if (cnt[r] > capr) o = 1;
+            off[r] = (int32_t)total;
+            total += cnt[r] < capr ? cnt[r] : capr;
+        }
+        off[d.world] = (int32_t)total;
+        if (total > st->la_pcap) o = 1;
+        ovf = o;
+    }
+    __syncthreads();
+    if (st->la_emit && !ovf) {
+        for (int r = 0; r < d.world; r++) {
+            const int4* src = reinterpret_cast<const int4*>(d.wrecv + r * bb + wx_pairs_off());
+            int4* dst = reinterpret_cast<int4*>(d.tpairs) + off[r];
+            for (int i = tid; i < cnt[r]; i += 1024) dst[i] = src[i];
+        }
+    }
+    for (int i = tid; i < d.world * GATHER_RECS; i += 1024) {
+        const int r = i / GATHER_RECS, j = i % GATHER_RECS;
+        d.grecv[i] = reinterpret_cast<const Cand*>(d.wrecv + r * bb + wx_recs_off())[j];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int64_t units = 0;
+        for (int r = 0; r < d.world; r++) units += reinterpret_cast<const int32_t*>(d.wrecv + r * bb)[2];
+        const int32_t* mine = reinterpret_cast<const int32_t*>(d.wrecv + d.rank * bb);
+        *d.lacnt = ovf ? st->la_pcap + 1 : off[d.world];
+        st->rescan_all = mine[1];
+        st->ncand = mine[1] ? 0 : mine[2];
+        st->n_screen_events += 1;
+        st->n_rescan_units += units;
+        st->ev_screened = 1;
+        la_close_base(*st, d.lalog, d.lacnt);
     }
 }
 
@@ -2275,6 +2340,24 @@ struct HipBackend {
             hipLaunchKernelGGL(k_reduce_local, dim3(1), dim3(1024), 0, stream, d, nrecs);
             *nper = 1;
         }
+        return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
+    }
+    // several ranks with lookahead windows: a base scan's sharded part ... (exchange) ... merge + the rest
+    int32_t launch_wx_scan(const Dev& d, int32_t m_bound) {
+        if (m_bound < 1) m_bound = 1;
+        (void)enqueue_scan(d, m_bound, true);
+        return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
+    }
+    int32_t allgather_wx_on_stream(const Dev& d, size_t bytes) {
+        if (!rccl_comm) { comm_err = "RCCL communicator not initialised"; return FNN_ERCCL; }
+        int rc = p_ncclAllGather(d.wsend, d.wrecv, bytes, /*ncclInt8*/ 0, rccl_comm, stream);
+        if (rc != 0) { comm_err = std::string("ncclAllGather: ") + (p_ncclGetErrorString ? p_ncclGetErrorString(rc) : "error"); return FNN_ERCCL; }
+        return FNN_OK;
+    }
+    int32_t launch_wx_rest(const Dev& d, int32_t m_bound) {
+        if (m_bound < 1) m_bound = 1;
+        hipLaunchKernelGGL(k_merge, dim3(1), dim3(1024), 0, stream, d);
+        enqueue_rest(d, m_bound, (const Cand*)d.grecv, d.world * GATHER_RECS);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
     int32_t launch_event_rest(const Dev& d, int32_t m_bound, int32_t ntotal) {

@@ -1,7 +1,11 @@
 """Several GPUs of one node, one process per GPU (torch.distributed for the bootstrap only).
 
-Every rank keeps the whole matrix and scans 1/world of each event's tiles; one 16-byte record
-per rank is all-gathered per event (RCCL on the engine's stream).  See include/fastnn.h.
+ONE problem on all ranks: every rank keeps the whole matrix and runs the whole event chain (the ranks stay in step
+because every decision is a deterministic function of identical state).  With lookahead windows - the shipped mode
+from 4096 taxa on - only the base scans are sharded (tile index mod world) and each is followed by ONE all-gather
+(RCCL on the engine's stream): per rank 64 candidate records of 24 bytes plus the tracked-pair records it emitted,
+a fixed block of 16 + 1536 + 16 * 65536 / world bytes.  Without windows every event's scan is sharded and exchanges
+at most 64 candidate records per rank.  See include/fastnn.h.
 """
 from __future__ import annotations
 
@@ -29,7 +33,12 @@ def rccl_path() -> str | None:
 
 
 def init_rccl(handle, dist, device) -> None:
-    """Collective over the default process group: rank 0 creates the RCCL id, everybody joins."""
+    """Collective over the default process group: rank 0 creates the RCCL id, everybody joins.
+
+    Symmetric by construction: every rank performs the same collectives in the same order whatever fails
+    where - (1) broadcast of {status, id} from rank 0, (2) all-reduce of "my library loaded and has the
+    symbols", and only if every rank is fine (3) ncclCommInitRank - so a failure on one rank surfaces as
+    an exception on ALL ranks instead of a hang."""
     import ctypes as C
 
     import torch
@@ -39,11 +48,27 @@ def init_rccl(handle, dist, device) -> None:
     world, rank = dist.get_world_size(), dist.get_rank()
     path = rccl_path()
     buf = (C.c_uint8 * 128)()
+    status, why = 1, ""
     if rank == 0:
-        a.check(a.comm_unique_id(buf, path.encode() if path else None))
-    t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=device)
+        try:
+            a.check(a.comm_unique_id(buf, path.encode() if path else None))
+        except Exception as e:  # noqa: BLE001 - reported through the broadcast below
+            status, why = 0, str(e)
+    t = torch.tensor([status] + list(bytes(buf)), dtype=torch.uint8, device=device)
     dist.broadcast(t, src=0)
-    handle.comm_init_rccl(world, rank, bytes(t.cpu().tolist()), path)
+    host = t.cpu().tolist()
+    ok_local = 1 if host[0] == 1 else 0
+    if ok_local:
+        try:  # can this rank load librccl at all?  (dlopen + symbol check, no communicator yet)
+            probe = (C.c_uint8 * 128)()
+            a.check(a.comm_unique_id(probe, path.encode() if path else None))
+        except Exception as e:  # noqa: BLE001
+            ok_local, why = 0, str(e)
+    flag = torch.tensor([ok_local], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        raise RuntimeError(f"RCCL bootstrap failed on at least one rank ({why or 'on another rank'})")
+    handle.comm_init_rccl(world, rank, bytes(host[1:]), path)
 
 
 def init_gloo(handle, dist) -> None:

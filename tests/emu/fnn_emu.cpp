@@ -165,8 +165,12 @@ struct EmuBackend {
         const float finf = (float)fnn::inf_f64();
         float* lbrec = d.srec;
         float* ubrec = d.srec + nunits;
+        // (several ranks with windows: a rank's pairs go to its exchange block, capped at its share of the list)
         auto emit = [&](int32_t rs, int32_t cs, float lb) {
-            if (st.la_emit && lb <= st.la_theta_pred) fnn::la_append(d, rs, cs, twoP);
+            if (!(st.la_emit && lb <= st.la_theta_pred)) return;
+            if (!d.wx) { fnn::la_append(d, rs, cs, twoP); return; }
+            const int32_t i = (*d.lacnt)++;
+            if (i < fnn::wx_pair_cap(d.world)) fnn::la_record(d, reinterpret_cast<int32_t*>(d.wsend + fnn::wx_pairs_off()) + 4 * (int64_t)i, rs, cs, twoP);
         };
         for (int32_t u : thread_order(nunits)) {
             fnn::Brk b{finf, finf};
@@ -192,7 +196,7 @@ struct EmuBackend {
         }
     // k_resolve: smallest upper bound, then the units whose lower bound does not exceed it
         float ubg = finf;
-        for (int32_t u = 0; u < nunits; u++) ubg = fnn::fminf_(ubg, ubrec[u]);
+        for (int32_t u = 0; u < nunits; u++) ubg = fnn::fminf_(ubg, ubrec[u]);  // (units of other ranks' tiles hold +inf)
         const float thr = ubg + 2.0f * fnn::screen_delta(st);
         st.ncand = 0;
         st.rescan_all = (!st.screen_ok || !(thr == thr) || g_force_rescan_all) ? 1 : 0;
@@ -202,14 +206,24 @@ struct EmuBackend {
                     if (st.ncand >= g_cand_cap) { st.rescan_all = 1; break; }
                     d.clist[st.ncand++] = u;
                 }
-        st.n_screen_events++;
-        st.ev_screened = 1;
+        int64_t rescanned = 0;
         if (st.rescan_all) {
             for (int32_t u : thread_order(nunits))
-                if ((u / 4) % d.world == d.rank) { rescan_unit(d, u, best); st.n_rescan_units++; }
+                if ((u / 4) % d.world == d.rank) { rescan_unit(d, u, best); rescanned++; }
         } else {
-            for (int32_t i : thread_order(st.ncand)) { rescan_unit(d, d.clist[i], best); st.n_rescan_units++; }
+            for (int32_t i : thread_order(st.ncand)) { rescan_unit(d, d.clist[i], best); rescanned++; }
         }
+        if (d.wx) {  // the base scan is closed after the exchange (wx_merge)
+            int32_t* h = reinterpret_cast<int32_t*>(d.wsend);
+            h[0] = st.la_emit ? *d.lacnt : 0; h[1] = st.rescan_all; h[2] = (int32_t)rescanned; h[3] = 0;
+            fnn::Cand* recs = reinterpret_cast<fnn::Cand*>(d.wsend + fnn::wx_recs_off());
+            for (int j = 0; j < fnn::GATHER_RECS; j++) recs[j] = fnn::cand_none();
+            recs[(d.rank * 7 + 3) % fnn::GATHER_RECS] = best;  // (any of the records may carry it)
+            return best;
+        }
+        st.n_screen_events++;
+        st.ev_screened = 1;
+        st.n_rescan_units += rescanned;
         fnn::la_close_base(st, d.lalog, d.lacnt);
         return best;
     }
@@ -290,6 +304,25 @@ struct EmuBackend {
         return FNN_OK;
     }
     int32_t allgather_on_stream(const fnn::Dev&, int32_t) { return FNN_ERCCL; }  // no RCCL in the emulation
+    int32_t allgather_wx_on_stream(const fnn::Dev&, size_t) { return FNN_ERCCL; }
+    bool use_screen(const fnn::Dev& d, int32_t m_bound) const { return d.H != nullptr && m_bound >= screen_min_m; }
+    // several ranks with lookahead windows: the sharded part of a base scan ... (exchange) ... merge + the rest
+    int32_t launch_wx_scan(const fnn::Dev& d, int32_t) {
+        fnn::State& st = *d.st;
+        if (!st.done) st.stall = 0;
+        st.ev_timed = 1;
+        if (st.la_valid) st.la_prev_end = 0;
+        fnn::la_prepare_base(st, d.lacnt);
+        (void)scan_screened(d);
+        return FNN_OK;
+    }
+    int32_t launch_wx_rest(const fnn::Dev& d, int32_t m_bound) {
+        fnn::wx_merge(d);
+        fnn::Cand best = fnn::cand_none();
+        for (int32_t r = 0; r < d.world * fnn::GATHER_RECS; r++)
+            if (fnn::cand_better(d.grecv[r], best)) best = d.grecv[r];
+        return event_rest(d, m_bound, best);
+    }
     int32_t launch_event_rest(const fnn::Dev& d, int32_t m_bound, int32_t ntotal) {
         fnn::Cand best;
         best = fnn::cand_none();

@@ -33,7 +33,8 @@ def main():
         order, st = h.run()
         ev = h.events()
     json.dump({"order": order.tolist(), "n_events": int(st.n_events), "sum_entries": int(st.sum_entries),
-               "kinds": ev["kind"].tolist(), "x": ev["x_id"].tolist(), "y": ev["y_id"].tolist()},
+               "kinds": ev["kind"].tolist(), "x": ev["x_id"].tolist(), "y": ev["y_id"].tolist(),
+               "window_hits": int(st.n_window_hits), "base_scans": int(st.n_base_scans)},
               open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
     dist.barrier()
     dist.destroy_process_group()

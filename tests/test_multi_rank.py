@@ -1,7 +1,9 @@
-"""The N > 1 path: several ranks, scan sharded over the ranks, one all-gathered candidate per
-event.  On CPU (gloo, world_size 2 and 3) through the emulation; on the GPU box with every rank
-on the one GPU (host-callback transport; RCCL itself needs distinct GPUs and is exercised by
-the driver's multi-GPU bench)."""
+"""The N > 1 path: ONE problem on several ranks.  Every rank holds the matrix and runs the whole event chain;
+with lookahead windows (the shipped mode) only the base scans are sharded over the ranks (tile index mod world)
+and followed by one exchange - candidate records + the pairs each rank emitted for the new window; without
+windows every event's scan is sharded and exchanges its candidate records.  On CPU (gloo, world_size 2 and 3)
+through the emulation; on the GPU box with every rank on the one GPU (host-callback transport; RCCL itself needs
+distinct GPUs and is exercised by the driver's multi-GPU bench)."""
 import json
 import os
 import subprocess
@@ -44,18 +46,30 @@ def check(res, oracle, n, seed, dist_name):
         assert r["x"] == ev_ref["x_id"].tolist() and r["y"] == ev_ref["y_id"].tolist()
 
 
-@pytest.mark.parametrize("world,n,seed,dist_name", [(2, 70, 1, "uniform53"), (2, 45, 2, "dec4"), (3, 64, 3, "uniform53")])
+@pytest.mark.parametrize("world,n,seed,dist_name", [(2, 70, 1, "uniform53"), (2, 45, 2, "dec4"), (3, 64, 3, "uniform53"),
+                                                    (2, 300, 4, "uniform53"), (3, 257, 5, "dec4")])
 def test_emulation_over_gloo(emu_api, oracle, tmp_path, world, n, seed, dist_name):
+    """Windows on (the emulation screens from 8 taxa on): sharded base scans, one exchange per base scan."""
     res = run_ranks("emu", world, n, seed, dist_name, tmp_path, 29511 + world + n)
     check(res, oracle, n, seed, dist_name)
+    assert all(r["window_hits"] > 0 and r["base_scans"] > 0 for r in res), [(r["window_hits"], r["base_scans"]) for r in res]
+    assert len({(r["window_hits"], r["base_scans"]) for r in res}) == 1  # the ranks stay in step
+
+
+@pytest.mark.parametrize("world,n,seed,env", [(2, 90, 6, {"FNN_LA_K": "-1"}),          # no windows: every event's scan sharded
+                                              (3, 120, 7, {"FNN_LA_PCAP": "40"}),       # tracked list overflows after the merge
+                                              (2, 150, 8, {"FNN_LA_K": "3", "FNN_LA_TARGET": "8"})])
+def test_emulation_over_gloo_modes(emu_api, oracle, tmp_path, world, n, seed, env):
+    res = run_ranks("emu", world, n, seed, "uniform53", tmp_path, 29711 + world + n, env)
+    check(res, oracle, n, seed, "uniform53")
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,n,seed,dist_name,screen", [(2, 600, 1, "uniform53", False), (3, 300, 2, "dec4", False),
                                                         (2, 1500, 3, "uniform53", True), (3, 700, 4, "dec4", True)])
 def test_hip_ranks_sharing_one_gpu(hip_api, oracle, tmp_path, world, n, seed, dist_name, screen):
-    # screen=True: the bf16 screening pass + k_resolve forced on at small n, so that every rank
-    # contributes its 64 per-workgroup records to the exchange
+    # screen=True: the bf16 screening pass + k_resolve forced on at small n: lookahead windows with sharded base scans
+    # (k_emit into the exchange block, k_merge); screen=False: no screening copy, every event's scan sharded
     extra = {"FNN_SCREEN_MIN_N": "8", "FNN_SCREEN_MIN_M": "64"} if screen else None
     res = run_ranks("hip", world, n, seed, dist_name, tmp_path, 29611 + world + (7 if screen else 0), extra)
     check(res, oracle, n, seed, dist_name)
