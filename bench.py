@@ -11,17 +11,24 @@ resident in HBM when the step starts.
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU) and orders the SAME
 matrix on all N GPUs (BASELINE.json's metric: one problem, strong scaling): every rank holds the matrix
 (8 GiB of 288) and runs the whole event chain; only the ~860 base scans of the lookahead windows - the
-part of the run that still streams the matrix, 0.19 s of it - are sharded (tile index mod N), each followed
+part of the run that still streams the matrix, ~0.19 s of it - are sharded (tile index mod N), each followed
 by ONE RCCL all-gather on the engine's stream (candidate records + the pairs every rank emitted for the
 new window).  The other ~31 900 events are a chain of latency-bound steps that no exchange can shorten
 (DESIGN.md "Multi-GPU"), so the curve is Amdahl-flat by construction.  If the RCCL communicator cannot be
 created the ranks agree to let rank 0 compute alone (reported in config.parallelism).
 FNN_BENCH_REPLICAS=1 instead runs N independent orders (seed + rank), one per GPU: that is NOT the
-BASELINE metric (it is reported under its own metric name, orders per second).
+BASELINE metric and is reported under its own metric name (orders per second).
+
+Outside the timed region the line also carries: `roofline` (the streaming kernel that is left, with its share
+of the GPU time), `chain` (per-kernel averages of the latency-bound event chain from an extra run with HIP events
+around every launch), `cpu_baseline` (the oracle on the host cores: the first events of the same matrix,
+extrapolated, plus a fully measured run at n = 4096 on one thread and on all cores next to the engine's own
+time at that size), and the comparison of the order with the oracle's golden (tests/golden/oracle_big.json).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,15 +38,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured copy rate
+PMC_SUMMARY = os.path.join("profiles", "r02", "pmc_screen_windows_summary_n32768.json")
+KCLASS = ["k_scan", "k_screen", "k_track", "k_decide", "k_update", "k_emit", "k_resolve", "k_finalize"]
 
 
-def cpu_baseline(n, seed, total_entries, budget_s=20.0):
+def host_cores():
+    # the GPU box gives one GPU's job a 16-core CPU share; more threads only oversubscribe it
+    return min(len(os.sched_getaffinity(0)), 16)
+
+
+def cpu_baseline(n, seed, total_entries, budget_s=15.0):
     """Oracle (C restatement, kind "port") on the host cores over a bounded sample of the
     SAME workload: the first events of the n-taxa run (each event scans ~n^2/2 entries).
     The sample's rate is extrapolated to the whole run's sum of scanned entries."""
     from oracle import nnet_oracle as O
-    # the GPU box gives one GPU's job a 16-core CPU share; more threads only oversubscribe it
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    cores = host_cores()
     t0 = time.time()
     D = O.synth(n, seed, "uniform53")
     t_gen = time.time() - t0
@@ -69,6 +82,41 @@ def cpu_baseline(n, seed, total_entries, budget_s=20.0):
     }
 
 
+def cpu_measured_small(api, dev_index, n=4096, seed=1):
+    """A FULLY measured configuration (BASELINE.json configs[1]): the oracle's whole run at n = 4096 on one
+    thread (the reference's -threads 1 semantics) and on all host cores, next to the engine's time there."""
+    from oracle import nnet_oracle as O
+    from fastneighbornet_amd._capi import Handle
+    D = O.synth(n, seed, "uniform53")
+    cores = host_cores()
+    t0 = time.time()
+    o_all, _, se = O.run(D, threads=cores, want_events=False)
+    t_all = time.time() - t0
+    t0 = time.time()
+    o_one, _, _ = O.run(D, threads=1, want_events=False)
+    t_one = time.time() - t0
+    with Handle(api, n, device=dev_index) as h:
+        h.synth(seed, "uniform53")
+        h.run()                      # warm-up
+        h.synth(seed, "uniform53")
+        order, st = h.run()
+    return {"n_taxa": n, "seed": seed, "oracle_1_thread_s": round(t_one, 2), "oracle_all_cores_s": round(t_all, 2),
+            "cores": cores, "engine_s": round(st.t_total_s, 4), "sum_entries": int(se),
+            "orders_identical": bool((o_all == o_one).all() and (order == o_one).all())}
+
+
+def golden_check(n, seed, order):
+    """The order against the oracle's golden for this (n, seed), generated in the build container."""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_big.json")))
+    except OSError:
+        return None
+    for c in doc["cases"]:
+        if (c["n"], c["seed"], c["dist"]) == (n, seed, "uniform53"):
+            return hashlib.sha256(order.tobytes()).hexdigest() == c["order_sha256"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +125,7 @@ def main():
     ap.add_argument("--taxa", "--n", dest="n", type=int, default=32768)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-chain", action="store_true", help="skip the extra run that times every kernel of the event chain")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -95,6 +144,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
 
+    import ctypes as C
     import fastneighbornet_amd as fa
     from fastneighbornet_amd import distributed as fd
     from fastneighbornet_amd._capi import Handle
@@ -114,7 +164,7 @@ def main():
     if replicas:
         parallelism = (f"REPLICAS (not the BASELINE metric): {world} independent orders (seed + rank), one per GPU, "
                        f"no data-path collective")
-    if world > 1 and shard_mode:
+    if shard_mode:
         ok, why = 1, ""
         try:
             h = Handle(api, n, device=dev_index)
@@ -122,7 +172,7 @@ def main():
                 fd.init_gloo(h, dist)
             else:
                 fd.init_rccl(h, dist, torch.device("cuda", dev_index))
-        except Exception as e:  # all ranks must agree on the fallback
+        except Exception as e:  # all ranks must agree on the fallback (init_rccl itself is symmetric)
             ok, why = 0, str(e)
         flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if same_gpu else "cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -164,34 +214,60 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- outside the timed region: every kernel of the event chain between HIP events (all ranks of a sharded run
+    # take part: the exchange is collective)
+    chain = None
+    if worker and not args.no_chain:
+        api.set_scan_timing(h._h, 2)
+        _, st2 = one_step()
+        ms = (C.c_double * 8)()
+        cnt = (C.c_int64 * 8)()
+        api.get_kernel_times(h._h, ms, cnt)
+        api.set_scan_timing(h._h, 1)
+        tot = sum(ms)
+        chain = {
+            "note": ("an extra, untimed run with HIP events around every launch (slower than the timed run by the event "
+                     "records); a window event = k_track (tracked pairs + sweep, the exact row sum of the previous "
+                     "event's cluster in a workgroup beside them, then Cx/Cy, 4-candidate choice and merge plan by the "
+                     "last workgroup) + k_update; an event that scans adds k_screen/k_emit/k_resolve (or k_scan) + k_decide"),
+            "run_s_with_event_records": round(st2.t_total_s, 4),
+            "kernels": {KCLASS[c]: {"launches": int(cnt[c]), "avg_us": round(ms[c] * 1e3 / cnt[c], 2),
+                                    "share_of_kernel_time": round(ms[c] / tot, 4)} for c in range(8) if cnt[c] > 0},
+        }
+    if dist is not None:
+        dist.barrier()
+
     if rank == 0:
         order, st = last
         sec = elapsed / args.steps
         fp64_equiv = 8.0 * float(st.sum_entries)     # BASELINE.md's 8 * sum E_t, for reference
         assert sorted(order[1:].tolist()) == list(range(1, n + 1)) and order[0] == 0 and order[1] == 1
+        gold = golden_check(n, seed, order) if not replicas else None
+        assert gold is not False, "the circular order differs from the oracle's golden (tests/golden/oracle_big.json)"
         share = args.gpus if sharded else 1  # this rank's launches cover 1/share of the entries
         # dominant streaming kernel: the bf16 screening pass.  With lookahead windows the timed launches
-        # are the host-scheduled base scans (kernel name k_screen<true, true>); the unscheduled ones
-        # (window failures) are the same kernel on a smaller grid and are not part of this figure.
+        # are the host-scheduled base scans (kernel name k_screen<true, true>)
         have_screen = st.scan_launches > 0
         k_bytes = float(st.scan_bytes) if have_screen else float(st.plain_bytes)
         k_time = st.t_scan_s if have_screen else st.t_plain_s
         k_launches = int(st.scan_launches if have_screen else st.plain_launches)
         scan_gbps = k_bytes / share / max(k_time, 1e-12) / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01", "pmc_screen_windows_summary_n32768.json")
+        pmc = os.path.join(ROOT, PMC_SUMMARY)
         if n == 32768 and args.gpus == 1 and have_screen and os.path.exists(pmc):
             traffic = round(json.load(open(pmc))["hbm_bytes_per_launch_avg"], 1)
+        if replicas:
+            head = {"metric": f"orders per second, n={n} taxa, {world} independent replicas (NOT the BASELINE metric)",
+                    "value": round(world / sec, 4), "unit": "orders/s", "higher_is_better": True, "scaling": "weak"}
+        else:
+            head = {"metric": f"sec to circular order, n={n} taxa (+ achieved HBM GB/s)", "value": round(sec, 4), "unit": "s",
+                    "higher_is_better": False, "scaling": "strong" if world > 1 else "weak"}
         out = {
-            "metric": f"sec to circular order, n={n} taxa (+ achieved HBM GB/s)",
-            "value": round(sec, 4),
-            "unit": "s",
+            **head,
             "n_gpus": args.gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(sec * 1e3, 2),
-            "higher_is_better": False,
-            "scaling": "strong" if (sharded or (world > 1 and not replicas)) else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -202,6 +278,7 @@ def main():
                 "n_taxa": n,
                 "events": int(st.n_events),
                 "sum_entries": int(st.sum_entries),
+                "order_matches_oracle_golden": gold,
                 "fp64_every_event_bytes": int(fp64_equiv),
                 "bytes_read_by_all_scan_work": int(st.bytes_total),
                 "lookahead_windows": {"events_with_a_scan": int(st.n_base_scans), "events_served_by_a_window": int(st.n_window_hits),
@@ -214,7 +291,8 @@ def main():
             # SURVEY.md 8(d)'s second figure, B_scan / t_order with B_scan = 8 B x sum_t E_t (what a scan of the fp64
             # matrix in every event would read).  NOT physical traffic: the windows avoid reading most of it.
             "b_scan_over_t_order_gbps": round(float(fp64_equiv) / sec / 1e9, 1),
-            "rx_decisions": {"certified_from_tree_sums": int(st.n_rx_certified), "exact_sequential_sums": int(st.n_rx_exact)},
+            "us_per_event": round((st.t_agglom_s) / max(st.n_events, 1) * 1e6, 2),
+            "rx_decisions": {"certified_from_approximate_row_sums": int(st.n_rx_certified), "exact_sequential_sums": int(st.n_rx_exact)},
             "phases_s": {"init": round(st.t_init_s, 4), "agglomerate": round(st.t_agglom_s, 4),
                          "expand": round(st.t_expand_s, 4), "screen_kernel_sum": round(st.t_scan_s, 4),
                          "plain_scan_kernel_sum": round(st.t_plain_s, 4)},
@@ -227,9 +305,12 @@ def main():
                 "unit": "GB/s",
                 "frac": round(scan_gbps / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
-                "traffic_note": ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel "
-                                 "(FETCH_SIZE x2 per the gfx950 correction), profiles/r01/pmc_screen_windows_summary_n32768.json"
+                "traffic_note": (f"HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel "
+                                 f"(FETCH_SIZE x2 per the gfx950 correction), measured this round: {PMC_SUMMARY}"
                                  if traffic else None),
+                # the kernel this roofline describes is a small part of the run: the rest is the latency-bound event
+                # chain (see `chain`), for which seconds-to-order and us per event are the yardsticks
+                "time_share": round(k_time / max(sec, 1e-12), 4),
                 "launches": k_launches,
                 "avg_launch_us": round(k_time / max(k_launches, 1) * 1e6, 2),
                 "algorithmic_bytes_per_launch_avg": round(k_bytes / share / max(k_launches, 1), 1),
@@ -241,9 +322,9 @@ def main():
                                     "achieved": round(float(st.plain_bytes) / max(st.t_plain_s, 1e-12) / 1e9, 1),
                                     "avg_launch_us": round(st.t_plain_s / max(st.plain_launches, 1) * 1e6, 2)},
             },
+            "chain": chain,
         }
         try:
-            import ctypes as C
             g = C.c_double(0.0)
             if api.stream_probe(dev_index, 4 << 30, 5, C.byref(g)) == 0:
                 out["roofline"]["measured_stream_read_gbps"] = round(g.value, 1)
@@ -251,12 +332,23 @@ def main():
             pass
         if h is not None:
             h.close()
+            h = None
         if not args.no_cpu_baseline and args.gpus == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, seed, int(st.sum_entries))
+                out["cpu_baseline"]["measured_n4096"] = cpu_measured_small(api, dev_index)
             except Exception as e:  # the baseline is reported, never required
-                out["cpu_baseline"] = {"value": None, "unit": "s", "cores": 0, "kind": "port",
-                                       "sample": f"failed: {e}"}
+                out.setdefault("cpu_baseline", {"value": None, "unit": "s", "cores": 0, "kind": "port"})
+                out["cpu_baseline"]["error"] = f"{type(e).__name__}: {e}"
+            # the reference itself (Java): only where an operator has supplied a JDK and the reference sources
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("java_baseline", os.path.join(ROOT, "tests", "golden", "java", "java_baseline.py"))
+                jb = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(jb)
+                out["cpu_baseline"]["java_reference"] = jb.run_if_available(ROOT)
+            except Exception as e:
+                out["cpu_baseline"]["java_reference"] = f"Java baseline unavailable ({type(e).__name__}: {e})"
         print(json.dumps(out), flush=True)
     if h is not None:
         h.close()  # every rank releases its engine (and its RCCL communicator) before the group goes away

@@ -2042,8 +2042,11 @@ struct HipBackend {
     hipStream_t stream = nullptr;
     int device = 0;
     bool opened = false;
-    // scan timing
-    bool timing = false;
+    // HIP-event timing of launches: 0 off, 1 the streaming scan kernels (bench.py's roofline figure), 2 every kernel of the
+    // launch sequences (bench.py's `chain` object, an extra untimed run)
+    int timing = 0;
+    double class_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // by kernel class: TC_*
+    int64_t class_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<hipEvent_t> ev_pool;
     std::vector<char> ev_kind;   // per event pair: 1 = screening pass (k_screen), 0 = plain fp64 scan (k_scan)
     size_t ev_used = 0;
@@ -2179,13 +2182,33 @@ struct HipBackend {
         return copy2d(d, ldd, s, lds, w, h, hipMemcpyDeviceToHost);
     }
 
+    enum { TC_SCAN = 0, TC_SCREEN = 1, TC_TRACK = 2, TC_DECIDE = 3, TC_UPDATE = 4, TC_EMIT = 5, TC_RESOLVE = 6, TC_OTHER = 7 };
     void drain_timing() {
-        for (size_t i = 0; i + 1 < ev_used; i += 2) {
+        for (size_t i = 0; i + 1 < ev_used && i / 2 < ev_kind.size(); i += 2) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]) == hipSuccess) (ev_kind[i / 2] ? scan_ms : plain_ms) += ms;
+            if (hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]) == hipSuccess) {
+                const int c = ev_kind[i / 2] & 7;
+                class_ms[c] += ms;
+                class_n[c]++;
+                if (c == TC_SCREEN) scan_ms += ms;
+                else if (c == TC_SCAN) plain_ms += ms;
+            }
         }
         ev_used = 0;
         ev_kind.clear();
+    }
+    // a launch between two event records (only when both events could be had: a failed hipEventCreate skips the timing
+    // of that launch altogether, so durations and classes cannot get out of step)
+    template <class F>
+    void timed(int cls, bool on, F&& launch) {
+        hipEvent_t e0 = on ? next_event() : nullptr, e1 = e0 ? next_event() : nullptr;
+        if (e0 && !e1) ev_used--;
+        if (e0 && e1) {
+            ev_kind.push_back((char)cls);
+            (void)hipEventRecord(e0, stream);
+            launch();
+            (void)hipEventRecord(e1, stream);
+        } else launch();
     }
     int32_t sync() {
         if (!HIPOK(hipStreamSynchronize(stream))) return FNN_EHIP;
@@ -2198,7 +2221,10 @@ struct HipBackend {
         s.t_plain_s = plain_ms * 1e-3;
         s.plain_launches = plain_launches;
     }
-    void reset_timing() { scan_ms = plain_ms = 0.0; scan_launches = plain_launches = 0; ev_used = 0; ev_kind.clear(); }
+    void reset_timing() {
+        scan_ms = plain_ms = 0.0; scan_launches = plain_launches = 0; ev_used = 0; ev_kind.clear();
+        for (int c = 0; c < 8; c++) { class_ms[c] = 0.0; class_n[c] = 0; }
+    }
 
     hipEvent_t next_event() {
         if (ev_used == ev_pool.size()) {
@@ -2272,51 +2298,53 @@ struct HipBackend {
     // schedule opens a new window at this event, so the scan is certain to run: only those
     // launches (and the plain fp64 scans) are timed for the roofline figure.
     int enqueue_scan(const Dev& d, int32_t m_bound, bool sched) {
-        hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool screen = use_screen(d, m_bound);
-        const bool timed = timing && (sched || !screen);
+        const bool tscan = timing != 0 && (sched || !screen), tall = timing == 2;
         // (an unscheduled event is launched without scan kernels: if its window cannot serve it, the
         //  device stalls - this and the following such events do nothing - until the host, which
         //  looks at the state every batch, launches an event with a scan)
         const bool has_scan = sched || !screen || !skip_unsched_scans;
-        if (d.la) hipLaunchKernelGGL(k_track, dim3(track_grid + 1), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0, has_scan ? 1 : 0, track_group, ticks ? 1 : 0);
-        if (timed) { e0 = next_event(); e1 = next_event(); ev_kind.push_back(screen ? 1 : 0); }
+        if (d.la) timed(TC_TRACK, tall, [&]() {
+            hipLaunchKernelGGL(k_track, dim3(track_grid + 1), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0, has_scan ? 1 : 0, track_group, ticks ? 1 : 0);
+        });
         int nrecs;
         if (screen && !has_scan) nrecs = 0;  // (a window event: the tail of k_track decides; no decide kernel follows)
         else if (screen) {
             int nt = (tri_tile_count(m_bound, SCR_TH, SCR_R) + d.world - 1) / d.world;
             const int want = sched ? scan_grid : unsched_grid;
             dim3 gs((unsigned)(nt < want ? (nt > 0 ? nt : 1) : want));
-            if (e0) (void)hipEventRecord(e0, stream);
-            if (sched) {
-                if (scan_nt) hipLaunchKernelGGL((k_screen<true, true>), gs, dim3(256), 0, stream, d);
-                else hipLaunchKernelGGL((k_screen<false, true>), gs, dim3(256), 0, stream, d);
-            } else {
-                if (scan_nt) hipLaunchKernelGGL((k_screen<true, false>), gs, dim3(256), 0, stream, d);
-                else hipLaunchKernelGGL((k_screen<false, false>), gs, dim3(256), 0, stream, d);
-            }
-            if (e1) (void)hipEventRecord(e1, stream);
-            if (d.la) hipLaunchKernelGGL(k_emit, dim3(emit_grid), dim3(256), 0, stream, d);
-            hipLaunchKernelGGL(k_resolve, dim3(RES_BLOCKS), dim3(1024), 0, stream, d);
+            timed(TC_SCREEN, tscan, [&]() {
+                if (sched) {
+                    if (scan_nt) hipLaunchKernelGGL((k_screen<true, true>), gs, dim3(256), 0, stream, d);
+                    else hipLaunchKernelGGL((k_screen<false, true>), gs, dim3(256), 0, stream, d);
+                } else {
+                    if (scan_nt) hipLaunchKernelGGL((k_screen<true, false>), gs, dim3(256), 0, stream, d);
+                    else hipLaunchKernelGGL((k_screen<false, false>), gs, dim3(256), 0, stream, d);
+                }
+            });
+            if (d.la) timed(TC_EMIT, tall, [&]() { hipLaunchKernelGGL(k_emit, dim3(emit_grid), dim3(256), 0, stream, d); });
+            timed(TC_RESOLVE, tall, [&]() { hipLaunchKernelGGL(k_resolve, dim3(RES_BLOCKS), dim3(1024), 0, stream, d); });
             nrecs = RES_BLOCKS;
+            if (tscan) scan_launches++;
         } else {
             dim3 gs = scan_dims(d, m_bound);
-            if (e0) (void)hipEventRecord(e0, stream);
-            if (scan_nt) hipLaunchKernelGGL(k_scan<true>, gs, dim3(SCAN_THREADS), 0, stream, d);
-            else hipLaunchKernelGGL(k_scan<false>, gs, dim3(SCAN_THREADS), 0, stream, d);
-            if (e1) (void)hipEventRecord(e1, stream);
+            timed(TC_SCAN, tscan, [&]() {
+                if (scan_nt) hipLaunchKernelGGL(k_scan<true>, gs, dim3(SCAN_THREADS), 0, stream, d);
+                else hipLaunchKernelGGL(k_scan<false>, gs, dim3(SCAN_THREADS), 0, stream, d);
+            });
             nrecs = (int)gs.x;
+            if (tscan) plain_launches++;
         }
-        if (timed) (screen ? scan_launches : plain_launches)++;
         return nrecs;
     }
     // everything after the scan; `src` holds the nrecs candidate records to reduce (0: a window event, already
     // decided by the tail of k_track - or stalled)
     void enqueue_rest(const Dev& d, int32_t m_bound, const Cand* src, int nrecs) {
         dim3 g1 = grid1(m_bound);
-        if (nrecs > 0) hipLaunchKernelGGL(k_decide, dim3(1), dim3(CH_T), 0, stream, d, src, nrecs);
-        hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d, defer_chain ? 1 : 0, ticks ? 1 : 0);
-        if (!defer_chain) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d);
+        const bool tall = timing == 2;
+        if (nrecs > 0) timed(TC_DECIDE, tall, [&]() { hipLaunchKernelGGL(k_decide, dim3(1), dim3(CH_T), 0, stream, d, src, nrecs); });
+        timed(TC_UPDATE, tall, [&]() { hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d, defer_chain ? 1 : 0, ticks ? 1 : 0); });
+        if (!defer_chain) timed(TC_OTHER, tall, [&]() { hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d); });
     }
     // single GPU: the whole event
     int32_t launch_event(const Dev& d, int32_t m_bound, bool sched) {
@@ -2504,7 +2532,13 @@ int32_t fnn_debug_decide_ticks(fnn_handle* h, int64_t* out4) {
 }
 int32_t fnn_set_scan_timing(fnn_handle* h, int32_t enable) {
     FNN_NEED(h);
-    h->eng.be.timing = enable != 0;
+    h->eng.be.timing = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+    return FNN_OK;
+}
+int32_t fnn_get_kernel_times(fnn_handle* h, double* ms8, int64_t* launches8) {
+    FNN_NEED(h);
+    if (!ms8 || !launches8) return fnn::fail(FNN_EINVAL, "fnn_get_kernel_times: NULL output");
+    for (int c = 0; c < 8; c++) { ms8[c] = h->eng.be.class_ms[c]; launches8[c] = h->eng.be.class_n[c]; }
     return FNN_OK;
 }
 

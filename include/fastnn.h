@@ -181,9 +181,13 @@ int32_t fnn_debug_update_ticks(fnn_handle* h, int64_t* out8);
  * symbolic replay of the micro-ops}. */
 int32_t fnn_debug_decide_ticks(fnn_handle* h, int64_t* out4);
 
-/* Enable per-launch HIP-event timing of the scan kernel (bench.py's roofline
- * figure).  Adds two event records per scan launch. */
+/* Per-launch HIP-event timing on the engine's stream (two event records per timed launch): 1 = the streaming scan
+ * kernels only (bench.py's roofline figure: fnn_stats.t_scan_s / scan_launches), 2 = every kernel of the launch
+ * sequences (perturbs the run a little: for an extra, untimed run), 0 = off. */
 int32_t fnn_set_scan_timing(fnn_handle* h, int32_t enable);
+/* With timing on: milliseconds and launches of the last run by kernel class {0 k_scan, 1 k_screen, 2 k_track,
+ * 3 k_decide, 4 k_update, 5 k_emit, 6 k_resolve, 7 k_finalize}. */
+int32_t fnn_get_kernel_times(fnn_handle* h, double* ms8, int64_t* launches8);
 
 /* One-call convenience == create + set_rows + run + destroy
  * (FastNN.java:326 + :378). */

@@ -27,9 +27,12 @@ def write_phylip(path, D, names=None, style="lower", sep=" "):
 
 @pytest.fixture(scope="module")
 def hostlib():
-    from fastneighbornet_amd import build
-    build.build()
-    lib = C.CDLL(os.path.join(PKG, "libfastnn_host.so"))
+    if os.environ.get("FNN_HOST_LIB"):  # (the sanitizer leg points at its instrumented build)
+        lib = C.CDLL(os.environ["FNN_HOST_LIB"])
+    else:
+        from fastneighbornet_amd import build
+        build.build()
+        lib = C.CDLL(os.path.join(PKG, "libfastnn_host.so"))
     lib.fnnh_read_taxa_count.argtypes = [C.c_char_p]
     lib.fnnh_read_phylip.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.c_char_p]
     return lib
