@@ -210,6 +210,151 @@ FNN_HD bool mono_apply_bits(double& s, int32_t E, uint64_t i0, uint64_t i1) {
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// Second form of the block-parallel sum ("records"): almost every chunk that the first form adds one by one
+// holds exactly ONE addend that needs an ordinary addition - the one that carries the running sum into the next
+// binade, or one whose fraction is exactly half an ulp (a tie) - and constants on either side of it.  A thread
+// therefore describes its chunk as
+//     CONST  (E, c)                         every addend is a constant increment c_i = rint(a_i / ulp_E)
+//     SPLIT  (E0, c0) a* (E1, c1)           constants before and after ONE special addend a*
+//     SERIAL                                anything else (several specials, negative / non-finite addends, ...)
+// and the sequence of all threads' pieces is evaluated as: merge neighbouring constant pieces of equal binade
+// (integer sums, any order), apply each merged piece to the bit pattern of the running sum (mono_apply_pattern: the
+// SAME verified step as a run of the first form - binade of the sum before, no carry into the exponent after), add
+// a* with an ordinary addition, add SERIAL chunks one by one.  Every constant piece is verified when applied, so
+// exactness never depends on the predictions (where a special addend sits, which binade follows it); a failed
+// verification makes the caller fall back to the first form for this sum.
+// ---------------------------------------------------------------------------
+constexpr int CHR_CONST = 0, CHR_SPLIT = 1, CHR_SERIAL = 2, CHR_EMPTY = 3;
+struct ChRec {
+    int32_t kind, E0, E1;   // E0 < 0 on a SPLIT: no constant piece in front of the special addend
+    uint64_t c0, c1;
+    double sp;
+};
+
+// constants of a[lo, hi) relative to binade E: their sum; false on a tie, a negative / non-finite addend or an
+// addend too large for the binade.  `tie_at` (may be null) receives the index of the first tie and the scan goes on.
+template <int N>
+FNN_HD bool chain_consts(const double (&a)[N], int lo, int hi, int32_t E, uint64_t& c, int* ntie, int* tie_at) {
+    const double invu = inv_ulp(E);
+    double acc0 = 0.0, acc1 = 0.0;
+    uint32_t sgn = 0;  // sign bits of the scaled addends, OR-ed (a negative addend - or -0.0, harmless - sets it)
+    int ties = 0, first = -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < N; i++) {
+        if (i < lo || i >= hi) continue;
+        const double t = a[i] * invu;                 // a in ulps; exact (see header)
+        const double ci = __builtin_rint(t);          // q + r unless there is a tie (round to nearest even)
+        const double e = t - ci;                      // exact, |e| <= 0.5
+        if (__builtin_fabs(e) == 0.5) { if (first < 0) first = i; ties++; }
+        else if (i & 1) acc1 += ci;
+        else acc0 += ci;
+        sgn |= hi32(t);
+    }
+    const double cs = acc0 + acc1;
+    const double tmin = (sgn >> 31) ? -1.0 : 0.0;
+    if (ntie) *ntie = ties;
+    if (tie_at) *tie_at = first;
+    c = mono_inc_bits(cs);
+    return cs < CH_TWO53 && !(tmin < 0.0) && cs == cs;
+}
+
+// a[j] for a run-time j without indexing the register array (unrolled selects)
+template <int N>
+FNN_HD double chain_pick(const double (&a)[N], int j) {
+    double v = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < N; i++) if (i == j) v = a[i];
+    return v;
+}
+
+// the record of one thread's chunk: a[0, cnt) are its addends, A0 the PREDICTED partial sum in front of the chunk
+template <int N>
+FNN_HD ChRec chain_thread_record(const double (&a)[N], int cnt, double A0, double loc, bool guard) {
+    ChRec r;
+    r.kind = CHR_SERIAL; r.E0 = r.E1 = -1; r.c0 = r.c1 = 0; r.sp = 0.0;
+    if (cnt <= 0) { r.kind = CHR_EMPTY; return r; }
+    int32_t E = -1;
+    if (chain_predict(A0, A0 + loc, guard, E)) {
+        int nt = 0, jt = -1;
+        uint64_t c = 0;
+        if (!chain_consts(a, 0, cnt, E, c, &nt, &jt)) return r;  // (negative / non-finite / too large: one by one)
+        if (nt == 0) { r.kind = CHR_CONST; r.E0 = E; r.c0 = c; return r; }
+        if (nt > 1) return r;
+        // exactly one tie: constants before and after it, in the same binade
+        uint64_t c0 = 0, c1 = 0;
+        if (!chain_consts(a, 0, jt, E, c0, nullptr, nullptr) || !chain_consts(a, jt + 1, cnt, E, c1, nullptr, nullptr)) return r;
+        r.kind = CHR_SPLIT; r.E0 = E; r.c0 = c0; r.sp = chain_pick(a, jt); r.E1 = E; r.c1 = c1;
+        return r;
+    }
+    // the predicted partial sums of the chunk do not stay in one binade: find the addend that leaves it
+    double p = A0, pafter = A0, asp = 0.0;
+    int js = -1;
+    int32_t E0 = -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < N; i++) {  // (unrolled with a predicate: a run-time index would put the addends in scratch memory)
+        if (js < 0 && i < cnt) {
+            int32_t Ei = -1;
+            const double pn = p + a[i];
+            if (!chain_predict(p, pn, guard, Ei) || (i > 0 && Ei != E0)) { js = i; pafter = pn; asp = a[i]; }
+            else { E0 = Ei; p = pn; }
+        }
+    }
+    if (js < 0) return r;  // (cannot happen: the whole-chunk prediction failed)
+    int32_t E1 = -1;
+    if (js + 1 < cnt && !chain_predict(pafter, A0 + loc, guard, E1)) return r;  // the rest leaves its binade again
+    uint64_t c0 = 0, c1 = 0;
+    int nt = 0;
+    if (js > 0) { if (!chain_consts(a, 0, js, E0, c0, &nt, nullptr) || nt) return r; }
+    if (js + 1 < cnt) { if (!chain_consts(a, js + 1, cnt, E1, c1, &nt, nullptr) || nt) return r; }
+    r.kind = CHR_SPLIT; r.E0 = js > 0 ? E0 : -1; r.c0 = c0; r.sp = asp; r.E1 = js + 1 < cnt ? E1 : -1; r.c1 = c1;
+    return r;
+}
+
+// serial evaluation of a sequence of records (CPU model; the GPU walker does the same with a segmented scan in front).
+// `serial(t, s)` adds thread t's addends one by one.  False: a verification failed (the caller falls back).
+template <class Serial>
+FNN_HD bool chain_walk_records(const ChRec* rec, int nthreads, double& s, int32_t* applied, Serial&& serial) {
+    bool have = false;
+    int32_t E = -1;
+    uint64_t c = 0;
+    auto flush = [&]() {
+        if (have && c != 0) {
+            if (!mono_apply_bits(s, E, c, c)) return false;
+            if (applied) ++*applied;
+        }
+        have = false; c = 0;
+        return true;
+    };
+    auto piece = [&](int32_t Ep, uint64_t cp) {
+        if (have && E == Ep) { c = c + cp > (1ULL << 60) ? (1ULL << 60) : c + cp; return true; }  // (anything beyond 2^52 is rejected when applied)
+        if (!flush()) return false;
+        have = true; E = Ep; c = cp;
+        return true;
+    };
+    for (int t = 0; t < nthreads; t++) {
+        const ChRec& r = rec[t];
+        if (r.kind == CHR_EMPTY) continue;
+        if (r.kind == CHR_CONST) { if (!piece(r.E0, r.c0)) return false; }
+        else if (r.kind == CHR_SPLIT) {
+            if (r.E0 >= 0 && !piece(r.E0, r.c0)) return false;
+            if (!flush()) return false;
+            s += r.sp;
+            if (r.E1 >= 0 && !piece(r.E1, r.c1)) return false;
+        } else {
+            if (!flush()) return false;
+            serial(t, s);
+        }
+    }
+    return flush();
+}
+
 // Counters of the walker (diagnostics / tests)
 struct ChainStats {
     int32_t runs;         // composed runs applied

@@ -784,6 +784,14 @@ struct ChainLds {
     uint64_t own[CH_T], sc[CH_T];  // increments of a chunk / of the run up to the chunk, as integers (mono_inc_bits);
                                    // chunks with a tie are "mixed", so an automaton here is one constant
     double vals[CH_NSLOT][EPT];
+    // record form (block_chain_sum2): special addend per thread; per-wave totals of the segmented scan
+    double spv[CH_T];
+    ChRec prec[CH_NSLOT];      // records of the parked chunks, computed lane-parallel (chain_record_wave)
+    double pend_A0[CH_NSLOT];
+    int32_t pend_cnt[CH_NSLOT];
+    uint64_t wk[CH_T / 64];
+    int32_t wr[CH_T / 64];
+    int32_t fail;
 };
 
 __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
@@ -807,6 +815,7 @@ __device__ __forceinline__ void chain_serial_global(double& s, const double* buf
         if (start + i < m) s += buf[chain_addr(start + i)];
 }
 
+__device__ int g_chain_form = 2;        // diagnostic (FNN_CHAIN_FORM=1): the first form in fnn_test_chain_sum
 __device__ int g_chain_stop_after = 0;  // diagnostic: 1 loads+prefix, 2 +automata, 3 +segmented scan (0 = full)
 
 // MODE 0: the whole sum.  MODE 1: steps 1-3 only (the records stay in L; m <= CH_T * EPT).  MODE 2:
@@ -973,6 +982,264 @@ __device__ __forceinline__ double block_chain_sum(const double* __restrict__ buf
     return L.s;
 }
 
+
+// ------------------------------------------------------------------ the record form of the chain sum
+// fnn_chain.h "records": a thread describes its 32 addends as constants around at most ONE addend that needs an
+// ordinary addition (a binade crossing or a tie); neighbouring constant pieces of equal binade are merged by a
+// segmented scan over the 1024 threads, and wave 0 only walks over the ~25 places where something has to happen
+// (a verified integer update of the sum's bit pattern, then one addition) instead of adding ~20 chunks of 32
+// addends one by one.  Any failed verification -> the first form computes the whole sum.
+// The record (fnn_chain.h: ChRec) of ONE chunk of <= 32 addends by one wave, lane l < 32 holding addend l: what
+// chain_thread_record does with a 32-step loop per thread (and every wave has some thread that needs it) takes a
+// prefix scan, two ballots and two masked reductions here.  Same contract: constants are only claimed for pieces whose
+// addends are all non-negative, finite, tie-free multiples-after-rounding in ONE predicted binade; the walker verifies
+// every piece when it applies it.
+__device__ __forceinline__ ChRec chain_record_wave(double al, int cnt, double A0, bool guard) {
+    const int lane = threadIdx.x & 63;
+    ChRec r;
+    r.kind = CHR_SERIAL; r.E0 = r.E1 = -1; r.c0 = r.c1 = 0; r.sp = 0.0;
+    const bool in = lane < cnt;
+    // predicted partial sums in front of / behind every addend
+    double inc = in ? al : 0.0;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        const double t = __shfl_up(inc, d, 64);
+        if ((lane & 31) >= d) inc += t;
+    }
+    const double pb = A0 + (inc - (in ? al : 0.0)), pa = A0 + inc;
+    int32_t El = -1;
+    const bool okl = in && chain_predict(pb, pa, guard, El);
+    const int32_t E_first = __builtin_amdgcn_readlane(El, 0);
+    const bool ok0 = __builtin_amdgcn_readlane((int)okl, 0) != 0;
+    const unsigned long long inm = __ballot(in);
+    const unsigned long long bad = __ballot(in && (!okl || El != E_first)) | (ok0 ? 0ULL : 1ULL);
+    // per-lane constant relative to a binade, with the tie / sign / range checks
+    auto konst = [&](int32_t E, bool& tie, bool& inval) {
+        const double t = al * inv_ulp(E);
+        const double ci = __builtin_rint(t);
+        tie = __builtin_fabs(t - ci) == 0.5;
+        inval = !(t >= 0.0 && t < CH_TWO53) || (hi32(t) >> 31);
+        return ci;
+    };
+    auto msum = [&](double v, unsigned long long mask) {  // sum of v over the lanes of mask (integer-valued: any order)
+        double x = ((mask >> lane) & 1ULL) ? v : 0.0;
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+        return __builtin_bit_cast(double, readfirstlane_u64(f2u(x)));
+    };
+    if (!bad) {
+        // one binade for the whole chunk: no tie -> CONST; one tie -> SPLIT around it
+        bool tie, inval;
+        const double ci = konst(E_first, tie, inval);
+        if (__ballot(in && inval)) return r;
+        const unsigned long long tm = __ballot(in && tie);
+        if (__builtin_popcountll(tm) > 1) return r;
+        if (!tm) { r.kind = CHR_CONST; r.E0 = E_first; r.c0 = mono_inc_bits(msum(ci, inm)); return r; }
+        const int jt = __builtin_ctzll(tm);
+        const unsigned long long lo = inm & ((1ULL << jt) - 1ULL), hi = inm & ~((2ULL << jt) - 1ULL);
+        r.kind = CHR_SPLIT; r.E0 = E_first; r.E1 = E_first;
+        r.c0 = mono_inc_bits(msum(ci, lo)); r.c1 = mono_inc_bits(msum(ci, hi));
+        r.sp = __builtin_bit_cast(double, readlane_u64(f2u(al), jt));
+        return r;
+    }
+    const int js = __builtin_ctzll(bad);
+    const unsigned long long lo = inm & ((1ULL << js) - 1ULL), hi = inm & ~((2ULL << js) - 1ULL);
+    int32_t E1 = -1;
+    if (hi) {
+        const int jn = __builtin_ctzll(hi);
+        E1 = __builtin_amdgcn_readlane(El, jn);
+        if (__ballot(((hi >> lane) & 1ULL) && (!okl || El != E1))) return r;  // the rest leaves its binade again
+    }
+    bool tie0 = false, inv0 = false, tie1 = false, inv1 = false;
+    const double c0l = lo ? konst(E_first, tie0, inv0) : 0.0;
+    const double c1l = hi ? konst(E1, tie1, inv1) : 0.0;
+    if (__ballot((((lo >> lane) & 1ULL) && (tie0 || inv0)) || (((hi >> lane) & 1ULL) && (tie1 || inv1)))) return r;
+    r.kind = CHR_SPLIT;
+    r.E0 = lo ? E_first : -1; r.c0 = lo ? mono_inc_bits(msum(c0l, lo)) : 0;
+    r.E1 = hi ? E1 : -1; r.c1 = hi ? mono_inc_bits(msum(c1l, hi)) : 0;
+    r.sp = __builtin_bit_cast(double, readlane_u64(f2u(al), js));
+    return r;
+}
+
+template <int EPT>
+__device__ __forceinline__ double block_chain_sum2(const double* __restrict__ buf, int m, int guard_bits, ChainLds<EPT>& L,
+                                                   ChainStats* stats) {
+    static_assert(EPT == CH_EPT, "the buffer layout is fixed to CH_EPT addends per thread");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    ChainStats cs{0, 0, 0, 0};
+    if (tid == 0) { L.s = 0.0; L.fail = 0; }
+    for (int base = 0; base < m; base += CH_T * EPT) {
+        if (tid == 0) L.slot_count = 0;
+        // 1. this thread's addends (chunk-interleaved buffer) and the predicted partial sum in front of them
+        double a[EPT];
+        const int idx0 = base + tid * EPT;
+        const double* src = buf + base + 2 * tid;
+#pragma unroll
+        for (int i = 0; i < EPT; i += 2) {
+            double2 v = make_double2(0.0, 0.0);
+            if (idx0 + i < m) v = *reinterpret_cast<const double2*>(src + (i >> 1) * (2 * CH_T));
+            a[i] = v.x;
+            a[i + 1] = (idx0 + i + 1 < m) ? v.y : 0.0;
+        }
+        double l4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < EPT; i++) l4[i & 3] += a[i];
+        const double loc = (l4[0] + l4[1]) + (l4[2] + l4[3]);  // (prediction only: any order)
+        double inc = loc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) L.wtot[w] = inc;
+        __syncthreads();
+        double wpre = 0.0;
+        for (int k = 0; k < w; k++) wpre += L.wtot[k];
+        const double s_in = L.s;
+        const double A0 = s_in + (wpre + (inc - loc));
+        // 2. the record of the chunk.  The common case - every addend a tie-free constant of ONE predicted binade - is
+        //    decided by the thread itself; any other chunk is parked in LDS and its record is worked out by a wave,
+        //    lane-parallel (chain_record_wave), so that no wave runs through a 32-step search for one of its threads
+        const int cnt = idx0 >= m ? 0 : (m - idx0 < EPT ? m - idx0 : EPT);
+        ChRec r;
+        r.kind = CHR_EMPTY; r.E0 = r.E1 = -1; r.c0 = r.c1 = 0; r.sp = 0.0;
+        int slot = -1;
+        if (cnt > 0) {
+            int32_t E = -1;
+            int nt = 0;
+            uint64_t c = 0;
+            if (chain_predict(A0, A0 + loc, guard_bits != 0, E) && chain_consts(a, 0, cnt, E, c, &nt, nullptr) && nt == 0) {
+                r.kind = CHR_CONST; r.E0 = E; r.c0 = c;
+            } else {
+                r.kind = CHR_SERIAL;
+                slot = atomicAdd(&L.slot_count, 1);
+                if (slot < CH_NSLOT) {
+#pragma unroll
+                    for (int i = 0; i < EPT; i++) L.vals[slot][i] = a[i];
+                    L.pend_A0[slot] = A0;
+                    L.pend_cnt[slot] = cnt;
+                } else slot = -1;  // (more odd chunks than slots: added one by one from memory)
+            }
+        }
+        __syncthreads();
+        {
+            const int ns = L.slot_count < CH_NSLOT ? L.slot_count : CH_NSLOT;
+            for (int sl = w; sl < ns; sl += CH_T / 64) {
+                const double al = lane < EPT ? L.vals[sl][lane < EPT ? lane : 0] : 0.0;
+                const ChRec pr = chain_record_wave(al, L.pend_cnt[sl], L.pend_A0[sl], guard_bits != 0);
+                if (lane == 0) L.prec[sl] = pr;
+            }
+        }
+        __syncthreads();
+        if (slot >= 0) r = L.prec[slot];
+        // 3. segmented scan of the constant pieces: element (reset, value); tailE = binade of the piece a thread leaves open
+        const int32_t tailE = r.kind == CHR_CONST ? r.E0 : (r.kind == CHR_SPLIT ? r.E1 : -2);
+        int32_t prevTail = __shfl_up(tailE, 1, 64);
+        L.E[tid] = tailE;
+        __syncthreads();
+        if (lane == 0) prevTail = tid > 0 ? L.E[tid - 1] : -2;
+        const bool ebreak = r.kind == CHR_CONST && prevTail != r.E0;
+        int rr = (r.kind == CHR_SPLIT || r.kind == CHR_SERIAL || ebreak) ? 1 : 0;
+        uint64_t kk = r.kind == CHR_CONST ? r.c0 : (r.kind == CHR_SPLIT ? (r.E1 >= 0 ? r.c1 : 0) : 0);
+        const int r_own = rr;
+        const uint64_t k_own = kk;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int pr = __shfl_up(rr, d, 64);
+            const uint64_t pk = shfl_up_u64(kk, d);
+            if (lane >= d) {
+                if (!rr) { const uint64_t t = pk + kk; kk = t > (1ULL << 60) ? (1ULL << 60) : t; }
+                rr |= pr;
+            }
+        }
+        if (lane == 63) { L.wr[w] = rr; L.wk[w] = kk; }
+        __syncthreads();
+        uint64_t X = 0;
+        for (int q = 0; q < w; q++) { const uint64_t t = X + L.wk[q]; X = L.wr[q] ? L.wk[q] : (t > (1ULL << 60) ? (1ULL << 60) : t); }
+        uint64_t after;
+        { const uint64_t t = X + kk; after = rr ? kk : (t > (1ULL << 60) ? (1ULL << 60) : t); }
+        uint64_t xin = shfl_up_u64(after, 1);
+        if (lane == 0) xin = X;
+        (void)r_own; (void)k_own;
+        // what the walker needs of an event thread: kind, binade and value of what is open in front of it, its own pieces
+        const bool evt = r.kind == CHR_SPLIT || r.kind == CHR_SERIAL || (ebreak && xin != 0);
+        __syncthreads();  // (L.E is re-used below)
+        L.E[tid] = prevTail;
+        L.flags[tid] = r.kind | (evt ? 4 : 0);
+        L.slot[tid] = r.kind == CHR_SERIAL ? slot : r.E0;
+        L.own[tid] = r.c0;
+        L.sc[tid] = xin;
+        L.spv[tid] = r.sp;
+        const int lastT = ((m - base < CH_T * EPT ? m - base : CH_T * EPT) - 1) / EPT;
+        if (tid == lastT) { L.wk[0] = after; L.wr[0] = tailE; }  // (the piece left open at the end of this super-chunk)
+        __syncthreads();
+        if (r.kind == CHR_SERIAL && tid <= lastT) cs.mixed++;
+        // 4. the walk: only the event threads, in order
+        if (w == 0) {
+            uint64_t sb = readfirstlane_u64(f2u(s_in));
+            bool ok = true;
+            auto apply = [&](int E, uint64_t c) {
+                if (c == 0) return;
+                if (mono_apply_pattern(sb, E, c, c)) cs.runs++;
+                else ok = false;
+            };
+            for (int ww = 0; ww < CH_T / 64 && ok; ww++) {
+                if (ww * 64 > lastT) break;
+                const int id = ww * 64 + lane;
+                const int rf = L.flags[id], rEin = L.E[id], rs = L.slot[id];
+                const uint64_t rc0 = L.own[id], rx = L.sc[id];
+                const double rsp = L.spv[id];
+                unsigned long long em = __ballot((rf & 4) != 0 && id <= lastT);
+                while (em && ok) {
+                    const int e = __builtin_ctzll(em);
+                    em &= em - 1;
+                    const int kind = readlane_i32(rf, e) & 3, Ein = readlane_i32(rEin, e), sl = readlane_i32(rs, e);
+                    const uint64_t x = readlane_u64(rx, e), c0 = readlane_u64(rc0, e);
+                    if (kind == CHR_CONST) apply(Ein, x);  // (a change of binade without a special addend in between)
+                    else if (kind == CHR_SPLIT) {
+                        const int E0 = sl;
+                        if (E0 >= 0 && E0 == Ein) { const uint64_t t = x + c0; apply(E0, t > (1ULL << 60) ? (1ULL << 60) : t); }
+                        else { apply(Ein, x); if (E0 >= 0) apply(E0, c0); }
+                        if (!ok) break;
+                        const double sv = u2f(sb) + u2f(readlane_u64(f2u(rsp), e));
+                        sb = readfirstlane_u64(f2u(sv));
+                    } else {
+                        apply(Ein, x);
+                        if (!ok) break;
+                        double sv = u2f(sb);
+                        if (sl >= 0) {
+                            const double* pv = L.vals[sl];
+#pragma unroll
+                            for (int j = 0; j < EPT; j++) sv += pv[j];
+                        } else chain_serial_global(sv, buf, base + (ww * 64 + e) * EPT, EPT, m);
+                        sb = readfirstlane_u64(f2u(sv));
+                    }
+                }
+            }
+            if (ok) apply((int)L.wr[0], L.wk[0]);
+            if (lane == 0) { L.s = u2f(sb); if (!ok) L.fail = 1; }
+        }
+        __syncthreads();
+        if (L.fail) break;
+    }
+    __syncthreads();
+    if (L.fail) {  // (rare: a mispredicted binade; the first form redoes the whole sum with its own fallbacks)
+        ChainStats c1{0, 0, 0, 0};
+        const double r1 = block_chain_sum<EPT>(buf, m, guard_bits, L, stats ? &c1 : nullptr);
+        if (stats && tid == 0) { stats->runs = cs.runs + c1.runs; stats->mixed = cs.mixed + c1.mixed; stats->run_fail = 1 + c1.run_fail; stats->thread_fail = c1.thread_fail; }
+        return r1;
+    }
+    if (stats) {
+        // (the serial chunks were counted by their own threads)
+        __shared__ int mixed_total;
+        if (tid == 0) mixed_total = 0;
+        __syncthreads();
+        if (cs.mixed) atomicAdd(&mixed_total, cs.mixed);
+        __syncthreads();
+        if (tid == 0) { cs.mixed = mixed_total; *stats = cs; }
+    }
+    return L.s;
+}
 
 // ------------------------------------------------------------------ the decide step
 // Cx / Cy from the event's best candidate (NetMakerOriginal.java:376-380), the 4-candidate choice
@@ -1346,7 +1613,7 @@ __device__ __forceinline__ void chain_deliver(const Dev& d, double usx) {
 __device__ __forceinline__ void chain_workgroup(const Dev& d, ChainLds<CH_EPT>& L) {
     State* st = d.st;
     if (!st->chain_pending) return;
-    const double usx = block_chain_sum<CH_EPT>(d.chain, st->chain_m, CH_GUARD_BITS, L, nullptr);
+    const double usx = block_chain_sum2<CH_EPT>(d.chain, st->chain_m, CH_GUARD_BITS, L, nullptr);
     if (threadIdx.x == 0) {
         chain_deliver(d, usx);
         __threadfence();
@@ -1941,7 +2208,7 @@ __global__ __launch_bounds__(CH_T) void k_finalize(Dev d) {
     State* st = d.st;
     if (!st->ev_active || st->stall) return;
     double usx = 0.0;
-    if (!st->ev_finish) usx = block_chain_sum<CH_EPT>(d.chain, st->m, CH_GUARD_BITS, L, nullptr);
+    if (!st->ev_finish) usx = block_chain_sum2<CH_EPT>(d.chain, st->m, CH_GUARD_BITS, L, nullptr);
     if (threadIdx.x == 0) finalize(d, usx);
 }
 
@@ -1949,7 +2216,7 @@ __global__ __launch_bounds__(CH_T) void k_finalize(Dev d) {
 template <int EPT>
 __global__ __launch_bounds__(CH_T) void k_test_chain(const double* buf, int m, int guard_bits, double* out, ChainStats* stats) {
     __shared__ ChainLds<EPT> L;
-    double r = block_chain_sum<EPT>(buf, m, guard_bits, L, stats);
+    double r = g_chain_form == 1 ? block_chain_sum<EPT>(buf, m, guard_bits, L, stats) : block_chain_sum2<EPT>(buf, m, guard_bits, L, stats);
     if (threadIdx.x == 0) *out = r;
 }
 
@@ -2619,6 +2886,9 @@ int32_t fnn_test_chain_sum(int32_t device, const double* host_buf, int32_t m, in
         int stop = 0;
         if (const char* ev = std::getenv("FNN_CHAIN_STOP")) stop = std::atoi(ev);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(fnn::g_chain_stop_after), &stop, sizeof(int));
+        int form = stop ? 1 : 2;
+        if (const char* ev = std::getenv("FNN_CHAIN_FORM")) form = std::atoi(ev);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(fnn::g_chain_form), &form, sizeof(int));
     }
     hipLaunchKernelGGL(fnn::k_test_chain<fnn::CH_EPT>, dim3(1), dim3(fnn::CH_T), 0, 0, dbuf, m, guard_bits, dout, dst);
     e = hipDeviceSynchronize();

@@ -616,11 +616,62 @@ static double chain_model(const double* buf, int m, int ept, int guard_bits, fnn
     return s;
 }
 
+// CPU model of the record form of the block-parallel sum (fnn_chain.h "records"; fnn_hip.hip: block_chain_sum2): the
+// same per-thread records (chain_thread_record) from a prefix that differs from the true partial sums the way the
+// GPU's tree-ordered prefix does, the same evaluation of the records, the same fallback to the first form.
+static double chain_model2(const double* buf, int m, int guard_bits, fnn::ChainStats* cs) {
+    using namespace fnn;
+    const int T = 1024, EPT = 32;
+    double s = 0.0;
+    ChainStats st{0, 0, 0, 0};
+    for (int base = 0; base < m; base += T * EPT) {
+        std::vector<ChRec> rec(T);
+        long double pre = 0.0L;
+        for (int t = 0; t < T; t++) {
+            double a[EPT];
+            int cnt = 0;
+            double loc = 0.0;
+            for (int i = 0; i < EPT; i++) {
+                const int idx = base + t * EPT + i;
+                a[i] = idx < m ? buf[idx] : 0.0;
+                if (idx < m) cnt++;
+                loc += a[i];
+            }
+            const double A0 = (double)((long double)s + pre);
+            pre += (long double)loc;
+            rec[t] = chain_thread_record<EPT>(a, cnt, A0, loc, guard_bits != 0);
+            if (rec[t].kind == CHR_SERIAL) st.mixed++;
+        }
+        int32_t applied = 0;
+        double s2 = s;
+        const bool ok = chain_walk_records(rec.data(), T, s2, &applied, [&](int t, double& acc) {
+            for (int i = 0; i < EPT; i++) { const int idx = base + t * EPT + i; if (idx < m) acc += buf[idx]; }
+        });
+        if (!ok) {  // a verification failed: the whole sum through the first form
+            ChainStats c1{0, 0, 0, 0};
+            const double r = chain_model(buf, m, EPT, guard_bits, &c1);
+            st.runs += c1.runs; st.mixed += c1.mixed; st.run_fail += 1 + c1.run_fail; st.thread_fail += c1.thread_fail;
+            if (cs) *cs = st;
+            return r;
+        }
+        st.runs += applied;
+        s = s2;
+    }
+    if (cs) *cs = st;
+    return s;
+}
+
 extern "C" {
 
 double emu_chain_model(const double* buf, int32_t m, int32_t ept, int32_t guard_bits, int32_t* stats4) {
     fnn::ChainStats cs;
     double r = chain_model(buf, m, ept, guard_bits, &cs);
+    if (stats4) { stats4[0] = cs.runs; stats4[1] = cs.mixed; stats4[2] = cs.run_fail; stats4[3] = cs.thread_fail; }
+    return r;
+}
+double emu_chain_model2(const double* buf, int32_t m, int32_t guard_bits, int32_t* stats4) {
+    fnn::ChainStats cs;
+    double r = chain_model2(buf, m, guard_bits, &cs);
     if (stats4) { stats4[0] = cs.runs; stats4[1] = cs.mixed; stats4[2] = cs.run_fail; stats4[3] = cs.thread_fail; }
     return r;
 }

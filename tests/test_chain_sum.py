@@ -12,6 +12,8 @@ def _fns(emu_api):
     lib = emu_api.lib
     lib.emu_chain_model.restype = C.c_double
     lib.emu_chain_model.argtypes = [C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+    lib.emu_chain_model2.restype = C.c_double
+    lib.emu_chain_model2.argtypes = [C.POINTER(C.c_double), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     lib.emu_chain_serial.restype = C.c_double
     lib.emu_chain_serial.argtypes = [C.POINTER(C.c_double), C.c_int32]
     return lib
@@ -63,3 +65,25 @@ def test_chain_model_is_bit_exact(emu_api, ept, guard):
     assert seen[3] < 1000000  # the integer form of the run update agreed with the fp64 form everywhere
     if guard == 0:
         assert seen[2] > 0 and seen[3] > 0  # mispredicted runs / threads were rejected and redone one by one
+
+
+@pytest.mark.parametrize("guard", [22, 0])
+def test_record_form_is_bit_exact(emu_api, guard):
+    """The second form (one special addend per chunk + merged constants, fnn_chain.h "records"): same inputs, same bar;
+    on the engine-like inputs almost no chunk is left to be added one by one."""
+    lib = _fns(emu_api)
+    seen = np.zeros(4, dtype=np.int64)
+    for name, v in chain_cases().items():
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        p = v.ctypes.data_as(C.POINTER(C.c_double))
+        st = (C.c_int32 * 4)()
+        got = lib.emu_chain_model2(p, len(v), guard, st)
+        ref = lib.emu_chain_serial(p, len(v))
+        a, b = np.array([got]).view(np.int64)[0], np.array([ref]).view(np.int64)[0]
+        assert a == b or (np.isnan(got) and np.isnan(ref)), (name, got, ref, list(st))
+        seen += np.array(list(st))
+        if name == "uniform_32768" and guard:
+            assert st[1] <= 3 and st[2] == 0, list(st)  # (the first chunk crosses several binades; no fallback)
+    assert seen[0] > 0 and seen[1] > 0
+    if guard == 0:
+        assert seen[2] > 0  # mispredictions were caught by the verification and went through the first form
