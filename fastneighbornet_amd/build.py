@@ -94,7 +94,8 @@ def build_host(force: bool = False) -> None:
 def build(force: bool = False) -> str:
     if force or stale():
         check_isa()
-        cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC, SRC_SPLITS]
+        # (rocBLAS / rocSOLVER: triangular solves and the Cholesky factorisation of the split-weight solver)
+        cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC, SRC_SPLITS, "-lrocblas", "-lrocsolver"]
         subprocess.check_call(cmd)
     build_host(force)
     return LIB

@@ -80,8 +80,10 @@ def canonical_order(D: np.ndarray, device: int = 0, validate: bool = True) -> np
 
 def split_weights(D: np.ndarray, ordering: np.ndarray, device: int = 0):
     """Non-negative least-squares weights of the circular splits of `ordering` over
-    `fnn_split_weights_f64` (CircularSplitWeights.java's method; index order of the reference's live
-    path, FastNN.java:405-419).  Returns (weights[n(n-1)/2], stats dict)."""
+    `fnn_split_weights_f64` (the optimum the reference's live path computes, FastNN.java:401-454, in its
+    index order :405-419).  Returns (weights[n(n-1)/2], stats dict); stats["method"]: "closed form"
+    (the unconstrained optimum is feasible), "from below" (Lawson-Hanson with a dense Cholesky factor of
+    the free set) or "reference" (CircularSplitWeights.java's active-set / conjugate-gradient method)."""
     from . import api
     a = api()
     D = np.ascontiguousarray(D, dtype=np.float64)
@@ -91,4 +93,7 @@ def split_weights(D: np.ndarray, ordering: np.ndarray, device: int = 0):
     st = _capi.FnnSwStats()
     a.check(a.split_weights_f64(D.ctypes.data_as(C.POINTER(C.c_double)), n, n, o.ctypes.data_as(C.POINTER(C.c_int32)),
                                 device, w.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)))
-    return w, {k: getattr(st, k) for k, _ in st._fields_ if k != "reserved"}
+    out = {k: getattr(st, k) for k, _ in st._fields_ if k != "reserved"}
+    out["method"] = "from below" if st.reserved[0] == 1 else ("reference" if st.cg_calls > 0 else "closed form")
+    out["refactorizations"] = int(st.reserved[1])
+    return w, out

@@ -217,19 +217,24 @@ int32_t fnn_comm_init_host(fnn_handle* h, int32_t world, int32_t rank, fnn_allga
 /* ---- circular split weights ------------------------------------------------
  * Non-negative least-squares weights of the n(n-1)/2 circular splits of `ordering` (the array
  * fnn_run returns: n + 1 entries, [1..n] = 1-based taxon ids in circular order) for the symmetric
- * n x n distances D (host memory, row stride ld).  Algorithm of CircularSplitWeights.java
- * (active-set method around a conjugate-gradient solve with the implicit operators A b, A^T y;
- * Chepoi-Fichet start) with the re-ordering of the distances restored; weights_out has n(n-1)/2
+ * n x n distances D (host memory, row stride ld): the unique optimum that the reference's live path
+ * computes with a dense design matrix (FastNN.java:401-454), here on the implicit operators A b, A^T y
+ * of CircularSplitWeights.java (2-D prefix sums) with the re-ordering of the distances restored.
+ * Three routes to the same optimum: the Chepoi-Fichet closed form when it is feasible; "from below"
+ * (Lawson-Hanson: the free set grows one split at a time, its normal equations - closed-form entries -
+ * solved exactly through a dense Cholesky factor; right for distances that are far from circular, where
+ * only ~2 n splits end up positive); CircularSplitWeights.java's own active-set / conjugate-gradient
+ * method (from above) where the free set is too large for a dense factor.  weights_out has n(n-1)/2
  * entries in the index order of the reference's live path (FastNN.java:405-419): k runs over
  * (i, j), 0 <= i < j <= n-1, row-major, split k = taxa ordering[i+1 .. j] against the rest.  The
  * reference keeps the splits with weight > 1e-6 (FastNN.java:455). */
 typedef struct fnn_sw_stats {
-    int64_t outer_iterations; /* passes of the active-set loop (a constraint is released per pass) */
+    int64_t outer_iterations; /* from below: steps (a split enters the free set per step); reference method: passes of its active-set loop */
     int64_t cg_calls;         /* conjugate-gradient solves */
     int64_t cg_iterations;    /* ... and their iterations (each applies A and A^T once) */
     int64_t nsplits;          /* weights above 1e-6 */
     double  t_solve_s;        /* device time from the re-ordered distances to the weights */
-    int64_t reserved[3];
+    int64_t reserved[3];      /* [0] 1 = solved from below, [1] Cholesky factorisations from scratch, [2] - */
 } fnn_sw_stats;
 int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ld, const int32_t* ordering, int32_t device,
                               double* weights_out, fnn_sw_stats* stats);
