@@ -38,7 +38,7 @@ typedef enum fnn_status {
     FNN_EINVAL  = -1,  /* bad argument / matrix not symmetric, not finite, non-zero diagonal */
     FNN_ENOMEM  = -2,  /* host or device allocation failed */
     FNN_EHIP    = -3,  /* HIP runtime error or no device */
-    FNN_ERCCL   = -4,  /* reserved: collective error (multi-GPU) */
+    FNN_ERCCL   = -4,  /* collective error (several GPUs: RCCL or the host callback) */
     FNN_ESTATE  = -5   /* call sequence error (e.g. run before the matrix is set) */
 } fnn_status;
 
@@ -132,7 +132,9 @@ int32_t fnn_set_rows(fnn_handle* h, int32_t row0, int32_t nrows, const double* r
  * a(n-1) - a(a-1)/2 + b - (a+1), DistancesAndNames.java:24-38).  Replaces the dense expansion of
  * FastNN.java:307-312: half the bytes cross the bus, the device mirrors the triangle itself. */
 int32_t fnn_set_packed_upper(fnn_handle* h, const double* packed);
-/* Same from DEVICE memory (whole matrix, row stride ld_in doubles). */
+/* Same from DEVICE memory (whole matrix, row stride ld_in doubles).  The copy runs on the engine's own (non-blocking)
+ * stream, which is NOT ordered against the stream that produced d_matrix: synchronise the producer (stream or device)
+ * before this call.  The call returns after the copy has completed. */
 int32_t fnn_set_matrix_device(fnn_handle* h, const double* d_matrix, int64_t ld_in);
 /* Fill the device matrix with the synthetic generator of SURVEY.md 8(d)
  * (SplitMix64; dist 0 = uniform53, 1 = dec4), bit-identical to the host generator. */
@@ -194,18 +196,23 @@ int32_t fnn_get_kernel_times(fnn_handle* h, double* ms8, int64_t* launches8);
 int32_t fnn_canonical_order_f64(const double* D, int32_t n, int64_t ld, const fnn_opts* opts,
                                 int32_t* order_out, fnn_stats* stats);
 
-/* ---- several GPUs of one node (one process per GPU) ------------------------------------
- * Every rank holds the whole matrix (8 GiB at n = 32768, 3 % of an MI355X) and scans 1/world
- * of the tiles of each event; ONE 16-byte record per rank is all-gathered per event (the
- * global Q-argmin) and every rank then applies the same deterministic update to its own copy,
- * so no matrix row ever crosses xGMI.  All ranks must upload the same matrix and make the same
- * calls; every rank returns the same order.
+/* ---- several GPUs of one node (one process per GPU): ONE problem on all ranks -----------------
+ * Every rank holds the whole matrix (8 GiB at n = 32768, 3 % of an MI355X) and runs the whole event chain
+ * itself (the ranks stay in step because every decision is a deterministic function of identical state), so no
+ * matrix row ever crosses xGMI.  All ranks must upload the same matrix and make the same calls; every rank
+ * returns the same order.  What is shared out:
+ *   - with lookahead windows (a screening copy exists: n >= 4096, lookahead not off): only the BASE SCANS of the
+ *     windows, by screening-tile index mod world; each is followed by ONE all-gather of a fixed block per rank -
+ *     16 B header + 64 candidate records of 24 B + 65536 / world tracked-pair records of 16 B - after which every
+ *     rank builds the same tracked list and reduces the same candidate records;
+ *   - without windows: the scan of every event, by tile index mod world, with one all-gather of <= 64 candidate
+ *     records (24 B each) per rank and event.
  *
  * fnn_comm_unique_id: rank 0 creates the 128-byte RCCL id and the caller ships it to the other
  * ranks (bench.py uses torch.distributed for that).  fnn_comm_init_rccl: collective over all
- * ranks; the all-gather then runs as ncclAllGather on the engine's stream (no host round
+ * ranks; the all-gathers then run as ncclAllGather on the engine's stream (no host round
  * trip).  rccl_path may name the librccl.so to dlopen (NULL: default search).
- * fnn_comm_init_host: test transport - the engine synchronises once per event and calls
+ * fnn_comm_init_host: test transport - the engine synchronises once per exchange and calls
  * `fn(ctx, send, recv, bytes_per_rank)` on the host, which must fill recv with every rank's
  * `send` in rank order and return 0. */
 #define FNN_COMM_ID_BYTES 128

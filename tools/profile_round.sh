@@ -1,22 +1,36 @@
 #!/bin/bash
-# Round measurements on the GPU box: bench line, rocprofv3 kernel stats of the same command, PMC passes
-# (FETCH_SIZE / WRITE_SIZE in separate runs, as MI355X_MICROARCH.md prescribes) over the scheduled screening
-# launches.  usage: tools/profile_round.sh <tag>   (writes under gpurun_out/)
+# Round measurements on the GPU box (everything lands under gpurun_out/<tag>_*; copy what is to be kept to profiles/<round>/):
+#   1. the bench line (python3 bench.py);
+#   2. rocprofv3 --kernel-trace --stats of the same command (without the CPU baseline and the extra chain run);
+#   3. PMC passes over the scheduled screening launches (FETCH_SIZE / WRITE_SIZE in separate runs, as MI355X_MICROARCH.md
+#      prescribes) -> HBM bytes per launch vs the algorithmic bytes;
+#   4. the event-chain evidence: per-event-kind table of kernel durations and gaps (tools/profile_chain.sh) at 32768 and 4096,
+#      and the in-kernel phase split of k_track / k_update (FNN_TICKS=1);
+#   5. the split-weight solver: kernel stats of one solve at 2048 taxa.
+# usage: tools/profile_round.sh <tag>
 set -o pipefail
-TAG=${1:-la}
+TAG=${1:-r02}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd $GRAFT_REPO_ROOT
-python3 bench.py --steps 1 --warmup 1 > $OUT/bench_${TAG}.json 2> $OUT/bench_${TAG}.err || exit 1
-tail -c 1500 $OUT/bench_${TAG}.json
+python3 bench.py --steps 1 --warmup 1 > $OUT/${TAG}_bench_n32768.json 2> $OUT/${TAG}_bench.err || exit 1
+tail -c 600 $OUT/${TAG}_bench_n32768.json; echo
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/bench_${TAG}_prof.json 2> $OUT/rocprof_${TAG}.err || exit 2
-find /tmp/prof_${TAG} -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
-find /tmp/prof_${TAG} -name "*domain_stats.csv" -exec cp {} $OUT/${TAG}_domain_stats.csv \;
-head -14 $OUT/${TAG}_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-chain > $OUT/${TAG}_bench_under_rocprof_n32768.json 2> $OUT/${TAG}_rocprof.err || exit 2
+find /tmp/prof_${TAG} -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats_n32768.csv \;
+find /tmp/prof_${TAG} -name "*domain_stats.csv" -exec cp {} $OUT/${TAG}_domain_stats_n32768.csv \;
+head -12 $OUT/${TAG}_kernel_stats_n32768.csv | cut -c1-140
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-include-regex "k_screen<true, true>" --output-format csv -d /tmp/pmc_${TAG}_$C -- python3 $GRAFT_REPO_ROOT/tools/quick_perf.py 32768 > $OUT/pmc_${TAG}_$C.log 2>&1 || exit 3
-  find /tmp/pmc_${TAG}_$C -name "*counter_collection.csv" -exec cp {} $OUT/pmc_${TAG}_$C.csv \;
-  grep total= $OUT/pmc_${TAG}_$C.log | cut -c1-120
+  rocprofv3 --pmc $C --kernel-include-regex "k_screen<true, true>" --output-format csv -d /tmp/pmc_${TAG}_$C -- python3 $GRAFT_REPO_ROOT/tools/quick_perf.py 32768 > $OUT/${TAG}_pmc_$C.log 2>&1 || exit 3
+  find /tmp/pmc_${TAG}_$C -name "*counter_collection.csv" -exec cp {} /tmp/pmc_${TAG}_$C.csv \;
+  grep total= $OUT/${TAG}_pmc_$C.log | cut -c1-120
 done
-BYTES=$(grep -o "timed_screen_bytes=[0-9]*" $OUT/pmc_${TAG}_FETCH_SIZE.log | cut -d= -f2)
-python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/pmc_${TAG}_FETCH_SIZE.csv $OUT/pmc_${TAG}_WRITE_SIZE.csv $BYTES $OUT/pmc_${TAG}_summary.json "k_screen<true, true>"
+BYTES=$(grep -o "timed_screen_bytes=[0-9]*" $OUT/${TAG}_pmc_FETCH_SIZE.log | cut -d= -f2)
+python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py /tmp/pmc_${TAG}_FETCH_SIZE.csv /tmp/pmc_${TAG}_WRITE_SIZE.csv $BYTES $OUT/${TAG}_pmc_screen_windows_summary_n32768.json "k_screen<true, true>" | cut -c1-400
+cd $GRAFT_REPO_ROOT
+bash tools/profile_chain.sh ${TAG} 32768 > $OUT/${TAG}_chain_32768.log 2>&1; grep -E "window" $OUT/${TAG}_chain_32768.log | cut -c1-260
+bash tools/profile_chain.sh ${TAG} 4096 > $OUT/${TAG}_chain_4096.log 2>&1; grep -E "window" $OUT/${TAG}_chain_4096.log | cut -c1-260
+FNN_TICKS=1 python3 tools/quick_perf.py 4096 16384 32768 > $OUT/${TAG}_ticks.log 2>&1; cut -c1-220 $OUT/${TAG}_ticks.log
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_sw_${TAG} -- python3 $GRAFT_REPO_ROOT/tests/tools/splits_perf.py 2048 > $OUT/${TAG}_splits_perf_n2048.log 2>&1
+find /tmp/prof_sw_${TAG} -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_splits_kernel_stats_n2048.csv \;
+tail -1 $OUT/${TAG}_splits_perf_n2048.log; head -8 $OUT/${TAG}_splits_kernel_stats_n2048.csv | cut -c1-140
