@@ -191,7 +191,7 @@ struct Dev {
     int32_t* clist;  // screening: units that may hold the true minimum
     int32_t* islot;  // lookahead: node id -> slot (-1: dead); 3n + 8 entries
     int32_t* cstamp; // lookahead: node id -> n_events + 1 when its current cluster was formed (0: initial)
-    int32_t* tpairs; // lookahead: tracked pairs {id a | paired bit, id b | paired bit, slot hint a, slot hint b} (LA_PCAP records)
+    int32_t* tpairs; // lookahead: tracked pairs, LA_PCAP records of LA_REC_INTS ints (la_record: ids, slot hints, the pair's 2 x 2 entries)
     int32_t* fresh;  // lookahead: per fresh cluster {representative id, stamp, slot} (LA_KMAX entries)
     uint32_t* ticket; // lookahead: arrival counter of k_track's workgroups
     int64_t* ticks;  // diagnostics (FNN_TICKS=1), 100 MHz ticks summed over events: [0..7] k_track's last workgroup, [8..15] k_update
@@ -520,6 +520,7 @@ FNN_HD void store_d(const Dev& d, int64_t r, int64_t c, double v) {
 // ---------------------------------------------------------------------------
 constexpr int LA_KMAX = 512;      // fresh clusters per window (>= K)
 constexpr int LA_PCAP = 65536;    // tracked pairs per window
+constexpr int LA_REC_INTS = 12;   // a tracked-pair record: 48 bytes (la_record)
 constexpr int LA_LOGCAP = 8192;   // diagnostic records (one per base scan)
 
 // Several ranks with lookahead windows: the matrix and the whole event chain are replicated; only a BASE SCAN is
@@ -531,7 +532,7 @@ constexpr int WX_HDR_WORDS = 4;
 FNN_HD int32_t wx_pair_cap(int32_t world) { return LA_PCAP / (world > 0 ? world : 1); }
 FNN_HD int64_t wx_recs_off() { return (int64_t)sizeof(int32_t) * WX_HDR_WORDS; }
 FNN_HD int64_t wx_pairs_off() { return wx_recs_off() + (int64_t)sizeof(Cand) * GATHER_RECS; }
-FNN_HD int64_t wx_block_bytes(int32_t world) { return wx_pairs_off() + 16 * (int64_t)wx_pair_cap(world); }
+FNN_HD int64_t wx_block_bytes(int32_t world) { return wx_pairs_off() + (int64_t)sizeof(int32_t) * LA_REC_INTS * (int64_t)wx_pair_cap(world); }
 
 // slack between the fp32 lower bound and the true fp64 Q over the window: the screening slack
 // (screen_delta, applied twice for good measure) plus the rounding drift of the row sums
@@ -611,23 +612,37 @@ FNN_HD void la_close_base(State& st, double* lalog, const int32_t* lacnt) {
     if (st.la_W > wmax) st.la_W = wmax;
 }
 
-// A tracked pair: the two representatives' node ids with their "paired" status in the top bit, and the slots
-// they sat in when the pair was recorded (hints: the tracking pass fetches the pair's matrix block at the
-// hinted slots while it checks that the ids still sit there; only a moved node costs a look-up in islot).
+// A tracked pair (48 bytes): the two representatives' node ids with their "paired" status in the top bit, the slots
+// they sat in when the pair was recorded (hints: the tracking pass checks that the ids still sit there; only a moved node
+// costs a look-up in islot), and the pair's 2 x 2 block of matrix entries D[a][b], D[a][b'], D[a'][b], D[a'][b']
+// (a', b' the partners; unused entries 0).  The window's premise is that the distance of two clusters that take part in
+// no event does not change - slot moves copy entries bit for bit - so the entries are fetched ONCE, when the pair is
+// recorded, and the tracking pass of the following events reads no matrix entry at all: a record, two row sums, two
+// positions (all from small, cache-resident arrays) instead of two random 16-byte reads in an 8 GiB matrix.
 // A live node's cluster changes in one way only - a singleton becomes paired - so "same id, same paired
 // status" means "same cluster" (a paired node keeps its partner until both disappear in a merge).
 constexpr int32_t LA_PAIRED_BIT = (int32_t)0x80000000u;
 FNN_HD void la_record(const Dev& d, int32_t* t, int32_t rs, int32_t cs, int32_t twoP) {
-    t[0] = d.sid[rs] | (rs < twoP ? LA_PAIRED_BIT : 0);
-    t[1] = d.sid[cs] | (cs < twoP ? LA_PAIRED_BIT : 0);
+    const bool pa = rs < twoP, pb = cs < twoP;
+    t[0] = d.sid[rs] | (pa ? LA_PAIRED_BIT : 0);
+    t[1] = d.sid[cs] | (pb ? LA_PAIRED_BIT : 0);
     t[2] = rs;
     t[3] = cs;
+    const double* R0 = d.D + (int64_t)rs * d.ld;
+    const double* R1 = R0 + d.ld;  // (rows are padded: rs + 1 is in bounds)
+    double e[4];
+    e[0] = R0[cs];
+    e[1] = pb ? R0[cs + 1] : 0.0;
+    e[2] = pa ? R1[cs] : 0.0;
+    e[3] = (pa && pb) ? R1[cs + 1] : 0.0;
+    double* te = reinterpret_cast<double*>(t + 4);
+    te[0] = e[0]; te[1] = e[1]; te[2] = e[2]; te[3] = e[3];
 }
 // append the pair of the representatives in slots rs, cs to the window's tracked list
 FNN_HD void la_append(const Dev& d, int32_t rs, int32_t cs, int32_t twoP) {
     State& st = *d.st;
     const int32_t i = FNN_ATOMIC_INC(d.lacnt);
-    if (i < st.la_pcap) la_record(d, d.tpairs + 4 * (int64_t)i, rs, cs, twoP);
+    if (i < st.la_pcap) la_record(d, d.tpairs + LA_REC_INTS * (int64_t)i, rs, cs, twoP);
 }
 
 // After the exchange of a sharded base scan: the tracked list from all ranks' emitted pairs, all ranks' candidate
@@ -653,7 +668,7 @@ FNN_HD void wx_merge(const Dev& d) {
         for (int32_t r = 0; r < d.world; r++) {
             const int32_t* h = reinterpret_cast<const int32_t*>(d.wrecv + r * bb);
             const int32_t* src = reinterpret_cast<const int32_t*>(d.wrecv + r * bb + wx_pairs_off());
-            for (int64_t i = 0; i < 4 * (int64_t)h[0]; i++) d.tpairs[4 * off + i] = src[i];
+            for (int64_t i = 0; i < LA_REC_INTS * (int64_t)h[0]; i++) d.tpairs[LA_REC_INTS * off + i] = src[i];
             off += h[0];
         }
     }
@@ -681,26 +696,6 @@ FNN_HD void la_note_cluster(const Dev& d, State& st, int32_t rep, int32_t partne
         if (st.la_nf < LA_KMAX) { d.fresh[3 * st.la_nf] = rep; d.fresh[3 * st.la_nf + 1] = stamp; d.fresh[3 * st.la_nf + 2] = st.U; }
         st.la_nf++;  // beyond LA_KMAX the window is no longer served (la_active)
     }
-}
-
-// exact evaluation of the micro-tile that holds the pair of the nodes in slots sa, sb: the scan's
-// own body on the same entries (the tile may hold up to three more live pairs: harmless extras)
-struct PairOps {
-    int32_t r0, c0;
-    double e00, e01, e10, e11, sxr0, sxr1, sxc0, sxc1;
-    int32_t pr0, pr1, pc0, pc1;
-};
-FNN_HD void pair_load(const Dev& d, int32_t sa, int32_t sb, PairOps& o) {
-    o.r0 = (sa > sb ? sa : sb) & ~1; o.c0 = (sa > sb ? sb : sa) & ~1;
-    const double* R0 = d.D + (int64_t)o.r0 * d.ld + o.c0;
-    const double* R1 = R0 + d.ld;  // rows are padded to an even count: r0 + 1 is always in bounds
-    o.e00 = R0[0]; o.e01 = R0[1]; o.e10 = R1[0]; o.e11 = R1[1];
-    o.sxr0 = d.Sx[o.r0]; o.sxr1 = d.Sx[o.r0 + 1]; o.sxc0 = d.Sx[o.c0]; o.sxc1 = d.Sx[o.c0 + 1];
-    o.pr0 = d.spos[o.r0]; o.pr1 = d.spos[o.r0 + 1]; o.pc0 = d.spos[o.c0]; o.pc1 = d.spos[o.c0 + 1];
-}
-FNN_HD void pair_eval(const PairOps& o, int32_t m, int32_t twoP, double cm2, Cand& best) {
-    scan_micro(o.r0, o.c0, m, twoP, cm2, o.e00, o.e01, o.e10, o.e11, o.sxr0, o.sxr1, o.pr0, o.pr1,
-               o.sxc0, o.sxc1, o.pc0, o.pc1, best);
 }
 
 // all pairs between the fresh two-node cluster in slots (f0, f0 + 1) and the node(s) in slots
@@ -760,29 +755,43 @@ FNN_HD TrackArgs track_args(const State& st) {
     return a;
 }
 FNN_HD int64_t track_item_count(const TrackArgs& a) { return (int64_t)a.np + (int64_t)(a.nf - a.nf0) * ((a.m + 1) / 2); }
-// a tracked pair: evaluated exactly if both clusters still exist unchanged
-struct PairRec { int32_t wa, wb, sa, sb; };
+// a tracked pair: evaluated exactly if both clusters still exist unchanged - the scan's own expressions
+// (scan_micro_t: the 1-, 2- or 4-term cluster distance in the reference's term order, Q with the row sums taken by
+// reference position, the (Q, i, j) tie-break) on the entries the record carries
+struct PairRec { int32_t wa, wb, sa, sb; double e[4]; };
 FNN_HD PairRec track_pair_load(const Dev& d, int64_t item) {
-    const int32_t* t = d.tpairs + 4 * item;
+    const int32_t* t = d.tpairs + LA_REC_INTS * item;
     PairRec r;
     r.wa = t[0]; r.wb = t[1]; r.sa = t[2]; r.sb = t[3];
+    const double* te = reinterpret_cast<const double*>(t + 4);
+    r.e[0] = te[0]; r.e[1] = te[1]; r.e[2] = te[2]; r.e[3] = te[3];
     return r;
 }
 FNN_HD void track_pair_rec(const Dev& d, const PairRec& r, const TrackArgs& a, Cand& best) {
     const int32_t wa = r.wa, wb = r.wb;
     const int32_t ia = wa & ~LA_PAIRED_BIT, ib = wb & ~LA_PAIRED_BIT;
     int32_t sa = r.sa, sb = r.sb;
-    PairOps o;
     // (a slot beyond the live range may still carry the id of a node that was moved out of it)
-    const bool inr = sa >= 0 && sb >= 0 && sa < a.m && sb < a.m;
-    if (inr) pair_load(d, sa, sb, o);  // (at the hinted slots, beside the check that the nodes still sit there)
-    if (!inr || d.sid[sa] != ia || d.sid[sb] != ib) {
+    if (!(sa >= 0 && sb >= 0 && sa < a.m && sb < a.m) || d.sid[sa] != ia || d.sid[sb] != ib) {
         sa = d.islot[ia]; sb = d.islot[ib];
         if (sa < 0 || sb < 0) return;  // a cluster is gone
-        pair_load(d, sa, sb, o);
     }
-    if ((sa < a.twoP) != (wa < 0) || (sb < a.twoP) != (wb < 0)) return;  // a singleton has become half of a new cluster
-    pair_eval(o, a.m, a.twoP, a.cm2, best);
+    const bool pa = wa < 0, pb = wb < 0;
+    if ((sa < a.twoP) != pa || (sb < a.twoP) != pb) return;  // a singleton has become half of a new cluster
+    const double sxa = d.Sx[sa], sxb = d.Sx[sb];
+    const int32_t posa = d.spos[sa], posb = d.spos[sb];
+    // e[.] = D[a][b], D[a][b'], D[a'][b], D[a'][b'].  The scan meets the pair in the micro-tile whose ROWS are the
+    // cluster in the larger slots; entry (row node i, column node j) of that tile:
+    const bool arow = sa > sb;
+    const double e00 = r.e[0], e01 = arow ? r.e[1] : r.e[2], e10 = arow ? r.e[2] : r.e[1], e11 = r.e[3];
+    const double sxr = arow ? sxa : sxb, sxc = arow ? sxb : sxa;
+    const int32_t pr = arow ? posa : posb, pc = arow ? posb : posa;
+    const int32_t srow = arow ? sa : sb, scol = arow ? sb : sa;
+    double dpq;
+    if (pa && pb) dpq = pr > pc ? (((e00 + e01) + e10) + e11) / 4.0 : (((e00 + e10) + e01) + e11) / 4.0;  // (:169)
+    else if (pa || pb) dpq = (e00 + (pa == arow ? e10 : e01)) / 2.0;  // singleton x pair: the singleton's two entries (:165/:167)
+    else dpq = e00;                                                    // (:163)
+    consider(qval(a.cm2, dpq, sxr, pr, sxc, pc), pr, pc, srow, scol, best);
 }
 FNN_HD void track_pair_item(const Dev& d, int64_t item, const TrackArgs& a, Cand& best) {
     track_pair_rec(d, track_pair_load(d, item), a, best);

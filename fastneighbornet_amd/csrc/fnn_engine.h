@@ -91,7 +91,7 @@ class Engine {
             !(dev.clist = (int32_t*)be.alloc(sizeof(int32_t) * SCR_CAP)) ||
             !(dev.islot = (int32_t*)be.alloc(sizeof(int32_t) * (3 * nn + 8))) ||
             !(dev.cstamp = (int32_t*)be.alloc(sizeof(int32_t) * (3 * nn + 8))) ||
-            !(dev.tpairs = (int32_t*)be.alloc(sizeof(int32_t) * 4 * LA_PCAP)) ||
+            !(dev.tpairs = (int32_t*)be.alloc(sizeof(int32_t) * LA_REC_INTS * LA_PCAP)) ||
             !(dev.fresh = (int32_t*)be.alloc(sizeof(int32_t) * 3 * LA_KMAX)) ||
             !(dev.ticket = (uint32_t*)be.alloc(sizeof(uint32_t) * 32 * 72)) ||
             !(dev.lacnt = (int32_t*)be.alloc(256)) ||

@@ -46,20 +46,41 @@ constexpr int SCAN_TH = 32;   // rows per scan tile
 constexpr int SCAN_THREADS = 256;
 
 // ------------------------------------------------------------------ reductions
-// minimum of the wave on the total order (Q, i, j); valid in every lane.  Only (q, key) travel through the
-// shuffles; the slots of the winning pair are read from a lane that contributed it (a key names one pair).
+// minimum of the wave on the total order (Q, i, j); valid in every lane.  Only (q, key) are reduced; the slots of the
+// winning pair are read from a lane that contributed it (a key names one pair).  The reduction runs on DPP moves
+// (row_shr 1, 2, 4, 8, then row_bcast 15 / 31: the result lands in lane 63) instead of __shfl_down, which hipcc lowers to
+// ds_bpermute: ~100 cycles of LDS-crossbar latency per dependent step, and k_track does four such reductions on its
+// critical path.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_pull(double q, uint64_t key, double& oq, uint64_t& ok) {
+    const uint64_t qb = __builtin_bit_cast(uint64_t, q);
+    const int ql = (int)(uint32_t)qb, qh = (int)(uint32_t)(qb >> 32), kl = (int)(uint32_t)key, kh = (int)(uint32_t)(key >> 32);
+    // (lanes without a source - out of the row, or rows not selected by the mask - keep their own value: no change under min)
+    const uint32_t oql = (uint32_t)__builtin_amdgcn_update_dpp(ql, ql, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t oqh = (uint32_t)__builtin_amdgcn_update_dpp(qh, qh, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t okl = (uint32_t)__builtin_amdgcn_update_dpp(kl, kl, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t okh = (uint32_t)__builtin_amdgcn_update_dpp(kh, kh, CTRL, ROW_MASK, 0xf, false);
+    oq = __builtin_bit_cast(double, ((uint64_t)oqh << 32) | oql);
+    ok = ((uint64_t)okh << 32) | okl;
+}
 __device__ __forceinline__ Cand wave_reduce(Cand c) {
     double q = c.q;
     uint64_t key = c.key;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double oq = __shfl_down(q, off, 64);
-        const uint64_t ok = (uint64_t)__shfl_down((unsigned long long)key, off, 64);
-        if (oq < q || (oq == q && ok < key)) { q = oq; key = ok; }
-    }
+#define FNN_DPP_STEP(CTRL, MASK) do { double oq; uint64_t ok; dpp_pull<CTRL, MASK>(q, key, oq, ok); \
+        if (oq < q || (oq == q && ok < key)) { q = oq; key = ok; } } while (0)
+    FNN_DPP_STEP(0x111, 0xf);  // row_shr:1
+    FNN_DPP_STEP(0x112, 0xf);  // row_shr:2
+    FNN_DPP_STEP(0x114, 0xf);  // row_shr:4
+    FNN_DPP_STEP(0x118, 0xf);  // row_shr:8   -> lane 15 of every row of 16 holds the row's minimum
+    FNN_DPP_STEP(0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+    FNN_DPP_STEP(0x143, 0xc);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's minimum
+#undef FNN_DPP_STEP
     Cand r;
-    r.q = __shfl(q, 0, 64);
-    r.key = (uint64_t)__shfl((unsigned long long)key, 0, 64);
+    const uint64_t qb = __builtin_bit_cast(uint64_t, q);
+    const uint32_t rql = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)qb, 63), rqh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(qb >> 32), 63);
+    const uint32_t rkl = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 63), rkh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), 63);
+    r.q = __builtin_bit_cast(double, ((uint64_t)rqh << 32) | rql);
+    r.key = ((uint64_t)rkh << 32) | rkl;
     const unsigned long long src = __ballot(c.key == r.key);
     const int l = src ? (int)__builtin_ctzll(src) : 0;
     r.si = __builtin_amdgcn_readlane(c.si, l);
@@ -421,7 +442,7 @@ __global__ __launch_bounds__(256) void k_emit(Dev d) {
         const int idx = base + i;
         if (idx < pcap) {
             const int2 pr = lbuf[i];
-            la_record(d, outp + 4 * (int64_t)idx, pr.x, pr.y, twoP);
+            la_record(d, outp + LA_REC_INTS * (int64_t)idx, pr.x, pr.y, twoP);
         }
     }
 }
@@ -687,8 +708,8 @@ __global__ __launch_bounds__(1024) void k_merge(Dev d) {
     if (st->la_emit && !ovf) {
         for (int r = 0; r < d.world; r++) {
             const int4* src = reinterpret_cast<const int4*>(d.wrecv + r * bb + wx_pairs_off());
-            int4* dst = reinterpret_cast<int4*>(d.tpairs) + off[r];
-            for (int i = tid; i < cnt[r]; i += 1024) dst[i] = src[i];
+            int4* dst = reinterpret_cast<int4*>(d.tpairs) + (int64_t)(LA_REC_INTS / 4) * off[r];
+            for (int i = tid; i < (LA_REC_INTS / 4) * cnt[r]; i += 1024) dst[i] = src[i];
         }
     }
     for (int i = tid; i < d.world * GATHER_RECS; i += 1024) {
@@ -1664,6 +1685,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     const int64_t start = (int64_t)wg * TRK_THREADS + threadIdx.x;
     PairRec rec0;
     rec0.wa = rec0.wb = 0; rec0.sa = rec0.sb = -1;
+    rec0.e[0] = rec0.e[1] = rec0.e[2] = rec0.e[3] = 0.0;
     if (start < LA_PCAP) rec0 = track_pair_load(d, start);
     if (st->done) {
         if (wg == 0 && threadIdx.x == 0) st->ev_active = 0;  // (a launch sequence without a decide kernel must not replay the last event)

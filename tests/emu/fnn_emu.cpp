@@ -170,7 +170,7 @@ struct EmuBackend {
             if (!(st.la_emit && lb <= st.la_theta_pred)) return;
             if (!d.wx) { fnn::la_append(d, rs, cs, twoP); return; }
             const int32_t i = (*d.lacnt)++;
-            if (i < fnn::wx_pair_cap(d.world)) fnn::la_record(d, reinterpret_cast<int32_t*>(d.wsend + fnn::wx_pairs_off()) + 4 * (int64_t)i, rs, cs, twoP);
+            if (i < fnn::wx_pair_cap(d.world)) fnn::la_record(d, reinterpret_cast<int32_t*>(d.wsend + fnn::wx_pairs_off()) + fnn::LA_REC_INTS * (int64_t)i, rs, cs, twoP);
         };
         for (int32_t u : thread_order(nunits)) {
             fnn::Brk b{finf, finf};
