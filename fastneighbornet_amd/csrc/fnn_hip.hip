@@ -51,6 +51,29 @@ constexpr int SCAN_THREADS = 256;
 // (row_shr 1, 2, 4, 8, then row_bcast 15 / 31: the result lands in lane 63) instead of __shfl_down, which hipcc lowers to
 // ds_bpermute: ~100 cycles of LDS-crossbar latency per dependent step, and k_track does four such reductions on its
 // critical path.
+// A workgroup's minimum handed to the workgroup that arrives last: three 8-byte write-through stores (agent scope:
+// they leave the XCD's L2) by ONE lane, which then waits for their acknowledgement and counts its arrival; the reader
+// loads them past its L1 after its own arrival returned last.  No cache write-back or invalidate on the event chain.
+static_assert(sizeof(Cand) == 24, "rec_publish / rec_fetch move a Cand as three 8-byte words");
+__device__ inline void rec_publish(Cand* p, const Cand& c) {
+    uint64_t* w = (uint64_t*)p;
+    __hip_atomic_store(w + 0, __builtin_bit_cast(uint64_t, c.q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 1, c.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(w + 2, (uint64_t)(uint32_t)c.si | ((uint64_t)(uint32_t)c.sj << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline Cand rec_fetch(const Cand* p) {
+    uint64_t* w = (uint64_t*)p;
+    const uint64_t a = __hip_atomic_load(w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t b = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t x = __hip_atomic_load(w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    Cand c;
+    c.q = __builtin_bit_cast(double, a);
+    c.key = b;
+    c.si = (int)(uint32_t)x;
+    c.sj = (int)(uint32_t)(x >> 32);
+    return c;
+}
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void dpp_pull(double q, uint64_t key, double& oq, uint64_t& ok) {
     const uint64_t qb = __builtin_bit_cast(uint64_t, q);
@@ -1770,28 +1793,29 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
             best = wave_reduce(b2);
             if (ta.approx) bestu = wave_reduce(bu2);
             if (lane_ == 0) {
-                d.recs[wg] = best;
-                if (ta.approx) d.recs[TRK_REC_U + wg] = bestu;
+                rec_publish(&d.recs[wg], best);
+                if (ta.approx) rec_publish(&d.recs[TRK_REC_U + wg], bestu);
             }
         }
     }
     TRK_TICK(3);
     if (threadIdx.x == 0) {
-        __threadfence();
+        // the record went out write-through (rec_publish) from this very thread: once its stores are acknowledged
+        // the arrival may be counted - no release fence (a cache write-back) on the event chain
+        __builtin_amdgcn_s_waitcnt(0);
         // last of its group of TRK_GROUP workgroups -> last of the groups (counters 128 bytes apart)
         const unsigned g = (unsigned)wg / (unsigned)tgroup, ngroups = ((unsigned)G + tgroup - 1) / (unsigned)tgroup;
         const unsigned gsize = g + 1 < ngroups ? (unsigned)tgroup : (unsigned)G - g * tgroup;
         int last = 0;
         if (atomicAdd(d.ticket + 32 * (g + 1), 1u) == gsize - 1) {
-            d.ticket[32 * (g + 1)] = 0u;
-            __threadfence();
+            d.ticket[32 * (g + 1)] = 0u;  // (read again by the next launch only)
             last = atomicAdd(d.ticket, 1u) == ngroups - 1 ? 1 : 0;
         }
         lastflag = last;
     }
     __syncthreads();
     if (!lastflag) return;
-    __threadfence();
+    // (no acquire fence: the records are read past the caches, rec_fetch, after the barrier above)
     TRK_TICK(4);
     // from here on this workgroup works on its LDS copy of the control block (no other workgroup writes to it
     // during this launch); the copy goes back at the end
@@ -1805,17 +1829,10 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         bu = b;
         const unsigned badword = __hip_atomic_load(d.ticket + TRK_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int i = threadIdx.x; i < G; i += 64) {
-            Cand c;
-            c.q = __builtin_nontemporal_load(&d.recs[i].q);
-            c.key = __builtin_nontemporal_load(&d.recs[i].key);
-            c.si = __builtin_nontemporal_load(&d.recs[i].si);
-            c.sj = __builtin_nontemporal_load(&d.recs[i].sj);
+            Cand c = rec_fetch(&d.recs[i]);
             if (cand_better(c, b)) b = c;
             if (ta.approx) {
-                c.q = __builtin_nontemporal_load(&d.recs[TRK_REC_U + i].q);
-                c.key = __builtin_nontemporal_load(&d.recs[TRK_REC_U + i].key);
-                c.si = __builtin_nontemporal_load(&d.recs[TRK_REC_U + i].si);
-                c.sj = __builtin_nontemporal_load(&d.recs[TRK_REC_U + i].sj);
+                c = rec_fetch(&d.recs[TRK_REC_U + i]);
                 if (cand_better(c, bu)) bu = c;
             }
         }
