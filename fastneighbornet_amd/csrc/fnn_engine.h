@@ -65,6 +65,7 @@ class Engine {
         if (o) opts = *o;
         int32_t rc = be.open(opts.device);
         if (rc != FNN_OK) return rc;
+        be.set_problem_size(n);
         // padded geometry: rows to a multiple of the scan tile height, row stride to a
         // multiple of the tile width plus 32 doubles so that column sweeps (stride ld)
         // do not hammer one HBM channel

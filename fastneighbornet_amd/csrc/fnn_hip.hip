@@ -2343,7 +2343,17 @@ struct HipBackend {
     static constexpr int64_t kColPad = SCR_TW;   // whole screening tiles (and scan tiles) stay in bounds
     // below this many taxa the fp32 copy is not even allocated (FNN_SCREEN_MIN_N, tests)
     int32_t screen_min_n() const { if (const char* e = std::getenv("FNN_SCREEN_MIN_N")) { int v = std::atoi(e); if (v >= 8) return v; } return 4096; }
-    int screen_min_m = 2048;                     // events with fewer live nodes use the plain scan (FNN_SCREEN_MIN_M)
+    // events with fewer live nodes use the plain fp64 scan.  Windows in the end game pay while the matrix is not yet
+    // averaged out: measured, n = 4096 gains 6 % with a floor of 512-1024 (17 events per window there), n = 32768 LOSES
+    // 4 % with 1024 (after 30 000 merges the criterion values lie so close together that a window holds ~1 event).
+    // Hence min(2048, n / 4), not below 512; FNN_SCREEN_MIN_M overrides.
+    int screen_min_m = 2048;
+    bool screen_min_m_fixed = false;
+    void set_problem_size(int32_t n) {
+        if (screen_min_m_fixed) return;
+        const int v = n / 4;
+        screen_min_m = v < 512 ? 512 : (v > 2048 ? 2048 : v);
+    }
     hipError_t last = hipSuccess;
     hipStream_t stream = nullptr;
     int device = 0;
@@ -2433,7 +2443,7 @@ struct HipBackend {
         if (const char* e = std::getenv("FNN_EMIT_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) emit_grid = v; }
         if (const char* e = std::getenv("FNN_TRACK_GROUP")) { int v = std::atoi(e); if (v >= 2 && v <= 1024) track_group = v; }
         if (const char* e = std::getenv("FNN_TRACK_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 1024) track_grid = v; }
-        if (const char* e = std::getenv("FNN_SCREEN_MIN_M")) { int v = std::atoi(e); if (v >= 8) screen_min_m = v; }
+        if (const char* e = std::getenv("FNN_SCREEN_MIN_M")) { int v = std::atoi(e); if (v >= 8) { screen_min_m = v; screen_min_m_fixed = true; } }
         opened = true;
         return FNN_OK;
     }

@@ -48,6 +48,7 @@ struct EmuBackend {
     static constexpr int64_t kColPad = 2048;
     int32_t screen_min_n() const { return 8; }   // tiny on purpose: the CPU tests exercise screening
     int32_t screen_min_m = 8;
+    void set_problem_size(int32_t) {}
     bool defer_chain = false; // (so does the deferred chain sum)
     int32_t launch_chain_flush(const fnn::Dev&) { return FNN_OK; }
     std::string err() const { return "emu"; }
