@@ -21,7 +21,8 @@ KIND_2WAY, KIND_3WAY, KIND_4WAY, KIND_FINISH = 2, 3, 4, 5
 class FnnOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("validate", C.c_int32), ("record_events", C.c_int32),
                 ("force_exact_rx", C.c_int32), ("disable_screen", C.c_int32), ("lookahead", C.c_int32),
-                ("lookahead_pairs", C.c_int32), ("reserved", C.c_int32 * 9)]
+                ("lookahead_pairs", C.c_int32), ("mode", C.c_int32), ("relaxed_seed_lo", C.c_uint32),
+                ("relaxed_seed_hi", C.c_uint32), ("relaxed_min_active", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class FnnEvent(C.Structure):
@@ -43,7 +44,7 @@ class FnnStats(C.Structure):
                 ("n_window_fails", C.c_int64), ("window_pairs", C.c_int64), ("bytes_total", C.c_int64),
                 ("n_events_persistent", C.c_int64), ("n_sweeps_exact", C.c_int64), ("t_plain_s", C.c_double),
                 ("plain_launches", C.c_int64), ("plain_bytes", C.c_int64), ("n_stalled_events", C.c_int64),
-                ("reserved", C.c_int64 * 1)]
+                ("n_relaxed_events", C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -118,7 +119,7 @@ class Handle:
 
     def __init__(self, api: Api, n: int, device: int = 0, validate: bool = False,
                  record_events: bool = False, force_exact_rx: bool = False, disable_screen: bool = False,
-                 lookahead: int = 0, lookahead_pairs: int = 0):
+                 lookahead: int = 0, lookahead_pairs: int = 0, relaxed_seed=None, relaxed_min_active: int = 0):
         self.api = api
         self.n = int(n)
         opts = FnnOpts()
@@ -129,6 +130,11 @@ class Handle:
         opts.disable_screen = 1 if disable_screen else 0
         opts.lookahead = lookahead
         opts.lookahead_pairs = lookahead_pairs
+        if relaxed_seed is not None:  # -mode Relaxed (NeighborNetLocal) with java.util.Random(relaxed_seed)
+            opts.mode = 1
+            opts.relaxed_seed_lo = int(relaxed_seed) & 0xFFFFFFFF
+            opts.relaxed_seed_hi = (int(relaxed_seed) >> 32) & 0xFFFFFFFF
+            opts.relaxed_min_active = relaxed_min_active
         h = C.c_void_p()
         api.check(api.create(self.n, C.byref(opts), C.byref(h)))
         self._h = h

@@ -153,6 +153,13 @@ struct State {
     int64_t n_stalled;        // events skipped that way
     int64_t n_sweep_waits;    // k_track: sweeps that had to wait for the exact row sum
     int64_t ev_ticks[8];      // (unused; the phase-split diagnostics live in Dev::ticks)
+    // ---- Relaxed mode (NeighborNetLocal.java; see "Relaxed mode" below) ----
+    int32_t rl_on, rl_min;      // findNodes is the relaxed search while m > rl_min (1024, NetMakerOriginal.java:361)
+    int32_t rl_top, rl_first;   // NeighborNetLocal.top / firstTime (:17-18)
+    int32_t rl_active, pad_rl;  // this event's pair came from the relaxed search (one record, d.recs[0])
+    uint64_t rl_rng;            // java.util.Random state (48 bits)
+    int64_t rl_evals;           // Q values evaluated by this event's search (recorded as the event's `entries`)
+    int64_t n_rl_rows, n_rl_events;  // statistics: row minima computed / events served by the relaxed search
     // ---- current event ----
     int32_t ev_active, ev_finish, need_rx;
     int32_t sa, sap, sb, sbp;  // slots of Cx, Cx.nbr, Cy, Cy.nbr (-1: none)
@@ -208,6 +215,13 @@ struct Dev {
     int32_t rank, world;  // scan sharding: rank scans the tiles with index = rank (mod world)
     int32_t gather;       // non-zero: candidate records are exchanged between ranks (go to gsend)
     int32_t wx;           // non-zero: several ranks WITH lookahead windows - only the base scans are sharded and exchanged
+    // Relaxed mode: NeighborNetLocal.rowPermutation (positions), and the per-call HashMap foundRowMinimums as per-slot
+    // entries {stamp == n_events + 1 of the call, value, number of tied rows, their slots in position order}
+    int32_t* rperm;
+    int32_t* rl_stamp;
+    int32_t* rl_cnt;
+    int32_t* rl_list;  // RL_TIES slots per slot
+    double* rl_val;
     State* st;
     Event* evlog;    // n records (if record_events)
     Agg3Rec* agglog; // n records
@@ -1098,6 +1112,7 @@ FNN_HD void pick(const Dev& d, Cand best, int32_t a, int32_t b, int32_t ida, int
     cur.best = 0.0; cur.entries = 0;
     if (st.m == 4 && st.c == 2) { finish_plan(d); return; }
     cur.entries = (int64_t)st.m * (st.m - 1) / 2 - (st.m - st.c);
+    if (st.rl_active) { cur.entries = st.rl_evals; st.n_rl_events++; }  // (Relaxed mode: the search's own count)
     cur.best = best.q;
     if (!st.la_hit) {  // (a window hit has already added the bytes k_track read)
         const int64_t bytes = (st.ev_screened ? 2 : 8) * cur.entries +
@@ -1241,6 +1256,191 @@ FNN_HD void t_finalize(const Dev& d) {
     d.T[st.tp_U + 1] = tv;
     st.tp_n = 0;
 }
+
+// ---------------------------------------------------------------------------
+// Relaxed mode: NeighborNetLocal.java:88-264 with additive == false (FastNN.java:329-338), serial branch.
+//
+// findNodes walks a random permutation of the positions; for the cluster p it lands on it computes the row minimum of
+// Q(p, .) over ALL rows (ties kept, in position order), then the row minima of those rows, and stops at the first p
+// that is a row minimum of one of its own row minima; one of the mutual pairs is drawn at random.  While
+// num_active <= 1024 the base class's full scan is used instead (NetMakerOriginal.java:361-365).
+//
+// Randomness: the reference draws from ThreadLocalRandom (:30), which cannot be seeded - no two runs of the reference
+// agree.  The engine draws from java.util.Random (the generator of the line it replaced, :27) with an explicit seed,
+// so that a run is reproducible and equals what the reference computes with `myRandom = new Random(seed)`.
+//
+// The body below is the control flow, written once: `Env` supplies single-reader loads / single-writer stores (GPU:
+// lane 0 of the control wave + a broadcast; the control values are wave-uniform) and the row minimum itself (GPU: the
+// whole workgroup; CPU emulation: a loop).  The HashMap foundRowMinimums of one call is the per-slot entry
+// {rl_stamp == n_events + 1, rl_val, rl_cnt, rl_list}; a list longer than RL_TIES, or more than RL_MINS mutual pairs,
+// is reported as an error (degenerate inputs only: every list holds the two nodes of a cluster at most otherwise).
+// ---------------------------------------------------------------------------
+constexpr int RL_TIES = 16;
+constexpr int RL_MINS = 64;
+
+struct JavaRandom {  // java.util.Random: next(bits), nextInt(bound)
+    uint64_t s;
+    FNN_HD static uint64_t scramble(uint64_t seed) { return (seed ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1ULL); }
+    FNN_HD int32_t next(int bits) {
+        s = (s * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1ULL);
+        return (int32_t)(s >> (48 - bits));
+    }
+    FNN_HD int32_t next_int(int32_t bound) {
+        int32_t r = next(31);
+        const int32_t m = bound - 1;
+        if ((bound & m) == 0) r = (int32_t)(((int64_t)bound * (int64_t)r) >> 31);
+        else {
+            for (int32_t u = r; (int32_t)((uint32_t)u - (uint32_t)(r = u % bound) + (uint32_t)m) < 0; u = next(31)) {}
+        }
+        return r;
+    }
+};
+
+// Q(p, q) of NeighborNetLocal.java:104-114 for the nodes in slots ps (partner pp or -1) and qs (partner qp or -1)
+FNN_HD double rl_q(const Dev& d, int32_t ps, int32_t pp, int32_t qs, int32_t qp, double cm2, double sxp) {
+    const double* Rp = d.D + (int64_t)ps * d.ld;
+    double Dpq;
+    if (pp < 0 && qp < 0) Dpq = Rp[qs];
+    else if (pp >= 0 && qp < 0) Dpq = (Rp[qs] + d.D[(int64_t)pp * d.ld + qs]) / 2.0;
+    else if (pp < 0 && qp >= 0) Dpq = (Rp[qs] + Rp[qp]) / 2.0;
+    else {
+        const double* Rn = d.D + (int64_t)pp * d.ld;
+        Dpq = (((Rp[qs] + Rp[qp]) + Rn[qs]) + Rn[qp]) / 4.0;
+    }
+    return (cm2 * Dpq - sxp) - d.Sx[qs];
+}
+
+struct RlRow { int32_t me, cnt; double value; };
+
+// findRowMin (:88-157): the cached list of p, else of p.nbr, else computed (and cached under p)
+template <class Env>
+FNN_HD RlRow rl_find_row_min(const Dev& d, Env& env, int32_t ps, int32_t pp, int32_t stamp, int64_t& evals) {
+    int32_t key;
+    if (env.load(&d.rl_stamp[ps]) == stamp) key = ps;
+    else if (pp >= 0 && env.load(&d.rl_stamp[pp]) == stamp) key = pp;
+    else {
+        env.rowmin(d, ps, pp, stamp);
+        evals += (int64_t)d.st->m - 1 - (pp >= 0 ? 1 : 0);
+        key = ps;
+    }
+    RlRow r;
+    r.me = key;
+    r.cnt = env.load(&d.rl_cnt[key]);
+    r.value = env.loadd(&d.rl_val[key]);
+    return r;
+}
+
+// findNodes (:170-264).  Returns the pair as a candidate record {value, slots of Cx = combineMe.me and Cy = combineMe.row};
+// the state of the search (generator, permutation, top) is stored by the caller's leader.
+template <class Env>
+FNN_HD Cand relaxed_find(const Dev& d, Env& env) {
+    State& st = *d.st;
+    const int32_t m = st.m, twoP = 2 * st.P;
+    JavaRandom rng;
+    rng.s = st.rl_rng;
+    int32_t top = st.rl_top;
+    const int32_t stamp = (int32_t)st.n_events + 1;
+    int64_t evals = 0, rows0 = 0;
+    int32_t err = 0;
+    // (:177-183, the identity permutation and top = ntax - 1 of the first call, are set up with the state: fnn_begin)
+    Cand out = cand_none();
+    int32_t nmin = 0;
+    bool found = false;
+    for (int32_t i = top + 1; i > 0; i--) {
+        const int32_t swapCell = rng.next_int(i);
+        const int32_t vsc = env.load(&d.rperm[swapCell]);
+        if (vsc >= m) {  // a position that is no longer active: drop it from the permutation (:188-198)
+            const int32_t vt = env.load(&d.rperm[top]);
+            env.store(&d.rperm[swapCell], vt);
+            env.store(&d.rperm[top], vsc);
+            if (i == top + 1) i--;
+            else i++;
+            top--;
+            continue;
+        }
+        const int32_t vi = env.load(&d.rperm[i - 1]);  // swap(rowPermutation, i-1, swapCell) (:199)
+        env.store(&d.rperm[i - 1], vsc);
+        env.store(&d.rperm[swapCell], vi);
+        const int32_t ps = env.load(&d.pslot[vsc]);   // p = netNodes[rowPermutation[i-1]]
+        const int32_t pp = ps < twoP ? (ps ^ 1) : -1;
+        if (pp >= 0 && env.load(&d.sid[pp]) < env.load(&d.sid[ps])) continue;  // one node per cluster (:201-203)
+        const RlRow r1 = rl_find_row_min(d, env, ps, pp, stamp, evals);
+        rows0++;
+        for (int32_t a = 0; a < r1.cnt; a++) {
+            const int32_t other = env.load(&d.rl_list[(int64_t)r1.me * RL_TIES + a]);
+            const int32_t op = other < twoP ? (other ^ 1) : -1;
+            const RlRow r2 = rl_find_row_min(d, env, other, op, stamp, evals);
+            for (int32_t b = 0; b < r2.cnt; b++) {
+                const int32_t row = env.load(&d.rl_list[(int64_t)r2.me * RL_TIES + b]);
+                const int32_t rowp = row < twoP ? (row ^ 1) : -1;
+                // testRM.row is p or p.nbr (the four clauses of :210-212)
+                if (row == ps || (rowp >= 0 && rowp == ps) || (rowp >= 0 && pp >= 0 && rowp == pp) || (pp >= 0 && row == pp)) {
+                    if (nmin < RL_MINS) env.keep(nmin, r2.me, row, r2.value);
+                    nmin++;
+                    break;
+                }
+            }
+        }
+        if (nmin > 0) {
+            if (nmin > RL_MINS) { err = 22; break; }
+            const int32_t choice = rng.next_int(nmin);
+            out = env.kept(d, choice);
+            found = true;
+            break;  // break outerloop (:258)
+        }
+    }
+    if (!found && !err) err = 21;  // (the reference would reuse the previous event's Cx / Cy)
+    if (env.lead()) {
+        st.rl_rng = rng.s;
+        st.rl_top = top;
+        st.rl_evals = evals;
+        st.rl_active = 1;
+        st.n_rl_rows += rows0;
+        if (err && !st.error) st.error = err;
+        if (env.err() && !st.error) st.error = env.err();
+    }
+    return out;
+}
+
+// Env of relaxed_find for one thread (CPU emulation): plain loads and stores, the row minimum as the reference's loop
+struct RlSerialEnv {
+    int32_t e = 0;
+    int32_t kme[RL_MINS], krow[RL_MINS];
+    double kval[RL_MINS];
+    FNN_HD bool lead() const { return true; }
+    FNN_HD int32_t err() const { return e; }
+    FNN_HD int32_t load(const int32_t* p) const { return *p; }
+    FNN_HD double loadd(const double* p) const { return *p; }
+    FNN_HD void store(int32_t* p, int32_t v) const { *p = v; }
+    FNN_HD void keep(int32_t i, int32_t me, int32_t row, double v) { kme[i] = me; krow[i] = row; kval[i] = v; }
+    FNN_HD Cand kept(const Dev& d, int32_t i) const {  // (key: the two positions, as in the scans' records)
+        Cand c;
+        c.q = kval[i]; c.si = kme[i]; c.sj = krow[i];
+        c.key = ((uint64_t)(uint32_t)d.spos[kme[i]] << 32) | (uint64_t)(uint32_t)d.spos[krow[i]];
+        return c;
+    }
+    FNN_HD void rowmin(const Dev& d, int32_t ps, int32_t pp, int32_t stamp) {  // NeighborNetLocal.java:96-125
+        const State& st = *d.st;
+        const int32_t m = st.m, twoP = 2 * st.P;
+        const double cm2 = (double)st.c - 2.0, sxp = d.Sx[ps];
+        double myMin = 1.7976931348623157e308;  // Double.MAX_VALUE
+        int32_t cnt = 0;
+        for (int32_t row = 0; row < m; row++) {
+            const int32_t qs = d.pslot[row];
+            if (qs == ps || qs == pp) continue;
+            const double q = rl_q(d, ps, pp, qs, qs < twoP ? (qs ^ 1) : -1, cm2, sxp);
+            if (q < myMin) { myMin = q; cnt = 0; }
+            if (q == myMin) {
+                if (cnt < RL_TIES) d.rl_list[(int64_t)ps * RL_TIES + cnt] = qs;
+                cnt++;
+            }
+        }
+        if (cnt > RL_TIES) { e = 20; cnt = RL_TIES; }
+        d.rl_stamp[ps] = stamp;
+        d.rl_cnt[ps] = cnt;
+        d.rl_val[ps] = myMin;
+    }
+};
 
 // handleAgglomerationEvent: candidate choice (:422-452), bookkeeping of the merge
 // (:462-488) and the micro-op plan for the matrix.  rx = {Rx(Cx), Rx(Cx.nbr),

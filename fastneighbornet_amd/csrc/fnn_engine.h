@@ -59,10 +59,13 @@ class Engine {
     fnn_allgather_fn host_fn = nullptr;
     void* host_ctx = nullptr;
 
+    bool relaxed() const { return opts.mode == FNN_MODE_RELAXED; }
+
     int32_t create(int32_t n_, const fnn_opts* o) {
         if (n_ < 0) return fail(FNN_EINVAL, "fnn_create: n < 0");
         n = n_;
         if (o) opts = *o;
+        if (opts.mode != FNN_MODE_CANONICAL && opts.mode != FNN_MODE_RELAXED) return fail(FNN_EINVAL, "fnn_create: unknown mode");
         int32_t rc = be.open(opts.device);
         if (rc != FNN_OK) return rc;
         be.set_problem_size(n);
@@ -102,13 +105,18 @@ class Engine {
             // -> sized from the update grid like rxpart
             !(dev.upart = (double*)be.alloc(sizeof(double) * 4 * upart_capacity(n))) ||
             !(dev.gsend = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS)) ||
+            (relaxed() && (!(dev.rperm = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
+                           !(dev.rl_stamp = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
+                           !(dev.rl_cnt = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
+                           !(dev.rl_list = (int32_t*)be.alloc(sizeof(int32_t) * RL_TIES * (nn + 8))) ||
+                           !(dev.rl_val = (double*)be.alloc(sizeof(double) * (nn + 8))))) ||
             !(dev.grecv = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS * 64)) ||
             !(dev.st = (State*)be.alloc(sizeof(State))) ||
             !(dev.evlog = (Event*)be.alloc(sizeof(Event) * (nn + 8))) ||
             !(dev.agglog = (Agg3Rec*)be.alloc(sizeof(Agg3Rec) * (nn + 8))))
             return fail(FNN_ENOMEM, "fnn_create: device allocation failed (" + be.err() + ")");
         dev.H = nullptr;
-        if (!opts.disable_screen && n >= be.screen_min_n()) {
+        if (!opts.disable_screen && !relaxed() && n >= be.screen_min_n()) {  // (Relaxed mode: no windows, plain scans at the end)
             if (!(dev.H = (uint16_t*)be.alloc(sizeof(uint16_t) * (size_t)nrows * (size_t)ld)))
                 return fail(FNN_ENOMEM, "fnn_create: device allocation of the bf16 copy failed (" + be.err() + ")");
         }
@@ -120,7 +128,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.recs); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.wsend); be.free(dev.wrecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.ticks); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.recs); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.wsend); be.free(dev.wrecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.rperm); be.free(dev.rl_stamp); be.free(dev.rl_cnt); be.free(dev.rl_list); be.free(dev.rl_val); be.free(dev.ticks); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }
@@ -204,6 +212,21 @@ class Engine {
         hst.record_events = opts.record_events ? 1 : 0;
         hst.ev_timed = 1;
         hst.force_exact_rx = opts.force_exact_rx ? 1 : 0;
+        if (relaxed()) {  // NeighborNetLocal's constructor (:25-32)
+            hst.rl_on = 1;
+            hst.rl_min = opts.relaxed_min_active > 0 ? opts.relaxed_min_active : 1024;
+            hst.rl_first = 0;      // (:177-183 done here: identity permutation, top = ntax - 1)
+            hst.rl_top = n - 1;
+            {
+                std::vector<int32_t> iota((size_t)(n > 0 ? n : 1));
+                for (size_t i = 0; i < iota.size(); i++) iota[i] = (int32_t)i;
+                if (be.h2d(dev.rperm, iota.data(), sizeof(int32_t) * iota.size()) != FNN_OK)
+                    return fail(FNN_EHIP, "fnn_begin: upload failed (" + be.err() + ")");
+            }
+            hst.rl_rng = JavaRandom::scramble(((uint64_t)opts.relaxed_seed_hi << 32) | (uint64_t)opts.relaxed_seed_lo);
+            if (be.memset(dev.rl_stamp, 0, sizeof(int32_t) * ((size_t)(n > 0 ? n : 1) + 8)) != FNN_OK)
+                return fail(FNN_EHIP, "fnn_begin: memset failed (" + be.err() + ")");
+        }
         // lookahead windows (fnn_core.h "Lookahead"): single rank with a screening copy
         {
             // default window length: 16 + n / 1024 events (48 at n = 32768; shorter windows for smaller problems, whose
@@ -227,6 +250,7 @@ class Engine {
             hst.la_K = K > 0 ? K : 0;
             hst.la_target = target;
             hst.la_min_m = be.screen_min_m;
+            be.set_relaxed(hst.rl_on ? hst.rl_min : 0);
             dev.la = hst.la_on;
             dev.wx = (comm_mode != 0 && hst.la_on) ? 1 : 0;
             ev_counter = 0;
@@ -258,6 +282,7 @@ class Engine {
     int32_t comm_set(int32_t mode, int32_t world_, int32_t rank_) {
         if (world_ < 1 || world_ > 64 || rank_ < 0 || rank_ >= world_)
             return fail(FNN_EINVAL, "fnn_comm_init: need 1 <= world <= 64 and 0 <= rank < world");
+        if (relaxed() && world_ > 1) return fail(FNN_EINVAL, "fnn_comm_init: the Relaxed mode runs on one GPU (its search is a chain of row minima)");
         // world == 1 normally needs no exchange; FNN_COMM_FORCE=1 keeps the exchange path on
         // (lets a one-GPU box exercise the RCCL plumbing end to end)
         comm_mode = (world_ > 1 || std::getenv("FNN_COMM_FORCE")) ? mode : 0;
@@ -447,6 +472,7 @@ class Engine {
         stats.n_events_persistent = 0;  // (the persistent event kernel of round 1 is gone; field kept for ABI stability)
         stats.n_sweeps_exact = hst.n_su_exact + hst.n_sweep_waits;
         stats.n_stalled_events = hst.n_stalled;
+        stats.n_relaxed_events = hst.n_rl_events;
         be.collect_timing(stats);
         return rc;
     }

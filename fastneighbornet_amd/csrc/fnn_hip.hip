@@ -191,6 +191,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(Dev d) {
     Cand best;
     best = cand_none();
     if (st->la_hit) return;  // the lookahead window already holds this event's minimum (recs[0])
+    if (st->rl_active) return;  // Relaxed mode: k_relaxed has found this event's pair (recs[0])
     if (!st->done) {
         const int m = st->m;
         const int twoP = 2 * st->P;
@@ -1612,6 +1613,161 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
 #undef DEC_TICK
 }
 
+// ------------------------------------------------------------------ k_relaxed
+// Relaxed mode (fnn_core.h "Relaxed mode"): the search for a pair of mutual row minima, one workgroup.  Wave 0 runs
+// relaxed_find with wave-uniform control (memory is read by lane 0 and broadcast, written by lane 0); a row minimum
+// is a command to the whole workgroup: every thread evaluates Q(p, .) at its positions, the minimum is reduced, a
+// second pass collects the positions that attain it (usually the two nodes of one cluster), lane 0 sorts them into
+// position order and files the list under p.  The other waves loop on the command word.
+constexpr int RL_T = 1024;
+struct RlLds {
+    int32_t cmd;               // 1: row minimum of slot ps (partner pp); 2: done
+    int32_t ps, pp, err;
+    int32_t tcnt;
+    int32_t tpos[RL_TIES], tslot[RL_TIES];
+    double wmin[RL_T / 64];
+    double gmin;
+    int32_t kme[RL_MINS], krow[RL_MINS];
+    double kval[RL_MINS];
+};
+
+// rl_q (fnn_core.h) without branches: the four entries are loaded whatever the kinds of p and q (the partner column
+// q ^ 1 and the partner row exist in the padded matrix; unused sums are discarded), so that the loads of several
+// slots are in flight together.  Same operations on the same operands for the case that applies.
+__device__ __forceinline__ double rl_q_flat(const double* Rp, const double* Rn, const double* Sx, bool ppair, int32_t twoP,
+                                            int32_t qs, double cm2, double sxp) {
+    const double a = Rp[qs], b = Rp[qs ^ 1], c = Rn[qs], e = Rn[qs ^ 1], sq = Sx[qs];
+    const bool qpair = qs < twoP;
+    const double t01 = (a + b) / 2.0, t10 = (a + c) / 2.0, t11 = (((a + b) + c) + e) / 4.0;
+    const double Dpq = ppair ? (qpair ? t11 : t10) : (qpair ? t01 : a);
+    return (cm2 * Dpq - sxp) - sq;
+}
+
+__device__ __forceinline__ void rl_rowmin_block(const Dev& d, RlLds& L) {
+    const State* st = d.st;
+    const int32_t m = st->m, twoP = 2 * st->P, ps = L.ps, pp = L.pp;
+    const double cm2 = (double)st->c - 2.0, sxp = d.Sx[ps];
+    const int tid = threadIdx.x;
+    // ONE pass, over the live slots [0, m) instead of the positions (a minimum does not depend on the order; the row
+    // of p is then read contiguously): every thread keeps its minimum, the first slot that attains it and how many do
+    double mine = 1.7976931348623157e308;  // Double.MAX_VALUE (:95)
+    int32_t mslot = -1, mcnt = 0;
+    const double* Rp = d.D + (int64_t)ps * d.ld;
+    const double* Rn = d.D + (int64_t)(pp >= 0 ? pp : ps) * d.ld;
+    const bool ppair = pp >= 0;
+#pragma unroll 4
+    for (int32_t qs = tid; qs < m; qs += RL_T) {
+        const double q = rl_q_flat(Rp, Rn, d.Sx, ppair, twoP, qs, cm2, sxp);
+        if (qs == ps || qs == pp) continue;
+        if (q < mine) { mine = q; mslot = qs; mcnt = 1; }
+        else if (q == mine) { if (mcnt == 0) mslot = qs; mcnt++; }
+    }
+    double wm = mine;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double o = __shfl_xor(wm, off, 64);
+        if (o < wm) wm = o;
+    }
+    if ((tid & 63) == 0) L.wmin[tid >> 6] = wm;
+    if (tid == 0) L.tcnt = 0;
+    __syncthreads();
+    double g = L.wmin[0];
+#pragma unroll
+    for (int w = 1; w < RL_T / 64; w++) { const double o = L.wmin[w]; if (o < g) g = o; }
+    // the rows that attain it, with their positions (the list is in position order, :98); a thread with several
+    // (the two nodes of a cluster sit in adjacent slots, i.e. in different threads: rare) goes over its slots again
+    if (mcnt > 0 && mine == g) {
+        if (mcnt == 1) {
+            const int k = atomicAdd(&L.tcnt, 1);
+            if (k < RL_TIES) { L.tpos[k] = d.spos[mslot]; L.tslot[k] = mslot; }
+        } else {
+            for (int32_t qs = tid; qs < m; qs += RL_T) {
+                if (qs == ps || qs == pp) continue;
+                const double q = rl_q_flat(Rp, Rn, d.Sx, ppair, twoP, qs, cm2, sxp);
+                if (q == g) {
+                    const int k = atomicAdd(&L.tcnt, 1);
+                    if (k < RL_TIES) { L.tpos[k] = d.spos[qs]; L.tslot[k] = qs; }
+                }
+            }
+        }
+    }
+    if (tid == 0) L.gmin = g;
+    __syncthreads();
+}
+
+struct RlBlockEnv {
+    RlLds& L;
+    int lane;
+    __device__ __forceinline__ bool lead() const { return lane == 0; }
+    __device__ __forceinline__ int32_t err() const { return L.err; }
+    __device__ __forceinline__ int32_t load(const int32_t* p) const {
+        int32_t v = 0;
+        if (lane == 0) v = *p;
+        return __builtin_amdgcn_readfirstlane(v);
+    }
+    __device__ __forceinline__ double loadd(const double* p) const {
+        uint64_t v = 0;
+        if (lane == 0) v = __builtin_bit_cast(uint64_t, *p);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo);
+    }
+    __device__ __forceinline__ void store(int32_t* p, int32_t v) const { if (lane == 0) *p = v; }
+    __device__ __forceinline__ void keep(int32_t i, int32_t me, int32_t row, double v) {
+        if (lane == 0) { L.kme[i] = me; L.krow[i] = row; L.kval[i] = v; }
+    }
+    __device__ __forceinline__ Cand kept(const Dev& d, int32_t i) const {
+        Cand c;
+        c.q = L.kval[i]; c.si = L.kme[i]; c.sj = L.krow[i];
+        c.key = ((uint64_t)(uint32_t)load(&d.spos[c.si]) << 32) | (uint64_t)(uint32_t)load(&d.spos[c.sj]);
+        return c;
+    }
+    __device__ __forceinline__ void rowmin(const Dev& d, int32_t ps, int32_t pp, int32_t stamp) {
+        if (lane == 0) { L.cmd = 1; L.ps = ps; L.pp = pp; }
+        __syncthreads();          // the other waves pick the command up
+        rl_rowmin_block(d, L);
+        if (lane == 0) {
+            int32_t cnt = L.tcnt;
+            if (cnt > RL_TIES) { L.err = 20; cnt = RL_TIES; }
+            for (int i = 1; i < cnt; i++) {  // position order (:98 walks the rows in order)
+                const int32_t kp = L.tpos[i], ks = L.tslot[i];
+                int j = i - 1;
+                while (j >= 0 && L.tpos[j] > kp) { L.tpos[j + 1] = L.tpos[j]; L.tslot[j + 1] = L.tslot[j]; j--; }
+                L.tpos[j + 1] = kp; L.tslot[j + 1] = ks;
+            }
+            for (int i = 0; i < cnt; i++) d.rl_list[(int64_t)ps * RL_TIES + i] = L.tslot[i];
+            d.rl_stamp[ps] = stamp;
+            d.rl_cnt[ps] = cnt;
+            d.rl_val[ps] = L.gmin;
+        }
+    }
+};
+
+__global__ __launch_bounds__(RL_T) void k_relaxed(Dev d) {
+    __shared__ RlLds L;
+    State* st = d.st;
+    // (uniform: every thread reads the same words; nothing writes to the control block before the end)
+    const bool run = !st->done && st->rl_on && st->m > st->rl_min && st->m > 3 && !(st->m == 4 && st->c == 2);
+    if (!run) {
+        if (threadIdx.x == 0) st->rl_active = 0;
+        return;
+    }
+    if (threadIdx.x == 0) { L.err = 0; L.cmd = 0; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        RlBlockEnv env{L, (int)threadIdx.x};
+        const Cand out = relaxed_find(d, env);
+        if (threadIdx.x == 0) { d.recs[0] = out; L.cmd = 2; }
+        __syncthreads();
+    } else {
+        for (;;) {
+            __syncthreads();
+            if (L.cmd == 2) break;
+            rl_rowmin_block(d, L);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ k_decide
 // the decide step of an event that scanned: the scan's (or all ranks') candidate records are reduced first
 __global__ __launch_bounds__(CH_T) void k_decide(Dev d, const Cand* src, int nrecs) {
@@ -1622,9 +1778,11 @@ __global__ __launch_bounds__(CH_T) void k_decide(Dev d, const Cand* src, int nre
     if (st->stall || st->la_hit) return;  // (nothing to decide / the tail of k_track has decided this event already)
     state_in(S.lst, st);
     if (threadIdx.x == 0) S.tkon = 0;
-    Cand best = reduce_records(d, src, nrecs, shc);
+    Cand best = reduce_records(d, src, st->rl_active ? 1 : nrecs, shc);  // (Relaxed mode: the search's one record)
     __syncthreads();
     decide_step(d, S, L, best);
+    __syncthreads();
+    if (threadIdx.x == 0) S.lst.rl_active = 0;
     __syncthreads();
     state_out(st, S.lst);
 }
@@ -2349,6 +2507,8 @@ struct HipBackend {
     // Hence min(2048, n / 4), not below 512; FNN_SCREEN_MIN_M overrides.
     int screen_min_m = 2048;
     bool screen_min_m_fixed = false;
+    int relaxed_min = 0;   // > 0: Relaxed mode - events with more live nodes than this search (k_relaxed) instead of scanning
+    void set_relaxed(int32_t min_active) { relaxed_min = min_active; }
     void set_problem_size(int32_t n) {
         if (screen_min_m_fixed) return;
         const int v = n / 4;
@@ -2644,6 +2804,10 @@ struct HipBackend {
             if (tscan) scan_launches++;
         } else {
             dim3 gs = scan_dims(d, m_bound);
+            // Relaxed mode: the search first; the scan returns at once if it found the pair (it runs when fewer
+            // nodes are live than the bound the host knows, i.e. at the switch to the full scans)
+            if (relaxed_min > 0 && m_bound > relaxed_min)
+                timed(TC_OTHER, tall, [&]() { hipLaunchKernelGGL(k_relaxed, dim3(1), dim3(RL_T), 0, stream, d); });
             timed(TC_SCAN, tscan, [&]() {
                 if (scan_nt) hipLaunchKernelGGL(k_scan<true>, gs, dim3(SCAN_THREADS), 0, stream, d);
                 else hipLaunchKernelGGL(k_scan<false>, gs, dim3(SCAN_THREADS), 0, stream, d);

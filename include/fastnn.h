@@ -63,8 +63,19 @@ typedef struct fnn_opts {
                               with m live nodes: 48 at n = 32768), < 0 = off (every event scans), > 0 = that
                               many (capped at 512); same result either way */
     int32_t lookahead_pairs;/* wanted number of tracked pairs per window (0 = default 32768) */
-    int32_t reserved[9];
+    int32_t mode;          /* FNN_MODE_CANONICAL (0, default) or FNN_MODE_RELAXED: `-mode Relaxed` without `-additive`
+                              (FastNN.java:329-338, NeighborNetLocal.java:170-264) - while more than 1024 nodes are
+                              active the pair to merge is found by the randomised search for mutual row minima instead
+                              of the full scan; everything else (4-candidate choice, merges, expansion) is the same */
+    uint32_t relaxed_seed_lo, relaxed_seed_hi; /* seed of the Relaxed mode's generator: java.util.Random(seed) (the
+                              reference draws from ThreadLocalRandom, NeighborNetLocal.java:30, which cannot be seeded;
+                              with java.util.Random - the generator of the line it replaced, :27 - a run is reproducible) */
+    int32_t relaxed_min_active; /* tests: the relaxed search runs while num_active > this (0 = the reference's 1024,
+                              NetMakerOriginal.java:361) */
+    int32_t reserved[5];
 } fnn_opts;
+
+enum { FNN_MODE_CANONICAL = 0, FNN_MODE_RELAXED = 1 };
 
 /* One agglomeration event == one iteration of the loop of
  * NetMakerOriginal.agglomNodes (:339-393).  Same fields as the test oracle's
@@ -108,7 +119,7 @@ typedef struct fnn_stats {
     int64_t plain_bytes;     /* 8 * E_t summed over them */
     int64_t n_stalled_events;/* launch sequences without scan kernels that found their window gone (they do nothing; the
                                 host relaunches with a scan at its next look at the state) */
-    int64_t reserved[1];
+    int64_t n_relaxed_events;/* Relaxed mode: events whose pair came from the search for mutual row minima (the others scanned) */
 } fnn_stats;
 
 typedef struct fnn_handle fnn_handle;

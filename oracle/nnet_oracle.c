@@ -26,7 +26,18 @@ typedef struct NetNode {
     struct NetNode* next; /* :12 */
     struct NetNode* prev; /* :13 */
     double Sx;       /* :15 */
+    /* Relaxed mode only: this node's entry of the per-call HashMap foundRowMinimums (NeighborNetLocal.java:171) */
+    int64_t rm_stamp;     /* == handle's rm_call when the entry is present */
+    int64_t rm_off;       /* first RowMinimum of its list in the handle's rm_pool */
+    int32_t rm_cnt;
 } NetNode;
+
+/* NetMakerOriginal.java:39-48 */
+typedef struct RowMinimum {
+    NetNode* me;
+    NetNode* row;
+    double value;
+} RowMinimum;
 
 struct nno_handle {
     int ntax;
@@ -43,6 +54,17 @@ struct nno_handle {
     double best;
     NetNode* Cx;
     NetNode* Cy;
+    /* Relaxed mode (NeighborNetLocal.java:14-32) */
+    int relaxed;          /* 0 = Canonical */
+    int relaxed_min;      /* findNodes is the relaxed search while num_active > relaxed_min (1024, NetMakerOriginal.java:361) */
+    uint64_t rng;         /* java.util.Random state (48 bits) */
+    int* rowPermutation;  /* :16 */
+    int firstTime;        /* :17 */
+    int top;              /* :18 */
+    int64_t rm_call;      /* findNodes call number (a fresh HashMap per call, :171) */
+    RowMinimum* rm_pool; int64_t rm_used, rm_cap;
+    int64_t q_evals;      /* Q values evaluated by the current call (the commented-out counter, :76/:119) */
+    double chosen_value;  /* combineMe.value of the current call */
 };
 
 #define DD(h, a, b) ((h)->D[(size_t)(a) * (size_t)(h)->ntax + (size_t)(b)])
@@ -152,6 +174,133 @@ static void findNodes_omp(nno_handle* h, int num_active, int num_clusters) {
         }
     }
     h->Cx = gCx; h->Cy = gCy; h->best = gbest;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Relaxed mode: NeighborNetLocal.java (serial branch, additive == false).
+ *
+ * Randomness: the reference draws from ThreadLocalRandom.current() (:30), which cannot be seeded, so no two runs of the
+ * reference agree; the line it replaced, `new Random(System.currentTimeMillis())` (:27), is java.util.Random.  The
+ * oracle (and the engine) use java.util.Random's documented generator with an explicit seed: the run is then exactly
+ * what the reference computes with `myRandom = new Random(seed)`.
+ * ------------------------------------------------------------------------------------------- */
+static void jr_set_seed(nno_handle* h, uint64_t seed) { h->rng = (seed ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1); }
+static int32_t jr_next(nno_handle* h, int bits) {  /* java.util.Random.next */
+    h->rng = (h->rng * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
+    return (int32_t)(h->rng >> (48 - bits));
+}
+static int32_t jr_next_int(nno_handle* h, int32_t bound) {  /* java.util.Random.nextInt(int) */
+    int32_t r = jr_next(h, 31);
+    const int32_t m = bound - 1;
+    if ((bound & m) == 0) r = (int32_t)(((int64_t)bound * (int64_t)r) >> 31);
+    else {
+        for (int32_t u = r; (int32_t)((uint32_t)u - (uint32_t)(r = u % bound) + (uint32_t)m) < 0; u = jr_next(h, 31)) {}
+    }
+    return r;
+}
+
+static RowMinimum* rm_push(nno_handle* h, NetNode* me, NetNode* row, double value) {
+    if (h->rm_used == h->rm_cap) {
+        h->rm_cap = h->rm_cap ? 2 * h->rm_cap : 1024;
+        h->rm_pool = (RowMinimum*)realloc(h->rm_pool, sizeof(RowMinimum) * (size_t)h->rm_cap);
+    }
+    RowMinimum* r = &h->rm_pool[h->rm_used++];
+    r->me = me; r->row = row; r->value = value;
+    return r;
+}
+
+/* NeighborNetLocal.java:88-157 findRowMin, numThreads == 1 branch (:96-125).  Returns the list through (*off, *cnt). */
+static void findRowMin(nno_handle* h, NetNode* p, int num_active, int num_clusters, int64_t* off, int32_t* cnt) {
+    if (p->rm_stamp == h->rm_call) { *off = p->rm_off; *cnt = p->rm_cnt; return; }                         /* :89-91 */
+    if (p->nbr != NULL && p->nbr->rm_stamp == h->rm_call) { *off = p->nbr->rm_off; *cnt = p->nbr->rm_cnt; return; } /* :92-94 */
+    NetNode** netNodes = h->netNodes;
+    double myMin = DBL_MAX;
+    int64_t start = h->rm_used;
+    double Dpq, Qpq;
+    for (int row = 0; row < num_active; row++) {
+        NetNode* q = netNodes[row];
+        if ((p == q) || ((p->nbr != NULL) && (p->nbr == q))) continue;
+        if ((p->nbr == NULL) && (q->nbr == NULL))
+            Dpq = DD(h, p->distID, q->distID);
+        else if ((p->nbr != NULL) && (q->nbr == NULL))
+            Dpq = (DD(h, p->distID, q->distID) + DD(h, p->nbr->distID, q->distID)) / 2.0;
+        else if ((p->nbr == NULL) && (q->nbr != NULL))
+            Dpq = (DD(h, p->distID, q->distID) + DD(h, p->distID, q->nbr->distID)) / 2.0;
+        else
+            Dpq = (DD(h, p->distID, q->distID) + DD(h, p->distID, q->nbr->distID) +
+                   DD(h, p->nbr->distID, q->distID) + DD(h, p->nbr->distID, q->nbr->distID)) / 4.0;
+        Qpq = ((double)num_clusters - 2.0) * Dpq - p->Sx - q->Sx;
+        h->q_evals++;
+        if (Qpq < myMin) {
+            myMin = Qpq;
+            h->rm_used = start;            /* myMinimums.clear() */
+            rm_push(h, p, q, Qpq);
+        } else if (Qpq == myMin) {
+            rm_push(h, p, q, Qpq);
+        }
+    }
+    p->rm_stamp = h->rm_call; p->rm_off = start; p->rm_cnt = (int32_t)(h->rm_used - start);   /* :155 */
+    *off = p->rm_off; *cnt = p->rm_cnt;
+}
+
+static void swap_int(int* x, int a, int b) { int t = x[a]; x[a] = x[b]; x[b] = t; }   /* :159-163 */
+
+/* NeighborNetLocal.java:170-264 findNodes with additive == false.  Returns 0 if the loop ran out without a pair of
+ * mutual row minima (the reference would then reuse the previous event's Cx / Cy: not restated, reported as an error). */
+static int findNodes_relaxed(nno_handle* h, int num_active, int num_clusters) {
+    NetNode** netNodes = h->netNodes;
+    int* rowPermutation = h->rowPermutation;
+    h->rm_call++;                 /* new HashMap (:171) */
+    h->rm_used = 0;
+    h->q_evals = 0;
+    /* myMinimums (:172): entries are copies of RowMinimum records */
+    RowMinimum myMinimums[64];
+    int nmin = 0;
+    if (h->firstTime) {
+        for (int i = 0; i < h->ntax; i++) rowPermutation[i] = i;
+        h->firstTime = 0;
+        h->top = h->ntax - 1;
+    }
+    for (int i = h->top + 1; i > 0; i--) {
+        int swapCell = jr_next_int(h, i);
+        if (rowPermutation[swapCell] >= num_active) {
+            swap_int(rowPermutation, swapCell, h->top);
+            if (i == h->top + 1) i--;
+            else i++;
+            h->top--;
+            continue;
+        }
+        swap_int(rowPermutation, i - 1, swapCell);
+        NetNode* p = netNodes[rowPermutation[i - 1]];
+        if ((p->nbr != NULL) && (p->nbr->id < p->id)) continue;   /* one node per cluster (:201-203) */
+        int64_t off; int32_t cnt;
+        findRowMin(h, p, num_active, num_clusters, &off, &cnt);
+        for (int32_t a = 0; a < cnt; a++) {
+            NetNode* other = h->rm_pool[off + a].row;
+            int64_t off2; int32_t cnt2;
+            findRowMin(h, other, num_active, num_clusters, &off2, &cnt2);
+            for (int32_t b = 0; b < cnt2; b++) {
+                const RowMinimum testRM = h->rm_pool[off2 + b];
+                if ((testRM.row == p) || ((testRM.row->nbr != NULL) && (testRM.row->nbr == p)) ||
+                    ((testRM.row->nbr != NULL) && (p->nbr != NULL) && (testRM.row->nbr == p->nbr)) ||
+                    ((p->nbr != NULL) && (testRM.row == p->nbr))) {
+                    if (nmin < 64) myMinimums[nmin] = testRM;
+                    nmin++;
+                    break;
+                }
+            }
+        }
+        if (nmin > 0) {
+            if (nmin > 64) return -2;   /* (more tied mutual minima than this restatement keeps) */
+            int choice = jr_next_int(h, nmin);
+            RowMinimum combineMe = myMinimums[choice];
+            h->Cx = combineMe.me;
+            h->Cy = combineMe.row;
+            h->chosen_value = combineMe.value;
+            return 1;                 /* break outerloop (:258) */
+        }
+    }
+    return 0;
 }
 
 /* NetMakerOriginal.java:549-561 ComputeRx */
@@ -386,6 +535,8 @@ nno_handle* nno_create(const double* D, int32_t n, int32_t threads) {
     h->num_active = n;   /* agglomNodes :334-335 */
     h->num_clusters = n;
     h->finished = 0;
+    h->relaxed = 0; h->relaxed_min = 1024; h->firstTime = 1;
+    h->rowPermutation = (int*)calloc((size_t)n + 1, sizeof(int));
     if (n > 3) initialize(h, n); /* :159 (for n <= 3 runNeighborNet returns before, :133-140) */
     else h->finished = 1;
     return h;
@@ -393,7 +544,7 @@ nno_handle* nno_create(const double* D, int32_t n, int32_t threads) {
 
 void nno_destroy(nno_handle* h) {
     if (!h) return;
-    free(h->D); free(h->netNodes); free(h->pool); free(h->amalgs);
+    free(h->D); free(h->netNodes); free(h->pool); free(h->amalgs); free(h->rowPermutation); free(h->rm_pool);
     free(h);
 }
 
@@ -431,8 +582,14 @@ int32_t nno_step(nno_handle* h, nno_event* ev) {
         return 1;
     }
     ev->entries = (int64_t)num_active * (num_active - 1) / 2 - (num_active - num_clusters);
-    /* :361-366: both branches are the same serial scan for numThreads == 1 */
-    if (h->threads > 1) findNodes_omp(h, num_active, num_clusters);
+    /* :361-366: both branches are the same serial scan for numThreads == 1 (Canonical); in Relaxed mode findNodes
+     * (num_active > 1024) is NeighborNetLocal's search, findNodesDefault the scan */
+    if (h->relaxed && num_active > h->relaxed_min) {
+        int rc = findNodes_relaxed(h, num_active, num_clusters);
+        if (rc != 1) return rc == 0 ? -3 : rc;
+        h->best = h->chosen_value;       /* (the reference leaves `best` alone; recorded for the trajectory) */
+        ev->entries = h->q_evals;        /* Q values evaluated instead of E_t */
+    } else if (h->threads > 1) findNodes_omp(h, num_active, num_clusters);
     else findNodes_serial(h, num_active, num_clusters);
     ev->best = h->best;
     if (h->Cx->id > h->Cy->id) { /* :376-380 */
@@ -444,6 +601,19 @@ int32_t nno_step(nno_handle* h, nno_event* ev) {
     ev->cy_id = h->Cy->id;
     handleAgglomerationEvent(h, h->Cx, h->Cy, ev);
     return 1;
+}
+
+void nno_set_relaxed(nno_handle* h, uint64_t seed, int32_t min_active) {
+    h->relaxed = 1;
+    h->relaxed_min = min_active > 0 ? min_active : 1024;
+    jr_set_seed(h, seed);
+}
+int32_t nno_java_random_next_int(uint64_t* state, int32_t bound, int32_t init_with_seed) {  /* (known-answer tests) */
+    nno_handle tmp;
+    if (init_with_seed) { jr_set_seed(&tmp, *state); } else tmp.rng = *state;
+    int32_t r = jr_next_int(&tmp, bound);
+    *state = tmp.rng;
+    return r;
 }
 
 int32_t nno_num_active(const nno_handle* h) { return h->num_active; }
@@ -525,6 +695,26 @@ int32_t nno_run(const double* D, int32_t n, int32_t threads, int32_t* order_out,
     }
     if (n_events) *n_events = k;
     if (sum_entries) *sum_entries = se;
+    int32_t rc = nno_expand(h, order_out);
+    nno_destroy(h);
+    return rc;
+}
+
+/* Whole Relaxed run (FastNN.java:329-338 with additive == false). */
+int32_t nno_run_relaxed(const double* D, int32_t n, uint64_t seed, int32_t min_active, int32_t* order_out,
+                        nno_event* events_out, int64_t max_events, int64_t* n_events) {
+    nno_handle* h = nno_create(D, n, 1);
+    if (!h) return -1;
+    nno_set_relaxed(h, seed, min_active);
+    int64_t k = 0;
+    nno_event ev;
+    int32_t r;
+    while ((r = nno_step(h, &ev)) == 1) {
+        if (events_out && k < max_events) events_out[k] = ev;
+        k++;
+    }
+    if (n_events) *n_events = k;
+    if (r < 0) { nno_destroy(h); return r; }
     int32_t rc = nno_expand(h, order_out);
     nno_destroy(h);
     return rc;

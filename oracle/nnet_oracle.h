@@ -73,6 +73,18 @@ int32_t nno_run(const double* D, int32_t n, int32_t threads, int32_t* order_out,
                 nno_event* events_out, int64_t max_events, int64_t* n_events,
                 int64_t* sum_entries);
 
+/* Relaxed mode (NeighborNetLocal.java, additive == false; FastNN.java:329-338): call after nno_create and before the
+ * first nno_step.  The reference's ThreadLocalRandom cannot be seeded; the draws come from java.util.Random(seed)
+ * instead (the generator of the line it replaced, NeighborNetLocal.java:27).  min_active: the relaxed search runs
+ * while num_active > min_active (0 = the reference's 1024, NetMakerOriginal.java:361; smaller values for tests).
+ * Events of the relaxed search record best = the chosen RowMinimum's value and entries = Q values evaluated.
+ * nno_step returns -3 if the search runs out without a pair of mutual row minima. */
+void    nno_set_relaxed(nno_handle* h, uint64_t seed, int32_t min_active);
+int32_t nno_run_relaxed(const double* D, int32_t n, uint64_t seed, int32_t min_active, int32_t* order_out,
+                        nno_event* events_out, int64_t max_events, int64_t* n_events);
+/* java.util.Random.nextInt(bound) on an explicit state (known-answer tests of the generator). */
+int32_t nno_java_random_next_int(uint64_t* state, int32_t bound, int32_t init_with_seed);
+
 /* SplitMix64 synthetic generator shared by tests and bench:
  * strict upper triangle row-major, k-th value from the k-th SplitMix64 output.
  * dist 0 = uniform53: (next>>11)*2^-53 + 2^-10 ; dist 1 = dec4:

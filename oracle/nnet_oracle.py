@@ -78,6 +78,11 @@ def lib():
         L.nno_run.argtypes = [dp, C.c_int32, C.c_int32, ip, C.c_void_p, C.c_int64,
                               C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.nno_synth.argtypes = [dp, C.c_int32, C.c_uint64, C.c_int32]
+        L.nno_set_relaxed.argtypes = [C.c_void_p, C.c_uint64, C.c_int32]
+        L.nno_run_relaxed.restype = C.c_int32
+        L.nno_run_relaxed.argtypes = [dp, C.c_int32, C.c_uint64, C.c_int32, ip, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.nno_java_random_next_int.restype = C.c_int32
+        L.nno_java_random_next_int.argtypes = [C.POINTER(C.c_uint64), C.c_int32, C.c_int32]
         _lib = L
     return _lib
 
@@ -114,15 +119,40 @@ def run(D: np.ndarray, threads: int = 1, want_events: bool = True):
     return order, ev[: nev.value] if want_events else None, se.value
 
 
+def run_relaxed(D: np.ndarray, seed: int, min_active: int = 0):
+    """Whole Relaxed run (NeighborNetLocal, additive off) with java.util.Random(seed). Returns (order, events)."""
+    D = np.ascontiguousarray(D, dtype=np.float64)
+    n = D.shape[0]
+    order = np.zeros(n + 1, dtype=np.int32)
+    cap = max(n, 1)
+    ev = np.zeros(cap, dtype=EVENT_DTYPE)
+    nev = C.c_int64(0)
+    rc = lib().nno_run_relaxed(_dptr(D), n, seed, min_active, _iptr(order), ev.ctypes.data, cap, C.byref(nev))
+    if rc != 0:
+        raise RuntimeError(f"relaxed oracle failed ({rc})")
+    return order, ev[: nev.value]
+
+
+def java_random_ints(seed: int, bounds):
+    """java.util.Random(seed).nextInt(b) for b in bounds."""
+    st = C.c_uint64(seed)
+    out = []
+    for i, b in enumerate(bounds):
+        out.append(lib().nno_java_random_next_int(C.byref(st), b, 1 if i == 0 else 0))
+    return out
+
+
 class Stepper:
     """Event-by-event access to the oracle state (for trajectory parity tests)."""
 
-    def __init__(self, D: np.ndarray, threads: int = 1):
+    def __init__(self, D: np.ndarray, threads: int = 1, relaxed_seed=None, relaxed_min_active: int = 0):
         D = np.ascontiguousarray(D, dtype=np.float64)
         self.n = D.shape[0]
         self._h = lib().nno_create(_dptr(D), self.n, threads)
         if not self._h:
             raise MemoryError("nno_create failed")
+        if relaxed_seed is not None:
+            lib().nno_set_relaxed(self._h, relaxed_seed, relaxed_min_active)
 
     def close(self):
         if self._h:

@@ -49,6 +49,7 @@ struct EmuBackend {
     int32_t screen_min_n() const { return 8; }   // tiny on purpose: the CPU tests exercise screening
     int32_t screen_min_m = 8;
     void set_problem_size(int32_t) {}
+    void set_relaxed(int32_t) {}
     bool defer_chain = false; // (so does the deferred chain sum)
     int32_t launch_chain_flush(const fnn::Dev&) { return FNN_OK; }
     std::string err() const { return "emu"; }
@@ -248,6 +249,11 @@ struct EmuBackend {
         if (d.H && st.m >= screen_min_m) return scan_screened(d);
         fnn::Cand best;
         best = fnn::cand_none();
+        st.rl_active = 0;
+        if (!st.done && st.m > 3 && !(st.m == 4 && st.c == 2) && st.rl_on && st.m > st.rl_min) {  // k_relaxed
+            fnn::RlSerialEnv env;
+            return fnn::relaxed_find(d, env);
+        }
         if (!st.done) {
             int32_t m = st.m, twoP = 2 * st.P;
             double cm2 = (double)st.c - 2.0;
