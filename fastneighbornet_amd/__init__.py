@@ -58,4 +58,4 @@ def api() -> _capi.Api:
     return _api
 
 
-from .canonical import NeighborNetCanonical, canonical_order, split_weights  # noqa: E402,F401
+from .canonical import NeighborNetCanonical, NeighborNetLocal, canonical_order, split_weights  # noqa: E402,F401

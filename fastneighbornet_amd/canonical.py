@@ -40,6 +40,7 @@ class NeighborNetCanonical:
         self._device = device
         self._validate = validate
         self._record = record_events
+        self._relaxed_seed = None
         self.ordering = None
         self.stats = None
         self.events = None
@@ -50,7 +51,7 @@ class NeighborNetCanonical:
             self.ordering = np.arange(self.ntax + 1, dtype=np.int32)
             return self.ordering
         with _capi.Handle(self._api, self.ntax, device=self._device, validate=self._validate,
-                          record_events=self._record) as h:
+                          record_events=self._record, relaxed_seed=self._relaxed_seed) as h:
             h.set_matrix(self.D)
             order, st = h.run()
             if self._record:
@@ -61,6 +62,20 @@ class NeighborNetCanonical:
 
     def getOrdering(self):  # NetMakerOriginal.java:72-74
         return self.ordering
+
+
+class NeighborNetLocal(NeighborNetCanonical):
+    """`-mode Relaxed` (NeighborNetLocal.java:25-32; FastNN.java:329-338): same constructor shape as the Java class
+    plus `seed`.  The reference draws from ThreadLocalRandom, which cannot be seeded; the engine draws from
+    java.util.Random(seed) - the generator of the line the reference commented out (:27) - so a run can be
+    repeated.  `additive=True` (the additivity check) is not provided."""
+
+    def __init__(self, d, numTaxa: int, numThreads: int = 1, additive: bool = False, pool=None, *, seed: int = 0,
+                 device: int = 0, validate: bool = True, record_events: bool = False):
+        if additive:
+            raise NotImplementedError("the additivity check of the relaxed search (-additive) is not provided")
+        super().__init__(d, numTaxa, numThreads, pool, device=device, validate=validate, record_events=record_events)
+        self._relaxed_seed = int(seed)
 
 
 def canonical_order(D: np.ndarray, device: int = 0, validate: bool = True) -> np.ndarray:

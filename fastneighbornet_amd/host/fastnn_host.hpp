@@ -86,6 +86,7 @@ class NeighborNetCanonical : public NetMakerOriginal {
         fnn_opts o{};
         o.device = device;
         o.validate = 1;
+        configure(o);
         int32_t rc;
         if (!packed) {
             rc = fnn_canonical_order_f64(D, ntax, ntax, &o, ordering.data(), &stats);
@@ -106,9 +107,36 @@ class NeighborNetCanonical : public NetMakerOriginal {
     }
     fnn_stats stats{};
 
+  protected:
+    virtual void configure(fnn_opts&) const {}
+
   private:
     int device;
     const std::vector<double>* packed = nullptr;
+};
+
+// -mode Relaxed on the GPU engine: NeighborNetLocal.java (constructor :25-32) without the additivity check.  The
+// reference draws from ThreadLocalRandom, which cannot be seeded; here the draws are java.util.Random(seed)'s, so a
+// run can be repeated (seed: the caller's, e.g. the clock as in the line the reference commented out, :27).
+class NeighborNetLocal : public NeighborNetCanonical {
+  public:
+    NeighborNetLocal(const double* d, int numTaxa, int numThreads, bool additive, void* pool, uint64_t seed, int device = 0)
+        : NeighborNetCanonical(d, numTaxa, numThreads, pool, device), seed(seed) { check(additive); }
+    NeighborNetLocal(const DistancesAndNames& dan, int numThreads, bool additive, void* pool, uint64_t seed, int device = 0)
+        : NeighborNetCanonical(dan, numThreads, pool, device), seed(seed) { check(additive); }
+
+  protected:
+    void configure(fnn_opts& o) const override {
+        o.mode = FNN_MODE_RELAXED;
+        o.relaxed_seed_lo = (uint32_t)(seed & 0xFFFFFFFFu);
+        o.relaxed_seed_hi = (uint32_t)(seed >> 32);
+    }
+
+  private:
+    static void check(bool additive) {
+        if (additive) throw std::invalid_argument("fastnn: the additivity check of the relaxed search (-additive) is not provided");
+    }
+    uint64_t seed;
 };
 
 // SplitAndWeight (CircularSplitWeights.java:47-50): the BitSet as the ascending list of its set bits

@@ -5,13 +5,15 @@
 //
 // A run without -order continues as FastNN.java:401-540 does: non-negative least-squares weights of
 // the circular splits (on the GPU, fnn_split_weights_f64: CircularSplitWeights.java's method) and
-// the Nexus document on stdout (OutputPrinter.java).  Not provided: the non-Canonical modes (a
-// message and exit status 2 instead of silently doing something else).
+// the Nexus document on stdout (OutputPrinter.java).  -mode Relaxed (NeighborNetLocal.java) runs on the engine too, with
+// -seed <long> for its generator (default: the clock, as in NeighborNetLocal.java:27); its -additive variant and the
+// Random_* / Filter modes are not provided (a message and exit status 2 instead of silently doing something else).
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <string>
 
 #include "fastnn_host.hpp"
@@ -41,7 +43,8 @@ int main(int argc, char** argv) {
     std::fprintf(stderr, "FastNN Version: 0.3.5\n");
     std::fprintf(stderr, "Engine: fastnn-mi355x (HIP gfx950, C ABI %d)\n", fnn_abi_version());
     std::string fileName, modeStr = "CANONICAL";
-    bool haveFile = false, order = false, timeMe = false, wantHelp = false;
+    bool haveFile = false, order = false, timeMe = false, wantHelp = false, additive = false, haveSeed = false;
+    unsigned long long seed = 0;
     int nThreads = 1, device = 0;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -60,7 +63,8 @@ int main(int argc, char** argv) {
         else if (a == "-mult" || a == "--mult") (void)needArg("mult");
         else if (a == "-gpu" || a == "--gpu") device = std::atoi(needArg("gpu"));
         else if (a == "-order" || a == "--order") order = true;
-        else if (a == "-additive" || a == "--additive") {}
+        else if (a == "-additive" || a == "--additive") additive = true;
+        else if (a == "-seed" || a == "--seed") { seed = std::strtoull(needArg("seed"), nullptr, 10); haveSeed = true; }
         else if (a == "-time" || a == "--time") timeMe = true;
         else {
             std::fprintf(stderr, "Parsing failed.  Reason: Unrecognized option: %s\n", a.c_str());
@@ -97,16 +101,27 @@ int main(int argc, char** argv) {
     }
     std::fprintf(stderr, "Calculating a tree for %d taxa using %d thread(s).\n", nTaxa, nThreads);
     std::fprintf(stderr, "Getting distances from the file: %s\n", fileName.c_str());
-    if (modeStr != "CANONICAL" && modeStr != "ORIGINAL") {
-        std::fprintf(stderr, "fastnn-mi355x: -mode %s is not provided by this engine (only Canonical is).\n", modeStr.c_str());
+    const bool relaxed = modeStr == "RELAXED";
+    if ((modeStr != "CANONICAL" && modeStr != "ORIGINAL" && !relaxed) || (relaxed && additive)) {
+        std::fprintf(stderr, "fastnn-mi355x: -mode %s%s is not provided by this engine (Canonical and Relaxed are).\n", modeStr.c_str(),
+                     relaxed ? " -additive" : "");
         return 2;
     }
     try {
         nnet::DistancesAndNames danOrg(fileName, nTaxa);
-        nnet::NeighborNetCanonical myNMO(danOrg, nThreads, nullptr, device);
-        std::fprintf(stderr, "Using the canonical implementation.\n");
+        std::unique_ptr<nnet::NeighborNetCanonical> myNMO;
+        if (relaxed) {  // FastNN.java:329-338
+            if (!haveSeed) seed = (unsigned long long)std::chrono::duration_cast<std::chrono::milliseconds>(
+                                      std::chrono::system_clock::now().time_since_epoch()).count();
+            myNMO.reset(new nnet::NeighborNetLocal(danOrg, nThreads, false, nullptr, seed, device));
+            std::fprintf(stderr, "Using the relaxed version without additivity checking.\n");
+            std::fprintf(stderr, "Relaxed search seed (java.util.Random): %llu\n", seed);
+        } else {
+            myNMO.reset(new nnet::NeighborNetCanonical(danOrg, nThreads, nullptr, device));
+            std::fprintf(stderr, "Using the canonical implementation.\n");
+        }
         auto t0 = std::chrono::steady_clock::now();
-        std::vector<int32_t> ordering = myNMO.runNeighborNet();
+        std::vector<int32_t> ordering = myNMO->runNeighborNet();
         auto t1 = std::chrono::steady_clock::now();
         if (timeMe) std::fprintf(stderr, "Got the order in (s): %.9g\n", std::chrono::duration<double>(t1 - t0).count());
         if (order) {

@@ -88,8 +88,14 @@ def test_cli_surface_without_gpu(tmp_path):
     p.write_text("3\nA\nB 1\nC 2 3\n")
     r = subprocess.run([exe, "-distFile", str(p), "-mode", "bogus"], capture_output=True, text=True)
     assert r.returncode == 1 and "No enum constant nnet.NetMakerOriginal.NMMode.BOGUS" in r.stderr
-    r = subprocess.run([exe, "-distFile", str(p), "-mode", "relaxed", "-order"], capture_output=True, text=True)
+    r = subprocess.run([exe, "-distFile", str(p), "-mode", "random_n", "-order"], capture_output=True, text=True)
     assert r.returncode == 2 and r.stdout == ""
+    r = subprocess.run([exe, "-distFile", str(p), "-mode", "relaxed", "-additive", "-order"], capture_output=True, text=True)
+    assert r.returncode == 2 and r.stdout == "" and "-additive" in r.stderr
+    # -mode Relaxed (FastNN.java:329-338); ntax <= 3 needs no device
+    r = subprocess.run([exe, "-distFile", str(p), "-mode", "relaxed", "-seed", "5", "-order"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout == "[0, 1, 2, 3]\n"
+    assert "Using the relaxed version without additivity checking.\n" in r.stderr
     # ntax <= 3: identity order without touching a device (NetMakerOriginal.java:133-140)
     r = subprocess.run([exe, "-distFile", str(p), "-mode", "Canonical", "-order", "-time"], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout == "[0, 1, 2, 3]\n"
@@ -110,8 +116,10 @@ def test_cli_config0_64_taxa_phylip(oracle, tmp_path):
     assert r.stdout == "[" + ", ".join(str(int(v)) for v in o_ref) + "]\n"
     assert "Got the order in (s): " in r.stderr
     # without -order: split weights on the GPU + the Nexus document (FastNN.java:398-491)
+    # the weights: the optimum of the live path's dense non-negative least-squares problem (FastNN.java:401-454)
     from oracle import csw_oracle as W
-    w_ref, _ = W.split_weights(D, o_ref)
+    import scipy.optimize as so
+    w_ref, _ = so.nnls(W.live_design_matrix(64, o_ref), W.packed_distances(D), maxiter=10 ** 7)
     r = subprocess.run([exe, "-distFile", p, "-mode", "Canonical", "-time"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "Got the splits and weights in (s): " in r.stderr and "Wrote the output in (s): " in r.stderr

@@ -126,3 +126,28 @@ def test_gpu_relaxed_is_canonical_below_the_threshold(hip_api, oracle):
         h.set_matrix(D)
         order, _ = h.run()
     assert (order == oracle.run(D)[0]).all()
+
+
+@pytest.mark.gpu
+def test_gpu_cli_and_host_mirrors_in_relaxed_mode(oracle, tmp_path):
+    """`fastnn -mode Relaxed -seed S -order` and NeighborNetLocal(...).runNeighborNet() (FastNN.java:329-338)."""
+    import os
+    import subprocess
+
+    import fastneighbornet_amd as fa
+    from test_host_cli import PKG, write_phylip
+    n, seed = 1100, 5
+    D = oracle.synth(n, 3)
+    p = str(tmp_path / "r.phy")
+    write_phylip(p, D)
+    D2 = D  # (write_phylip prints repr(): the reader gets the same doubles back)
+    o_ref, _ = oracle.run_relaxed(D2, seed, 0)
+    r = subprocess.run([os.path.join(PKG, "bin", "fastnn"), "-distFile", p, "-mode", "Relaxed", "-seed", str(seed), "-order", "-time"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == "[" + ", ".join(str(int(v)) for v in o_ref) + "]\n"
+    assert "Using the relaxed version without additivity checking.\n" in r.stderr
+    nn = fa.NeighborNetLocal(D2, n, 1, False, None, seed=seed)
+    assert (nn.runNeighborNet() == o_ref).all() and nn.stats["n_relaxed_events"] > 0
+    with pytest.raises(NotImplementedError):
+        fa.NeighborNetLocal(D2, n, 1, True, None, seed=seed)
