@@ -191,7 +191,8 @@ struct Dev {
     double* chain;   // 4 buffers of cstride doubles, addressed through chain_addr(position)
     int64_t cstride; // n rounded up to a whole super-chunk
     Cand* recs;      // per-block scan records
-    uint16_t* H;     // bf16 screening copy of D (same geometry, H[r][c] == bf16(D[r][c]))
+    uint16_t* H;     // bf16 screening copy of D: H[r * ldh + c] == bf16(D[r][c]) (its own row stride, see fnn_create)
+    int64_t ldh;
     float* srec;     // screening: per unit [tile][4] lower bounds, then [tile][4] upper bounds
     float* stile;    // screening: per tile lower bound, then per tile upper bound
     uint64_t* shit;  // screening: per unit, the lanes (8 columns each) that hold a pair under the window's threshold
@@ -500,7 +501,7 @@ FNN_HD int32_t screen_unit_count(int32_t m) { return 4 * tri_tile_count(m, SCR_T
 FNN_HD void store_d(const Dev& d, int64_t r, int64_t c, double v) {
     const int64_t idx = r * d.ld + c;
     d.D[idx] = v;
-    if (d.H && c <= r) d.H[idx] = bf16_from_double(v);
+    if (d.H && c <= r) d.H[r * d.ldh + c] = bf16_from_double(v);
 }
 
 // ---------------------------------------------------------------------------
@@ -1801,11 +1802,11 @@ FNN_HD double update_bulk(const Dev& d, const PlanView& st, int32_t k, bool pair
             const int64_t rb = (int64_t)dst * d.ld, rk = (int64_t)k * d.ld;
             d.D[rb + k] = tv[t][0];
             d.D[rk + dst] = tv[t][0];
-            if (d.H) d.H[k < dst ? rb + k : rk + dst] = bf16_from_double(tv[t][0]);
+            if (d.H) d.H[k < dst ? (int64_t)dst * d.ldh + k : (int64_t)k * d.ldh + dst] = bf16_from_double(tv[t][0]);
             if (paired) {
                 d.D[rb + k + 1] = tv[t][1];
                 d.D[rk + d.ld + dst] = tv[t][1];
-                if (d.H) d.H[k + 1 < dst ? rb + k + 1 : rk + d.ld + dst] = bf16_from_double(tv[t][1]);
+                if (d.H) d.H[k + 1 < dst ? (int64_t)dst * d.ldh + k + 1 : (int64_t)(k + 1) * d.ldh + dst] = bf16_from_double(tv[t][1]);
             }
         }
     }

@@ -42,7 +42,7 @@ class Engine {
     B be;
     Dev dev{};
     int32_t n = 0;
-    int64_t ld = 0, nrows = 0;
+    int64_t ld = 0, ldh = 0, nrows = 0;
     fnn_opts opts{};
     bool have_matrix = false, begun = false, ended = false;
     State hst{};           // host copy of the device state
@@ -74,8 +74,14 @@ class Engine {
         // do not hammer one HBM channel
         nrows = round_up(n > 0 ? n : 1, B::kRowPad);
         ld = round_up(n > 0 ? n : 1, B::kColPad) + 32;
+        // the bf16 copy has its own row stride (FNN_LDH_PAD: shifts between 64 B and 4.5 KB per row were measured in the
+        // screening pass at n = 32768 - all within 4.5-4.85 TB/s; a 512-B shift reached 5.1 TB/s only together with a
+        // 2-KB shift of the fp64 rows, which slows the event chain by 7 %: no robust gain, so both use the same padding)
+        ldh = ld;
+        if (const char* e = std::getenv("FNN_LDH_PAD")) { int v = std::atoi(e); if (v >= 32 && v % 8 == 0 && v <= 65536) ldh = round_up(n > 0 ? n : 1, B::kColPad) + v; }
         dev.n = n;
         dev.ld = ld;
+        dev.ldh = ldh;
         dev.cstride = round_up(n > 0 ? n : 1, CH_SC);
         dev.rank = 0;
         dev.world = 1;
@@ -117,7 +123,7 @@ class Engine {
             return fail(FNN_ENOMEM, "fnn_create: device allocation failed (" + be.err() + ")");
         dev.H = nullptr;
         if (!opts.disable_screen && !relaxed() && n >= be.screen_min_n()) {  // (Relaxed mode: no windows, plain scans at the end)
-            if (!(dev.H = (uint16_t*)be.alloc(sizeof(uint16_t) * (size_t)nrows * (size_t)ld)))
+            if (!(dev.H = (uint16_t*)be.alloc(sizeof(uint16_t) * (size_t)nrows * (size_t)ldh)))
                 return fail(FNN_ENOMEM, "fnn_create: device allocation of the bf16 copy failed (" + be.err() + ")");
         }
         // zero the padding once so that stray loads never see signalling patterns

@@ -257,8 +257,8 @@ __device__ __forceinline__ void screen_tile_fast(const Dev& d, int rbase, int c0
         uint4 a[SCR_BATCH], b[SCR_BATCH];
 #pragma unroll
         for (int k = 0; k < SCR_BATCH; k++) {
-            a[k] = ld16h<NT>(colbase + (int64_t)(rb + 2 * k) * d.ld);
-            b[k] = ld16h<NT>(colbase + (int64_t)(rb + 2 * k + 1) * d.ld);
+            a[k] = ld16h<NT>(colbase + (int64_t)(rb + 2 * k) * d.ldh);
+            b[k] = ld16h<NT>(colbase + (int64_t)(rb + 2 * k + 1) * d.ldh);
         }
 #pragma unroll
         for (int k = 0; k < SCR_BATCH; k++) {
@@ -307,8 +307,8 @@ __device__ __forceinline__ void screen_tile_nonneg(const Dev& d, int rbase, int 
         uint4 a[SCR_BATCH], b[SCR_BATCH];
 #pragma unroll
         for (int k = 0; k < SCR_BATCH; k++) {
-            a[k] = ld16h<NT>(colbase + (int64_t)(rb + 2 * k) * d.ld);
-            b[k] = ld16h<NT>(colbase + (int64_t)(rb + 2 * k + 1) * d.ld);
+            a[k] = ld16h<NT>(colbase + (int64_t)(rb + 2 * k) * d.ldh);
+            b[k] = ld16h<NT>(colbase + (int64_t)(rb + 2 * k + 1) * d.ldh);
         }
 #pragma unroll
         for (int k = 0; k < SCR_BATCH; k++) {
@@ -432,8 +432,8 @@ __global__ __launch_bounds__(256) void k_emit(Dev d) {
                 uint4 a[4], b[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    a[q] = ld16h<false>(colbase + (int64_t)(rb + 2 * q) * d.ld);
-                    b[q] = ld16h<false>(colbase + (int64_t)(rb + 2 * q + 1) * d.ld);
+                    a[q] = ld16h<false>(colbase + (int64_t)(rb + 2 * q) * d.ldh);
+                    b[q] = ld16h<false>(colbase + (int64_t)(rb + 2 * q + 1) * d.ldh);
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(256) void k_screen(Dev d) {
 #pragma unroll
                 for (int k = 0; k < SCR_BATCH; k++) {
                     const int r0 = rb + 2 * k;  // rows < nrows (padded), c0 + 7 < ld (ld padded to 2048)
-                    a[k] = ld16h<NT>(colbase + (int64_t)r0 * d.ld);
-                    b[k] = ld16h<NT>(colbase + (int64_t)(r0 + 1) * d.ld);
+                    a[k] = ld16h<NT>(colbase + (int64_t)r0 * d.ldh);
+                    b[k] = ld16h<NT>(colbase + (int64_t)(r0 + 1) * d.ldh);
                 }
 #pragma unroll
                 for (int k = 0; k < SCR_BATCH; k++) {
@@ -763,8 +763,8 @@ __global__ __launch_bounds__(256) void k_prep_screen(Dev d, int64_t nrows) {
     const int64_t total = nrows * d.ld;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const double v = d.D[i];
-        if (d.H) d.H[i] = bf16_from_double(v);
         const int64_t r = i / d.ld, c = i - r * d.ld;
+        if (d.H) d.H[r * d.ldh + c] = bf16_from_double(v);
         if (r < d.n && c < d.n) {
             const unsigned long long x = f2u(v) & 0x7FFFFFFFFFFFFFFFULL;
             b = x > b ? x : b;
@@ -2350,7 +2350,7 @@ __global__ __launch_bounds__(256) void k_update(Dev d, int defer, int ticks) {
                     const int64_t rb = (int64_t)dst * d.ld;
                     d.D[rb + k] = nv[t];
                     d.D[rk + dst] = nv[t];
-                    if (d.H) d.H[k < dst ? rb + k : rk + dst] = bf16_from_double(nv[t]);
+                    if (d.H) d.H[k < dst ? (int64_t)dst * d.ldh + k : (int64_t)k * d.ldh + dst] = bf16_from_double(nv[t]);
                 }
             }
         }

@@ -116,7 +116,7 @@ struct EmuBackend {
         for (int64_t r = 0; r < nrows; r++)
             for (int64_t c = 0; c < d.ld; c++) {
                 double v = d.D[r * d.ld + c];
-                if (d.H) d.H[r * d.ld + c] = fnn::bf16_from_double(v);
+                if (d.H) d.H[r * d.ldh + c] = fnn::bf16_from_double(v);
                 uint64_t b;
                 std::memcpy(&b, &v, 8);
                 b &= 0x7FFFFFFFFFFFFFFFULL;
@@ -182,8 +182,8 @@ struct EmuBackend {
                 const int32_t rb = rt * fnn::SCR_TH, cb = ct * fnn::SCR_TW + (u % 4) * fnn::SCR_UW;
                 for (int32_t r0 = rb; r0 < rb + fnn::SCR_TH && r0 < m; r0 += 2)
                     for (int32_t c0 = cb; c0 < cb + fnn::SCR_UW && c0 <= r0; c0 += 2) {
-                        const uint16_t* R0 = d.H + (int64_t)r0 * d.ld;
-                        const uint16_t* R1 = d.H + (int64_t)(r0 + 1) * d.ld;
+                        const uint16_t* R0 = d.H + (int64_t)r0 * d.ldh;
+                        const uint16_t* R1 = d.H + (int64_t)(r0 + 1) * d.ldh;
                         bool r1 = r0 + 1 < m, c1 = c0 + 1 < m;
                         const float e00 = fnn::bf16_to_float(R0[c0]), e01 = fnn::bf16_to_float(R0[c0 + 1]);
                         const float e10 = fnn::bf16_to_float(R1[c0]), e11 = fnn::bf16_to_float(R1[c0 + 1]);
