@@ -1,12 +1,15 @@
 // fnn_splits.hip -- circular split weights (non-negative least squares) on gfx950.
 //
-// The "next" row N1 of SURVEY.md 8(f): given the circular ordering, estimate the weights of the
-// n(n-1)/2 circular splits by constrained (x >= 0) ordinary least squares, as the reference does
-// with an active-set method around a conjugate-gradient solve on implicit operators
-// (CircularSplitWeights.java:366-557 runActiveConjugate, :769-831 circularConjugateGrads,
-// :603-731 calculateAtx / calculateAb, :247-271 runUnconstrainedLS, :283-337 worstIndices), with
-// the re-ordering of the distances by the circular ordering restored (setupD :202-211)
-// and the result mapped to the index space of the reference's live path (FastNN.java:405-419).
+// The "next" row N1 of SURVEY.md 8(f): given the circular ordering, the weights of the n(n-1)/2 circular splits are
+// the solution of the non-negative least-squares problem min |A x - d|, x >= 0 - what the reference's live path computes
+// with a dense design matrix and a third-party Lawson-Hanson solver (FastNN.java:401-454), here on the implicit
+// operators of CircularSplitWeights.java (:603-731 calculateAtx / calculateAb) with the re-ordering of the distances by
+// the circular ordering restored (setupD :202-211) and the result in the index space of the live path
+// (FastNN.java:405-419).  Method: the closed-form unconstrained optimum if it is feasible; else Lawson-Hanson "from
+// below" on closed-form entries of A^T A with an explicitly maintained inverse of the free block (rank-one updates by
+// rocBLAS, rebuilds by rocSOLVER), Kuhn-Tucker test on a fresh inverse; the reference's own active-set / conjugate-
+// gradient method (:366-557 runActiveConjugate, :769-831 circularConjugateGrads, :283-337 worstIndices) remains as the
+// fallback and behind FNN_SW_REFERENCE_METHOD=1 (it stops short of the optimum by ~1e-5: DESIGN.md section 7).
 //
 // GPU formulation.  All vectors of the method (split weights x, distances d, residuals ...) are
 // kept as the strict upper triangle of dense n x n fp64 arrays: entry [i][j], i < j, is the split
@@ -20,9 +23,9 @@
 //                 = (RS[j] - RS[i]) - 2 (P[j][j] - P[i][j]),  RS = prefix of the row sums of the
 //                   symmetric completion of y.
 // Everything is bandwidth-bound elementwise / scan work on n^2 doubles; the control flow of the
-// active-set method (a handful of scalars per step) runs on the host.  Results agree with the
-// reference's algorithm to rounding (different summation order), not bit for bit; the optimum is
-// unique and the tests hold the weights to 1e-6 relative of the oracle and of a dense NNLS solve.
+// solver (a handful of scalars per step) runs on the host.  The optimum is unique (A is square and non-singular); the
+// tests hold the weights to 1e-6 of a dense NNLS solve of the live path's problem where that is computable (n <= 64),
+// to the known weights of generated circular metrics up to 4096 taxa, and to the Kuhn-Tucker conditions beyond.
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>

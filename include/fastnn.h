@@ -54,10 +54,10 @@ typedef struct fnn_opts {
                               sequential-sum kernel instead of certifying the 4-candidate choice
                               from tree sums (same result; exercises the rare path) */
     int32_t disable_screen;/* 1 = always scan the fp64 matrix in full; default (0): from 4096 taxa on, events
-                              with >= 2048 live nodes first stream a bf16 copy of the matrix (2 bytes per entry,
-                              a quarter of the fp64 bytes) to find, within a rigorous error bound, the few
-                              32 x 512 tile units that can hold the minimum; only those are rescanned in
-                              fp64 (same result) */
+                              with >= min(2048, n / 4) live nodes (not below 512) first stream a bf16 copy of the
+                              matrix (2 bytes per entry, a quarter of the fp64 bytes) to find, within a rigorous
+                              error bound, the few 32 x 512 tile units that can hold the minimum; only those are
+                              rescanned in fp64 (same result) */
     int32_t lookahead;     /* events one screening pass may serve ("lookahead window"): 0 = default
                               (min(16 + n / 1024, 64) at most, and min(that, 16 + m / 1024) for a window opened
                               with m live nodes: 48 at n = 32768), < 0 = off (every event scans), > 0 = that

@@ -34,3 +34,10 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_sw_${TAG} -- python3 $GRAFT_REPO_ROOT/tests/tools/splits_perf.py 2048 > $OUT/${TAG}_splits_perf_n2048.log 2>&1
 find /tmp/prof_sw_${TAG} -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_splits_kernel_stats_n2048.csv \;
 tail -1 $OUT/${TAG}_splits_perf_n2048.log; head -8 $OUT/${TAG}_splits_kernel_stats_n2048.csv | cut -c1-140
+cd $GRAFT_REPO_ROOT
+#   6. the Relaxed mode (one workgroup searching for mutual row minima): whole runs and the kernel statistics of one
+python3 tools/relaxed_perf.py 4096 16384 > $OUT/${TAG}_relaxed_perf.log 2>&1; cat $OUT/${TAG}_relaxed_perf.log
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_rl_${TAG} -- python3 $GRAFT_REPO_ROOT/tools/relaxed_perf.py 4096 > /dev/null 2>&1
+find /tmp/prof_rl_${TAG} -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_relaxed_kernel_stats_n4096.csv \;
+head -6 $OUT/${TAG}_relaxed_kernel_stats_n4096.csv | cut -c1-140
