@@ -317,7 +317,7 @@ def main():
                 "algorithmic_bytes_note": "per launch: E_t = m(m-1)/2 - (m-c) entries at 2 B (the bf16 copy) + the fp64 rescans of "
                                           "the candidate units (32 x 512 x 8 B each)",
                 "per_gpu": args.gpus > 1,
-                "plain_fp64_scan": {"kernel": "fnn::k_scan<true> (events below the screening threshold of 2048 live nodes)",
+                "plain_fp64_scan": {"kernel": "fnn::k_scan<true> (events below the screening threshold of min(2048, n/4) live nodes)",
                                     "launches": int(st.plain_launches),
                                     "achieved": round(float(st.plain_bytes) / max(st.t_plain_s, 1e-12) / 1e9, 1),
                                     "avg_launch_us": round(st.t_plain_s / max(st.plain_launches, 1) * 1e6, 2)},
