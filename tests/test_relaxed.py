@@ -151,3 +151,17 @@ def test_gpu_cli_and_host_mirrors_in_relaxed_mode(oracle, tmp_path):
     assert (nn.runNeighborNet() == o_ref).all() and nn.stats["n_relaxed_events"] > 0
     with pytest.raises(NotImplementedError):
         fa.NeighborNetLocal(D2, n, 1, True, None, seed=seed)
+
+
+def test_relaxed_mode_rejects_several_ranks_and_bad_modes(emu_api):
+    import ctypes as C
+
+    from fastneighbornet_amd._capi import FnnError, FnnOpts
+    with Handle(emu_api, 64, relaxed_seed=1) as h:
+        with pytest.raises(FnnError, match="one GPU"):
+            h.comm_init_host(2, 0, lambda send: [send, send])
+        h.comm_init_host(1, 0, lambda send: [send])   # a world of one is fine
+    opts = FnnOpts()
+    opts.mode = 7
+    out = C.c_void_p()
+    assert emu_api.create(8, C.byref(opts), C.byref(out)) < 0
