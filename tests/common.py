@@ -10,9 +10,10 @@ def bits(a):
 
 def compare_trajectory(api, oracle, D, deep=True, deep_every=1, **hkw):
     """Step engine and oracle together; every event record must agree exactly; with
-    `deep`, node ids / partners / Sx bits / the whole live matrix are compared too."""
+    `deep`, node ids / partners / Sx bits / the whole live matrix are compared too.
+    (relaxed_seed / relaxed_min_active in hkw put both sides into the Relaxed mode.)"""
     n = D.shape[0]
-    st = oracle.Stepper(D)
+    st = oracle.Stepper(D, relaxed_seed=hkw.get("relaxed_seed"), relaxed_min_active=hkw.get("relaxed_min_active", 0))
     h = Handle(api, n, **hkw)
     try:
         h.set_matrix(D)

@@ -99,6 +99,21 @@ def test_emulation_matches_oracle(emu_api, oracle, n, seed, dist, min_active):
     compare(emu_api, oracle, oracle.synth(n, seed, dist), 1000 + seed, min_active)
 
 
+@pytest.mark.parametrize("n,dist", [(40, "uniform53"), (150, "dec4")])
+def test_emulation_deep_state_matches_oracle(emu_api, oracle, n, dist):
+    """after every event: node ids, partners, Sx bits and the live matrix bits (the merges are the Canonical ones, but
+    here Cx / Cy need not be their clusters' representatives)"""
+    from common import compare_trajectory
+    compare_trajectory(emu_api, oracle, oracle.synth(n, 11, dist), relaxed_seed=77, relaxed_min_active=4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,dist", [(65, "uniform53"), (300, "dec4")])
+def test_gpu_deep_state_matches_oracle(hip_api, oracle, n, dist):
+    from common import compare_trajectory
+    compare_trajectory(hip_api, oracle, oracle.synth(n, 12, dist), relaxed_seed=78, relaxed_min_active=4)
+
+
 def test_emulation_default_threshold(emu_api, oracle):
     compare(emu_api, oracle, oracle.synth(1300, 9), 5, 0)   # 1300 -> 1024 relaxed, then the full scans
 
