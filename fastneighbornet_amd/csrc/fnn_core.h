@@ -1311,24 +1311,24 @@ FNN_HD double rl_q(const Dev& d, int32_t ps, int32_t pp, int32_t qs, int32_t qp,
     return (cm2 * Dpq - sxp) - d.Sx[qs];
 }
 
-struct RlRow { int32_t me, cnt; double value; };
+struct RlRow { int32_t me, cnt; double value; int32_t l0, l1; };  // (l0, l1: the first two rows of the list)
 
-// findRowMin (:88-157): the cached list of p, else of p.nbr, else computed (and cached under p)
+// The control wave pays one global round trip per dependent load, so independent loads are issued together: `Env`
+// has load3 / load4 (several words, one round trip) and row(key) (count, value and the first two rows of a cached
+// list); a row minimum that was just computed comes back from the workgroup without touching memory.
+
+// findRowMin (:88-157): the cached list of p, else of p.nbr, else computed (and cached under p).  sp / sn: the stamps
+// of p's and p.nbr's cache entries (sn = 0 without a partner).
 template <class Env>
-FNN_HD RlRow rl_find_row_min(const Dev& d, Env& env, int32_t ps, int32_t pp, int32_t stamp, int64_t& evals) {
-    int32_t key;
-    if (env.load(&d.rl_stamp[ps]) == stamp) key = ps;
-    else if (pp >= 0 && env.load(&d.rl_stamp[pp]) == stamp) key = pp;
-    else {
-        env.rowmin(d, ps, pp, stamp);
-        evals += (int64_t)d.st->m - 1 - (pp >= 0 ? 1 : 0);
-        key = ps;
-    }
-    RlRow r;
-    r.me = key;
-    r.cnt = env.load(&d.rl_cnt[key]);
-    r.value = env.loadd(&d.rl_val[key]);
-    return r;
+FNN_HD RlRow rl_find_row_min(const Dev& d, Env& env, int32_t ps, int32_t pp, int32_t sp, int32_t sn, int32_t stamp, int64_t& evals) {
+    if (sp == stamp) return env.row(d, ps);
+    if (pp >= 0 && sn == stamp) return env.row(d, pp);
+    evals += (int64_t)d.st->m - 1 - (pp >= 0 ? 1 : 0);
+    return env.rowmin(d, ps, pp, stamp);
+}
+template <class Env>
+FNN_HD int32_t rl_list_at(const Dev& d, Env& env, const RlRow& r, int32_t k) {
+    return k == 0 ? r.l0 : (k == 1 ? r.l1 : env.load(&d.rl_list[(int64_t)r.me * RL_TIES + k]));
 }
 
 // findNodes (:170-264).  Returns the pair as a candidate record {value, slots of Cx = combineMe.me and Cy = combineMe.row};
@@ -1349,9 +1349,9 @@ FNN_HD Cand relaxed_find(const Dev& d, Env& env) {
     bool found = false;
     for (int32_t i = top + 1; i > 0; i--) {
         const int32_t swapCell = rng.next_int(i);
-        const int32_t vsc = env.load(&d.rperm[swapCell]);
+        int32_t vsc, vi, vt;  // rowPermutation[swapCell], [i-1], [top]  (0 <= i-1 <= top inside the loop)
+        env.load3(&d.rperm[swapCell], &d.rperm[i - 1], &d.rperm[top], vsc, vi, vt);
         if (vsc >= m) {  // a position that is no longer active: drop it from the permutation (:188-198)
-            const int32_t vt = env.load(&d.rperm[top]);
             env.store(&d.rperm[swapCell], vt);
             env.store(&d.rperm[top], vsc);
             if (i == top + 1) i--;
@@ -1359,20 +1359,24 @@ FNN_HD Cand relaxed_find(const Dev& d, Env& env) {
             top--;
             continue;
         }
-        const int32_t vi = env.load(&d.rperm[i - 1]);  // swap(rowPermutation, i-1, swapCell) (:199)
-        env.store(&d.rperm[i - 1], vsc);
+        env.store(&d.rperm[i - 1], vsc);  // swap(rowPermutation, i-1, swapCell) (:199)
         env.store(&d.rperm[swapCell], vi);
         const int32_t ps = env.load(&d.pslot[vsc]);   // p = netNodes[rowPermutation[i-1]]
         const int32_t pp = ps < twoP ? (ps ^ 1) : -1;
-        if (pp >= 0 && env.load(&d.sid[pp]) < env.load(&d.sid[ps])) continue;  // one node per cluster (:201-203)
-        const RlRow r1 = rl_find_row_min(d, env, ps, pp, stamp, evals);
+        int32_t idp, idn, sp, sn;  // ids and cache stamps of p and p.nbr
+        env.load4(&d.sid[ps], &d.sid[pp >= 0 ? pp : ps], &d.rl_stamp[ps], &d.rl_stamp[pp >= 0 ? pp : ps], idp, idn, sp, sn);
+        if (pp >= 0 && idn < idp) continue;  // one node per cluster (:201-203)
+        const RlRow r1 = rl_find_row_min(d, env, ps, pp, sp, pp >= 0 ? sn : 0, stamp, evals);
         rows0++;
         for (int32_t a = 0; a < r1.cnt; a++) {
-            const int32_t other = env.load(&d.rl_list[(int64_t)r1.me * RL_TIES + a]);
+            const int32_t other = rl_list_at(d, env, r1, a);
             const int32_t op = other < twoP ? (other ^ 1) : -1;
-            const RlRow r2 = rl_find_row_min(d, env, other, op, stamp, evals);
+            int32_t so, son, u0, u1;
+            env.load4(&d.rl_stamp[other], &d.rl_stamp[op >= 0 ? op : other], &d.rl_stamp[other], &d.rl_stamp[other], so, son, u0, u1);
+            (void)u0; (void)u1;
+            const RlRow r2 = rl_find_row_min(d, env, other, op, so, op >= 0 ? son : 0, stamp, evals);
             for (int32_t b = 0; b < r2.cnt; b++) {
-                const int32_t row = env.load(&d.rl_list[(int64_t)r2.me * RL_TIES + b]);
+                const int32_t row = rl_list_at(d, env, r2, b);
                 const int32_t rowp = row < twoP ? (row ^ 1) : -1;
                 // testRM.row is p or p.nbr (the four clauses of :210-212)
                 if (row == ps || (rowp >= 0 && rowp == ps) || (rowp >= 0 && pp >= 0 && rowp == pp) || (pp >= 0 && row == pp)) {
@@ -1420,7 +1424,20 @@ struct RlSerialEnv {
         c.key = ((uint64_t)(uint32_t)d.spos[kme[i]] << 32) | (uint64_t)(uint32_t)d.spos[krow[i]];
         return c;
     }
-    FNN_HD void rowmin(const Dev& d, int32_t ps, int32_t pp, int32_t stamp) {  // NeighborNetLocal.java:96-125
+    FNN_HD void load3(const int32_t* pa, const int32_t* pb, const int32_t* pc, int32_t& a, int32_t& b, int32_t& c) const {
+        a = *pa; b = *pb; c = *pc;
+    }
+    FNN_HD void load4(const int32_t* pa, const int32_t* pb, const int32_t* pc, const int32_t* pd, int32_t& a, int32_t& b,
+                      int32_t& c, int32_t& dd) const {
+        a = *pa; b = *pb; c = *pc; dd = *pd;
+    }
+    FNN_HD RlRow row(const Dev& d, int32_t key) const {
+        RlRow r;
+        r.me = key; r.cnt = d.rl_cnt[key]; r.value = d.rl_val[key];
+        r.l0 = d.rl_list[(int64_t)key * RL_TIES]; r.l1 = d.rl_list[(int64_t)key * RL_TIES + 1];
+        return r;
+    }
+    FNN_HD RlRow rowmin(const Dev& d, int32_t ps, int32_t pp, int32_t stamp) {  // NeighborNetLocal.java:96-125
         const State& st = *d.st;
         const int32_t m = st.m, twoP = 2 * st.P;
         const double cm2 = (double)st.c - 2.0, sxp = d.Sx[ps];
@@ -1440,6 +1457,7 @@ struct RlSerialEnv {
         d.rl_stamp[ps] = stamp;
         d.rl_cnt[ps] = cnt;
         d.rl_val[ps] = myMin;
+        return row(d, ps);
     }
 };
 

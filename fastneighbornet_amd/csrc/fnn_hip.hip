@@ -1629,6 +1629,8 @@ struct RlLds {
     double gmin;
     int32_t kme[RL_MINS], krow[RL_MINS];
     double kval[RL_MINS];
+    int32_t tkon;
+    long long tk[4];           // diagnostics (FNN_TICKS=1): ticks in {row-minimum pass, its finish, the rest}, row minima
 };
 
 // rl_q (fnn_core.h) without branches: the four entries are loaded whatever the kinds of p and q (the partner column
@@ -1650,17 +1652,51 @@ __device__ __forceinline__ void rl_rowmin_block(const Dev& d, RlLds& L) {
     const int tid = threadIdx.x;
     // ONE pass, over the live slots [0, m) instead of the positions (a minimum does not depend on the order; the row
     // of p is then read contiguously): every thread keeps its minimum, the first slot that attains it and how many do
+    // (the second pass below, for a thread with several, is rare: the two nodes of a cluster - the usual tie - are
+    //  one thread's pair, so that thread goes over its slots again)
     double mine = 1.7976931348623157e308;  // Double.MAX_VALUE (:95)
-    int32_t mslot = -1, mcnt = 0;
+    int32_t mslot = -1, mslot2 = -1, mcnt = 0;  // (the first two slots that attain it: the two nodes of a cluster tie)
     const double* Rp = d.D + (int64_t)ps * d.ld;
     const double* Rn = d.D + (int64_t)(pp >= 0 ? pp : ps) * d.ld;
     const bool ppair = pp >= 0;
-#pragma unroll 4
-    for (int32_t qs = tid; qs < m; qs += RL_T) {
-        const double q = rl_q_flat(Rp, Rn, d.Sx, ppair, twoP, qs, cm2, sxp);
-        if (qs == ps || qs == pp) continue;
-        if (q < mine) { mine = q; mslot = qs; mcnt = 1; }
-        else if (q == mine) { if (mcnt == 0) mslot = qs; mcnt++; }
+    // A thread takes slot PAIRS (2j, 2j + 1): the pair's entries in p's row, in the partner's row and its two row sums
+    // are three 16-byte loads; eight pairs per round, all 24 loads issued before the first value is used (left to
+    // itself the compiler sinks the partner row's loads into the branch that needs them: two dependent round trips per
+    // slot).  One round covers 16 384 slots; a round costs about one HBM latency (~4 us) whatever it loads.
+    constexpr int RL_PAIRS = 8;
+    const int32_t npairs = (m + 1) >> 1;
+    for (int32_t j0 = tid; j0 < npairs; j0 += RL_PAIRS * RL_T) {
+        double2 A[RL_PAIRS], Cc[RL_PAIRS], S[RL_PAIRS];
+        const int32_t nu = (npairs - (j0 - tid) + RL_T - 1) / RL_T;  // (uniform: the pairs this round still has, in units of RL_T)
+#pragma unroll
+        for (int u = 0; u < RL_PAIRS; u++) {
+            A[u] = Cc[u] = S[u] = make_double2(0.0, 0.0);
+            if (u < nu) {
+                const int32_t j = j0 + u * RL_T, jj = j < npairs ? j : npairs - 1;
+                A[u] = *reinterpret_cast<const double2*>(Rp + 2 * jj);
+                Cc[u] = *reinterpret_cast<const double2*>(Rn + 2 * jj);
+                S[u] = *reinterpret_cast<const double2*>(d.Sx + 2 * jj);
+            }
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < RL_PAIRS; u++) {
+            const int32_t j = j0 + u * RL_T;
+            if (j >= npairs) continue;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int32_t qs = 2 * j + h;
+                if (qs >= m || qs == ps || qs == pp) continue;
+                const bool qpair = qs < twoP;
+                const double a = h ? A[u].y : A[u].x, b = h ? A[u].x : A[u].y;      // D[p][q], D[p][q.nbr]
+                const double c = h ? Cc[u].y : Cc[u].x, e = h ? Cc[u].x : Cc[u].y;  // D[p.nbr][q], D[p.nbr][q.nbr]
+                const double t01 = (a + b) / 2.0, t10 = (a + c) / 2.0, t11 = (((a + b) + c) + e) / 4.0;
+                const double Dpq = ppair ? (qpair ? t11 : t10) : (qpair ? t01 : a);
+                const double q = (cm2 * Dpq - sxp) - (h ? S[u].y : S[u].x);
+                if (q < mine) { mine = q; mslot = qs; mcnt = 1; }
+                else if (q == mine) { if (mcnt == 0) mslot = qs; else if (mcnt == 1) mslot2 = qs; mcnt++; }
+            }
+        }
     }
     double wm = mine;
 #pragma unroll
@@ -1675,20 +1711,23 @@ __device__ __forceinline__ void rl_rowmin_block(const Dev& d, RlLds& L) {
 #pragma unroll
     for (int w = 1; w < RL_T / 64; w++) { const double o = L.wmin[w]; if (o < g) g = o; }
     // the rows that attain it, with their positions (the list is in position order, :98); a thread with several
-    // (the two nodes of a cluster sit in adjacent slots, i.e. in different threads: rare) goes over its slots again
+    // (usually the two nodes of one cluster, which are one thread's pair) goes over its slots again
     if (mcnt > 0 && mine == g) {
-        if (mcnt == 1) {
-            const int k = atomicAdd(&L.tcnt, 1);
+        if (mcnt <= 2) {
+            const int k = atomicAdd(&L.tcnt, mcnt);
             if (k < RL_TIES) { L.tpos[k] = d.spos[mslot]; L.tslot[k] = mslot; }
+            if (mcnt == 2 && k + 1 < RL_TIES) { L.tpos[k + 1] = d.spos[mslot2]; L.tslot[k + 1] = mslot2; }
         } else {
-            for (int32_t qs = tid; qs < m; qs += RL_T) {
-                if (qs == ps || qs == pp) continue;
-                const double q = rl_q_flat(Rp, Rn, d.Sx, ppair, twoP, qs, cm2, sxp);
-                if (q == g) {
-                    const int k = atomicAdd(&L.tcnt, 1);
-                    if (k < RL_TIES) { L.tpos[k] = d.spos[qs]; L.tslot[k] = qs; }
+            for (int32_t j = tid; j < npairs; j += RL_T)  // this thread's own pairs again (same expression, same bits)
+                for (int h = 0; h < 2; h++) {
+                    const int32_t qs = 2 * j + h;
+                    if (qs >= m || qs == ps || qs == pp) continue;
+                    const double q = rl_q_flat(Rp, Rn, d.Sx, ppair, twoP, qs, cm2, sxp);
+                    if (q == g) {
+                        const int k = atomicAdd(&L.tcnt, 1);
+                        if (k < RL_TIES) { L.tpos[k] = d.spos[qs]; L.tslot[k] = qs; }
+                    }
                 }
-            }
         }
     }
     if (tid == 0) L.gmin = g;
@@ -1722,13 +1761,47 @@ struct RlBlockEnv {
         c.key = ((uint64_t)(uint32_t)load(&d.spos[c.si]) << 32) | (uint64_t)(uint32_t)load(&d.spos[c.sj]);
         return c;
     }
-    __device__ __forceinline__ void rowmin(const Dev& d, int32_t ps, int32_t pp, int32_t stamp) {
+    __device__ __forceinline__ void load3(const int32_t* pa, const int32_t* pb, const int32_t* pc, int32_t& a, int32_t& b, int32_t& c) const {
+        int32_t x = 0, y = 0, z = 0;
+        if (lane == 0) { x = *pa; y = *pb; z = *pc; }  // (issued together: one round trip)
+        a = __builtin_amdgcn_readfirstlane(x); b = __builtin_amdgcn_readfirstlane(y); c = __builtin_amdgcn_readfirstlane(z);
+    }
+    __device__ __forceinline__ void load4(const int32_t* pa, const int32_t* pb, const int32_t* pc, const int32_t* pd, int32_t& a,
+                                          int32_t& b, int32_t& c, int32_t& dd) const {
+        int32_t x = 0, y = 0, z = 0, w = 0;
+        if (lane == 0) { x = *pa; y = *pb; z = *pc; w = *pd; }
+        a = __builtin_amdgcn_readfirstlane(x); b = __builtin_amdgcn_readfirstlane(y);
+        c = __builtin_amdgcn_readfirstlane(z); dd = __builtin_amdgcn_readfirstlane(w);
+    }
+    __device__ __forceinline__ RlRow row(const Dev& d, int32_t key) const {  // a cached list: one round trip
+        int32_t cnt = 0, l0 = 0, l1 = 0;
+        uint64_t v = 0;
+        if (lane == 0) {
+            cnt = d.rl_cnt[key];
+            v = __builtin_bit_cast(uint64_t, d.rl_val[key]);
+            const int2 l = *reinterpret_cast<const int2*>(d.rl_list + (int64_t)key * RL_TIES);
+            l0 = l.x; l1 = l.y;
+        }
+        RlRow r;
+        r.me = key;
+        r.cnt = __builtin_amdgcn_readfirstlane(cnt);
+        r.l0 = __builtin_amdgcn_readfirstlane(l0);
+        r.l1 = __builtin_amdgcn_readfirstlane(l1);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        r.value = __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo);
+        return r;
+    }
+    __device__ __forceinline__ RlRow rowmin(const Dev& d, int32_t ps, int32_t pp, int32_t stamp) {
+        long long t0 = 0, t1 = 0;
+        if (L.tkon) t0 = (long long)wall_clock64();
         if (lane == 0) { L.cmd = 1; L.ps = ps; L.pp = pp; }
         __syncthreads();          // the other waves pick the command up
         rl_rowmin_block(d, L);
+        if (L.tkon) t1 = (long long)wall_clock64();
         if (lane == 0) {
             int32_t cnt = L.tcnt;
-            if (cnt > RL_TIES) { L.err = 20; cnt = RL_TIES; }
+            if (cnt > RL_TIES) { L.err = 20; cnt = RL_TIES; L.tcnt = cnt; }
             for (int i = 1; i < cnt; i++) {  // position order (:98 walks the rows in order)
                 const int32_t kp = L.tpos[i], ks = L.tslot[i];
                 int j = i - 1;
@@ -1740,24 +1813,37 @@ struct RlBlockEnv {
             d.rl_cnt[ps] = cnt;
             d.rl_val[ps] = L.gmin;
         }
+        if (L.tkon && lane == 0) { L.tk[0] += t1 - t0; L.tk[1] += (long long)wall_clock64() - t1; L.tk[3]++; }
+        // the result straight from LDS (the same wave wrote it: LDS operations of a wave complete in order)
+        RlRow r;
+        r.me = ps;
+        r.cnt = L.tcnt;
+        r.value = L.gmin;
+        r.l0 = L.tslot[0];
+        r.l1 = L.tslot[1];
+        return r;
     }
 };
 
-__global__ __launch_bounds__(RL_T) void k_relaxed(Dev d) {
+__global__ __launch_bounds__(RL_T) void k_relaxed(Dev d, int ticks) {
     __shared__ RlLds L;
     State* st = d.st;
+    const long long tstart = ticks ? (long long)wall_clock64() : 0;
     // (uniform: every thread reads the same words; nothing writes to the control block before the end)
     const bool run = !st->done && st->rl_on && st->m > st->rl_min && st->m > 3 && !(st->m == 4 && st->c == 2);
     if (!run) {
         if (threadIdx.x == 0) st->rl_active = 0;
         return;
     }
-    if (threadIdx.x == 0) { L.err = 0; L.cmd = 0; }
+    if (threadIdx.x == 0) { L.err = 0; L.cmd = 0; L.tkon = ticks; L.tk[0] = L.tk[1] = L.tk[2] = L.tk[3] = 0; }
     __syncthreads();
     if (threadIdx.x < 64) {
         RlBlockEnv env{L, (int)threadIdx.x};
         const Cand out = relaxed_find(d, env);
         if (threadIdx.x == 0) { d.recs[0] = out; L.cmd = 2; }
+        if (ticks && threadIdx.x == 0) {
+            d.ticks[24] += L.tk[0]; d.ticks[25] += L.tk[1]; d.ticks[26] += (long long)wall_clock64() - tstart; d.ticks[27] += L.tk[3];
+        }
         __syncthreads();
     } else {
         for (;;) {
@@ -2807,7 +2893,7 @@ struct HipBackend {
             // Relaxed mode: the search first; the scan returns at once if it found the pair (it runs when fewer
             // nodes are live than the bound the host knows, i.e. at the switch to the full scans)
             if (relaxed_min > 0 && m_bound > relaxed_min)
-                timed(TC_OTHER, tall, [&]() { hipLaunchKernelGGL(k_relaxed, dim3(1), dim3(RL_T), 0, stream, d); });
+                timed(TC_OTHER, tall, [&]() { hipLaunchKernelGGL(k_relaxed, dim3(1), dim3(RL_T), 0, stream, d, ticks ? 1 : 0); });
             timed(TC_SCAN, tscan, [&]() {
                 if (scan_nt) hipLaunchKernelGGL(k_scan<true>, gs, dim3(SCAN_THREADS), 0, stream, d);
                 else hipLaunchKernelGGL(k_scan<false>, gs, dim3(SCAN_THREADS), 0, stream, d);
@@ -3002,6 +3088,12 @@ int32_t fnn_debug_update_ticks(fnn_handle* h, int64_t* out8) {
     FNN_NEED(h);
     if (!out8) return fnn::fail(FNN_EINVAL, "fnn_debug_update_ticks: out8 is NULL");
     if (h->eng.be.d2h(out8, h->eng.dev.ticks + 8, sizeof(int64_t) * 8) != FNN_OK) return FNN_EHIP;
+    return FNN_OK;
+}
+int32_t fnn_debug_relaxed_ticks(fnn_handle* h, int64_t* out4) {
+    FNN_NEED(h);
+    if (!out4) return fnn::fail(FNN_EINVAL, "fnn_debug_relaxed_ticks: out4 is NULL");
+    if (h->eng.be.d2h(out4, h->eng.dev.ticks + 24, sizeof(int64_t) * 4) != FNN_OK) return FNN_EHIP;
     return FNN_OK;
 }
 int32_t fnn_debug_decide_ticks(fnn_handle* h, int64_t* out4) {

@@ -193,6 +193,9 @@ int32_t fnn_debug_update_ticks(fnn_handle* h, int64_t* out8);
 /* ... and the decide step inside k_track's tail: {the one round trip of loads, Cx/Cy + certified choice, merge plan,
  * symbolic replay of the micro-ops}. */
 int32_t fnn_debug_decide_ticks(fnn_handle* h, int64_t* out4);
+/* Relaxed mode, FNN_TICKS=1: 100 MHz ticks summed over the run in {the workgroup's row-minimum passes, their finish by
+ * the control lane, the whole search kernels}, and the number of row minima computed. */
+int32_t fnn_debug_relaxed_ticks(fnn_handle* h, int64_t* out4);
 
 /* Per-launch HIP-event timing on the engine's stream (two event records per timed launch): 1 = the streaming scan
  * kernels only (bench.py's roofline figure: fnn_stats.t_scan_s / scan_launches), 2 = every kernel of the launch
