@@ -223,6 +223,7 @@ struct Dev {
     int32_t* rl_cnt;
     int32_t* rl_list;  // RL_TIES slots per slot
     double* rl_val;
+    uint64_t* rl_mail; // several workgroups in k_relaxed: command word, arrival counter, per-workgroup records (RL_MAIL_WORDS)
     State* st;
     Event* evlog;    // n records (if record_events)
     Agg3Rec* agglog; // n records
@@ -1278,6 +1279,9 @@ FNN_HD void t_finalize(const Dev& d) {
 // ---------------------------------------------------------------------------
 constexpr int RL_TIES = 16;
 constexpr int RL_MINS = 64;
+constexpr int RL_GMAX = 16;                       // workgroups the row pass of one minimum may be spread over
+constexpr int RL_REC_WORDS = 2 + RL_TIES;         // a workgroup's record: value, (count | tag), RL_TIES (position | slot)
+constexpr int RL_MAIL_WORDS = 32 + RL_GMAX * 32;  // command word (line 0), arrival counter (line 1), records (256 B apart)
 
 struct JavaRandom {  // java.util.Random: next(bits), nextInt(bound)
     uint64_t s;

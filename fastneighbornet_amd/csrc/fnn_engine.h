@@ -115,7 +115,8 @@ class Engine {
                            !(dev.rl_stamp = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
                            !(dev.rl_cnt = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
                            !(dev.rl_list = (int32_t*)be.alloc(sizeof(int32_t) * RL_TIES * (nn + 8))) ||
-                           !(dev.rl_val = (double*)be.alloc(sizeof(double) * (nn + 8))))) ||
+                           !(dev.rl_val = (double*)be.alloc(sizeof(double) * (nn + 8))) ||
+                           !(dev.rl_mail = (uint64_t*)be.alloc(sizeof(uint64_t) * RL_MAIL_WORDS)))) ||
             !(dev.grecv = (Cand*)be.alloc(sizeof(Cand) * GATHER_RECS * 64)) ||
             !(dev.st = (State*)be.alloc(sizeof(State))) ||
             !(dev.evlog = (Event*)be.alloc(sizeof(Event) * (nn + 8))) ||
@@ -134,7 +135,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.recs); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.wsend); be.free(dev.wrecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.rperm); be.free(dev.rl_stamp); be.free(dev.rl_cnt); be.free(dev.rl_list); be.free(dev.rl_val); be.free(dev.ticks); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.recs); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.wsend); be.free(dev.wrecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.rperm); be.free(dev.rl_stamp); be.free(dev.rl_cnt); be.free(dev.rl_list); be.free(dev.rl_val); be.free(dev.rl_mail); be.free(dev.ticks); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }
@@ -230,7 +231,8 @@ class Engine {
                     return fail(FNN_EHIP, "fnn_begin: upload failed (" + be.err() + ")");
             }
             hst.rl_rng = JavaRandom::scramble(((uint64_t)opts.relaxed_seed_hi << 32) | (uint64_t)opts.relaxed_seed_lo);
-            if (be.memset(dev.rl_stamp, 0, sizeof(int32_t) * ((size_t)(n > 0 ? n : 1) + 8)) != FNN_OK)
+            if (be.memset(dev.rl_stamp, 0, sizeof(int32_t) * ((size_t)(n > 0 ? n : 1) + 8)) != FNN_OK ||
+                be.memset(dev.rl_mail, 0, sizeof(uint64_t) * RL_MAIL_WORDS) != FNN_OK)
                 return fail(FNN_EHIP, "fnn_begin: memset failed (" + be.err() + ")");
         }
         // lookahead windows (fnn_core.h "Lookahead"): single rank with a screening copy

@@ -1631,6 +1631,8 @@ struct RlLds {
     double kval[RL_MINS];
     int32_t tkon;
     long long tk[4];           // diagnostics (FNN_TICKS=1): ticks in {row-minimum pass, its finish, the rest}, row minima
+    int32_t wg, nwg;           // this workgroup's share of the row pass: pair chunks wg, wg + nwg, ... (nwg = 1: all)
+    uint32_t seq, base;        // control workgroup: commands published so far, arrival counter at the start
 };
 
 // rl_q (fnn_core.h) without branches: the four entries are loaded whatever the kinds of p and q (the partner column
@@ -1663,16 +1665,18 @@ __device__ __forceinline__ void rl_rowmin_block(const Dev& d, RlLds& L) {
     // are three 16-byte loads; eight pairs per round, all 24 loads issued before the first value is used (left to
     // itself the compiler sinks the partner row's loads into the branch that needs them: two dependent round trips per
     // slot).  One round covers 16 384 slots; a round costs about one HBM latency (~4 us) whatever it loads.
+    // (several workgroups: chunks of RL_T pairs are dealt out round-robin, workgroup wg takes chunks wg, wg + nwg, ...)
     constexpr int RL_PAIRS = 8;
     const int32_t npairs = (m + 1) >> 1;
-    for (int32_t j0 = tid; j0 < npairs; j0 += RL_PAIRS * RL_T) {
+    const int32_t cstep = L.nwg * RL_T, cfirst = L.wg * RL_T;
+    for (int32_t j0 = cfirst + tid; j0 - tid < npairs; j0 += RL_PAIRS * cstep) {
         double2 A[RL_PAIRS], Cc[RL_PAIRS], S[RL_PAIRS];
-        const int32_t nu = (npairs - (j0 - tid) + RL_T - 1) / RL_T;  // (uniform: the pairs this round still has, in units of RL_T)
+        const int32_t nu = (npairs - (j0 - tid) + cstep - 1) / cstep;  // (uniform: the chunks this round still has)
 #pragma unroll
         for (int u = 0; u < RL_PAIRS; u++) {
             A[u] = Cc[u] = S[u] = make_double2(0.0, 0.0);
             if (u < nu) {
-                const int32_t j = j0 + u * RL_T, jj = j < npairs ? j : npairs - 1;
+                const int32_t j = j0 + u * cstep, jj = j < npairs ? j : npairs - 1;
                 A[u] = *reinterpret_cast<const double2*>(Rp + 2 * jj);
                 Cc[u] = *reinterpret_cast<const double2*>(Rn + 2 * jj);
                 S[u] = *reinterpret_cast<const double2*>(d.Sx + 2 * jj);
@@ -1681,7 +1685,7 @@ __device__ __forceinline__ void rl_rowmin_block(const Dev& d, RlLds& L) {
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int u = 0; u < RL_PAIRS; u++) {
-            const int32_t j = j0 + u * RL_T;
+            const int32_t j = j0 + u * cstep;
             if (j >= npairs) continue;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -1718,7 +1722,7 @@ __device__ __forceinline__ void rl_rowmin_block(const Dev& d, RlLds& L) {
             if (k < RL_TIES) { L.tpos[k] = d.spos[mslot]; L.tslot[k] = mslot; }
             if (mcnt == 2 && k + 1 < RL_TIES) { L.tpos[k + 1] = d.spos[mslot2]; L.tslot[k + 1] = mslot2; }
         } else {
-            for (int32_t j = tid; j < npairs; j += RL_T)  // this thread's own pairs again (same expression, same bits)
+            for (int32_t j = cfirst + tid; j < npairs; j += cstep)  // this thread's own pairs again (same expression, same bits)
                 for (int h = 0; h < 2; h++) {
                     const int32_t qs = 2 * j + h;
                     if (qs >= m || qs == ps || qs == pp) continue;
@@ -1732,6 +1736,35 @@ __device__ __forceinline__ void rl_rowmin_block(const Dev& d, RlLds& L) {
     }
     if (tid == 0) L.gmin = g;
     __syncthreads();
+}
+
+// Several workgroups on one row minimum (the row pass is bound by what ONE CU can stream, ~40 GB/s): the control
+// workgroup publishes the command as ONE 8-byte write-through store {event stamp | sequence number | slot of p}; a worker
+// workgroup polls that word past its L1, takes its share of the pair chunks, writes its record {minimum, count | sequence
+// number, (position | slot) of the rows that attain it} write-through, waits for the acknowledgement and counts its
+// arrival; the control wave polls the counter and reads the records past its L1.  (MI355X_MICROARCH.md "valid forms":
+// an 8-byte granule needs no ordering; every handed-off byte stored sc1 and drained before the counter, every load of
+// it sc1, by the wave whose poll matched.)  Every wait is bounded: a worker that never sees its command leaves, the
+// control wave then reports error 23 instead of hanging.
+constexpr uint32_t RL_EXIT = 0xFFFFFu;
+constexpr long RL_SPINS = 400000;   // (x ~1 us per poll)
+__device__ __forceinline__ uint64_t rl_cmd_word(uint32_t stamp, uint32_t seq, uint32_t ps) {
+    return ((uint64_t)(stamp & 0xFFFFFFu) << 40) | ((uint64_t)(seq & 0xFFFFFu) << 20) | (uint64_t)(ps & 0xFFFFFu);
+}
+__device__ __forceinline__ uint64_t ld_sc1(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint64_t* rl_rec(const Dev& d, int w) { return d.rl_mail + 32 + 32 * w; }
+
+// a worker workgroup's record of the row minimum it has just taken part in (thread 0, after rl_rowmin_block)
+__device__ __forceinline__ void rl_publish_part(const Dev& d, RlLds& L, uint32_t seq) {
+    uint64_t* r = rl_rec(d, L.wg);
+    int32_t cnt = L.tcnt;
+    if (cnt > RL_TIES) cnt = RL_TIES + 1;  // (more ties than a list holds: the control wave reports it)
+    st_sc1(r + 0, __builtin_bit_cast(uint64_t, L.gmin));
+    for (int i = 0; i < cnt && i < RL_TIES; i++) st_sc1(r + 2 + i, ((uint64_t)(uint32_t)L.tpos[i] << 32) | (uint64_t)(uint32_t)L.tslot[i]);
+    st_sc1(r + 1, ((uint64_t)(uint32_t)cnt << 32) | (uint64_t)seq);
+    __builtin_amdgcn_s_waitcnt(0);
+    atomicAdd(reinterpret_cast<uint32_t*>(d.rl_mail + 16), 1u);
 }
 
 struct RlBlockEnv {
@@ -1795,9 +1828,64 @@ struct RlBlockEnv {
     __device__ __forceinline__ RlRow rowmin(const Dev& d, int32_t ps, int32_t pp, int32_t stamp) {
         long long t0 = 0, t1 = 0;
         if (L.tkon) t0 = (long long)wall_clock64();
-        if (lane == 0) { L.cmd = 1; L.ps = ps; L.pp = pp; }
+        const int nwg = L.nwg;
+        const uint32_t seq = L.seq + 1u;
+        if (lane == 0) {
+            L.cmd = 1; L.ps = ps; L.pp = pp; L.seq = seq;
+            if (nwg > 1) st_sc1(d.rl_mail, rl_cmd_word((uint32_t)stamp, seq, (uint32_t)ps));  // the other workgroups' command
+        }
         __syncthreads();          // the other waves pick the command up
         rl_rowmin_block(d, L);
+        if (nwg > 1) {
+            // the other workgroups' records: wait for their arrivals, then lane w reads the head of workgroup w's record
+            int ok = 1;
+            if (lane == 0) {
+                const uint32_t want = L.base + (uint32_t)(nwg - 1) * seq;
+                long spins = 0;
+                while ((uint32_t)ld_sc1(d.rl_mail + 16) != want) {
+                    if (++spins > RL_SPINS) { ok = 0; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            ok = __builtin_amdgcn_readfirstlane(ok);
+            double v = 1.7976931348623157e308;
+            int32_t c = 0;
+            if (lane == 0) { v = L.gmin; c = L.tcnt > RL_TIES ? RL_TIES + 1 : L.tcnt; }
+            if (ok && lane >= 1 && lane < nwg) {
+                const uint64_t* r = rl_rec(d, lane);
+                const uint64_t head = ld_sc1(r + 1);
+                v = __builtin_bit_cast(double, ld_sc1(r + 0));
+                c = (int32_t)(head >> 32);
+                if ((uint32_t)head != seq) ok = 0;
+            }
+            ok = __ballot(!ok) ? 0 : 1;
+            double g = v;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double o = __shfl_xor(g, off, 64);
+                if (o < g) g = o;
+            }
+            // the merged list: this workgroup's own rows if they attain g, then the other workgroups' (any order: sorted below)
+            const unsigned long long has = __ballot(lane < nwg && c > 0 && v == g);
+            int32_t total = (has & 1ULL) ? __builtin_amdgcn_readfirstlane(c) : 0;
+            if (total > RL_TIES) total = RL_TIES + 1;
+            for (unsigned long long rest = has & ~1ULL; rest; rest &= rest - 1) {
+                const int w = (int)__builtin_ctzll(rest);
+                const int32_t cw = __builtin_amdgcn_readlane(c, w);
+                if (cw > RL_TIES || total + cw > RL_TIES) { total = RL_TIES + 1; break; }
+                if (lane < cw) {
+                    const uint64_t e = ld_sc1(rl_rec(d, w) + 2 + lane);
+                    L.tpos[total + lane] = (int32_t)(e >> 32);
+                    L.tslot[total + lane] = (int32_t)(uint32_t)e;
+                }
+                total += cw;
+            }
+            if (lane == 0) {
+                L.tcnt = total;
+                L.gmin = g;
+                if (!ok && !L.err) L.err = 23;
+            }
+        }
         if (L.tkon) t1 = (long long)wall_clock64();
         if (lane == 0) {
             int32_t cnt = L.tcnt;
@@ -1829,18 +1917,52 @@ __global__ __launch_bounds__(RL_T) void k_relaxed(Dev d, int ticks) {
     __shared__ RlLds L;
     State* st = d.st;
     const long long tstart = ticks ? (long long)wall_clock64() : 0;
-    // (uniform: every thread reads the same words; nothing writes to the control block before the end)
+    // (uniform over the whole grid: every thread reads the same words; the control workgroup writes to the control block
+    //  only after every other workgroup has arrived for the last row minimum, i.e. after they have all read it)
     const bool run = !st->done && st->rl_on && st->m > st->rl_min && st->m > 3 && !(st->m == 4 && st->c == 2);
+    const uint32_t stamp = (uint32_t)st->n_events + 1u;
     if (!run) {
-        if (threadIdx.x == 0) st->rl_active = 0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->rl_active = 0;
         return;
     }
-    if (threadIdx.x == 0) { L.err = 0; L.cmd = 0; L.tkon = ticks; L.tk[0] = L.tk[1] = L.tk[2] = L.tk[3] = 0; }
+    if (threadIdx.x == 0) {
+        L.err = 0; L.cmd = 0; L.tkon = blockIdx.x == 0 ? ticks : 0; L.tk[0] = L.tk[1] = L.tk[2] = L.tk[3] = 0;
+        L.wg = (int32_t)blockIdx.x; L.nwg = (int32_t)gridDim.x; L.seq = 0;
+        L.base = gridDim.x > 1 && blockIdx.x == 0 ? (uint32_t)ld_sc1(d.rl_mail + 16) : 0u;  // (nobody arrives before the first command)
+    }
     __syncthreads();
+    if (blockIdx.x != 0) {
+        // a worker workgroup: commands until the exit command
+        for (uint32_t seq = 1;; seq++) {
+            if (threadIdx.x == 0) {
+                long spins = 0;
+                uint64_t w;
+                for (;;) {
+                    w = ld_sc1(d.rl_mail);
+                    if ((uint32_t)(w >> 40) == (stamp & 0xFFFFFFu) && (uint32_t)((w >> 20) & 0xFFFFFu) == (seq & 0xFFFFFu)) break;
+                    if (++spins > 4 * RL_SPINS) { w = RL_EXIT; break; }  // (never seen: leave; the control wave reports it)
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const uint32_t ps = (uint32_t)(w & 0xFFFFFu);
+                L.cmd = ps == RL_EXIT ? 2 : 1;
+                L.ps = (int32_t)ps;
+                L.pp = (int32_t)ps < 2 * st->P ? (int32_t)(ps ^ 1u) : -1;
+            }
+            __syncthreads();
+            if (L.cmd == 2) break;
+            rl_rowmin_block(d, L);
+            if (threadIdx.x == 0) rl_publish_part(d, L, seq);
+        }
+        return;
+    }
     if (threadIdx.x < 64) {
         RlBlockEnv env{L, (int)threadIdx.x};
         const Cand out = relaxed_find(d, env);
-        if (threadIdx.x == 0) { d.recs[0] = out; L.cmd = 2; }
+        if (threadIdx.x == 0) {
+            d.recs[0] = out;
+            L.cmd = 2;
+            if (gridDim.x > 1) st_sc1(d.rl_mail, rl_cmd_word(stamp, L.seq + 1u, RL_EXIT));
+        }
         if (ticks && threadIdx.x == 0) {
             d.ticks[24] += L.tk[0]; d.ticks[25] += L.tk[1]; d.ticks[26] += (long long)wall_clock64() - tstart; d.ticks[27] += L.tk[3];
         }
@@ -2593,6 +2715,7 @@ struct HipBackend {
     // Hence min(2048, n / 4), not below 512; FNN_SCREEN_MIN_M overrides.
     int screen_min_m = 2048;
     bool screen_min_m_fixed = false;
+    int relaxed_grid = 0;  // workgroups of k_relaxed (FNN_RELAXED_GRID; 0 = by the number of live nodes)
     int relaxed_min = 0;   // > 0: Relaxed mode - events with more live nodes than this search (k_relaxed) instead of scanning
     void set_relaxed(int32_t min_active) { relaxed_min = min_active; }
     void set_problem_size(int32_t n) {
@@ -2689,6 +2812,7 @@ struct HipBackend {
         if (const char* e = std::getenv("FNN_EMIT_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) emit_grid = v; }
         if (const char* e = std::getenv("FNN_TRACK_GROUP")) { int v = std::atoi(e); if (v >= 2 && v <= 1024) track_group = v; }
         if (const char* e = std::getenv("FNN_TRACK_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 1024) track_grid = v; }
+        if (const char* e = std::getenv("FNN_RELAXED_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= RL_GMAX) relaxed_grid = v; }
         if (const char* e = std::getenv("FNN_SCREEN_MIN_M")) { int v = std::atoi(e); if (v >= 8) { screen_min_m = v; screen_min_m_fixed = true; } }
         opened = true;
         return FNN_OK;
@@ -2893,7 +3017,13 @@ struct HipBackend {
             // Relaxed mode: the search first; the scan returns at once if it found the pair (it runs when fewer
             // nodes are live than the bound the host knows, i.e. at the switch to the full scans)
             if (relaxed_min > 0 && m_bound > relaxed_min)
-                timed(TC_OTHER, tall, [&]() { hipLaunchKernelGGL(k_relaxed, dim3(1), dim3(RL_T), 0, stream, d, ticks ? 1 : 0); });
+                timed(TC_OTHER, tall, [&]() {
+                    // one workgroup streams ~40 GB/s: from ~12 000 live nodes on the row pass is spread over several
+                    // (a hand-over between workgroups costs ~3 us per row minimum)
+                    int g = relaxed_grid > 0 ? relaxed_grid : (m_bound >= 12288 ? m_bound / 4096 : 1);
+                    if (g > RL_GMAX) g = RL_GMAX;
+                    hipLaunchKernelGGL(k_relaxed, dim3(g), dim3(RL_T), 0, stream, d, ticks ? 1 : 0);
+                });
             timed(TC_SCAN, tscan, [&]() {
                 if (scan_nt) hipLaunchKernelGGL(k_scan<true>, gs, dim3(SCAN_THREADS), 0, stream, d);
                 else hipLaunchKernelGGL(k_scan<false>, gs, dim3(SCAN_THREADS), 0, stream, d);

@@ -135,6 +135,16 @@ def test_gpu_matches_oracle(hip_api, oracle, n, seed, dist, min_active):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("grid", [2, 3, 16])
+@pytest.mark.parametrize("n,seed,dist,min_active", [(257, 5, "dec4", 16), (2100, 6, "uniform53", 64), (3000, 8, "dec4", 0)])
+def test_gpu_row_pass_on_several_workgroups(hip_api, oracle, monkeypatch, grid, n, seed, dist, min_active):
+    """the row pass of a minimum spread over `grid` workgroups (the default from ~12 000 live nodes on): command word,
+    per-workgroup records, merged tie lists - same trajectory"""
+    monkeypatch.setenv("FNN_RELAXED_GRID", str(grid))
+    compare(hip_api, oracle, oracle.synth(n, seed, dist), 3000 + seed, min_active)
+
+
+@pytest.mark.gpu
 def test_gpu_relaxed_is_canonical_below_the_threshold(hip_api, oracle):
     D = oracle.synth(700, 2)
     with Handle(hip_api, 700, relaxed_seed=3) as h:

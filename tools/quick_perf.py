@@ -13,6 +13,13 @@ for n in sizes:
         t = time.time()
         order, st = h.run()
         dt = time.time() - t
+        if n <= 8192 and not os.environ.get("FNN_TICKS"):
+            # small problems: the first run of a process pays first-touch costs (~10 ms); bench.py times after a warm-up
+            # run, so print that figure as well
+            first = st.t_total_s
+            h.synth(1, "uniform53")
+            order, st = h.run()
+            print(f"n={n}: first run of the process {first:.3f}s, second run {st.t_total_s:.3f}s", flush=True)
         import ctypes as C
         tk = (C.c_int64 * 8)()
         a._fn("debug_event_ticks", C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)])
