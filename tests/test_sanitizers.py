@@ -59,6 +59,8 @@ def test_emulation_under_asan_ubsan(san_libs):
     # whole trajectories against the oracle in all thread orders (slot bookkeeping, windows, the block form of the
     # involved slots, the cached slot tables, T), the chain-sum model, two ranks' worth of exchange logic in-process
     _run(rt, {"FNN_EMU_LIB": emu}, ["tests/test_emu_parity.py", "tests/test_chain_sum.py", "-k", "not big"])
+    # the Relaxed mode's search (permutation, per-slot row-minimum cache, tie lists) against the oracle
+    _run(rt, {"FNN_EMU_LIB": emu}, ["tests/test_relaxed.py", "-m", "not gpu", "-k", "emulation or rejects"])
 
 
 def test_host_side_under_asan_ubsan(san_libs):
