@@ -145,6 +145,12 @@ def test_gpu_row_pass_on_several_workgroups(hip_api, oracle, monkeypatch, grid, 
 
 
 @pytest.mark.gpu
+def test_gpu_matches_oracle_at_13000_taxa_with_the_shipped_grid_rule(hip_api, oracle):
+    """from 12 288 live nodes on the row pass runs on m / 4096 workgroups by default: the first ~700 events of this run"""
+    compare(hip_api, oracle, oracle.synth(13000, 4), 9, 0)
+
+
+@pytest.mark.gpu
 def test_gpu_relaxed_is_canonical_below_the_threshold(hip_api, oracle):
     D = oracle.synth(700, 2)
     with Handle(hip_api, 700, relaxed_seed=3) as h:
