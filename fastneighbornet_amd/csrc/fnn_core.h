@@ -191,6 +191,7 @@ struct Dev {
     double* chain;   // 4 buffers of cstride doubles, addressed through chain_addr(position)
     int64_t cstride; // n rounded up to a whole super-chunk
     Cand* recs;      // per-block scan records
+    uint64_t* rchk;  // k_track's fan-in: a check word per record (2 x 1024), see rec_publish
     uint16_t* H;     // bf16 screening copy of D: H[r * ldh + c] == bf16(D[r][c]) (its own row stride, see fnn_create)
     int64_t ldh;
     float* srec;     // screening: per unit [tile][4] lower bounds, then [tile][4] upper bounds

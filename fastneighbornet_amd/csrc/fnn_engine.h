@@ -94,6 +94,7 @@ class Engine {
             !(dev.pslot = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
             !(dev.chain = (double*)be.alloc(sizeof(double) * 4 * (size_t)dev.cstride)) ||
             !(dev.recs = (Cand*)be.alloc(sizeof(Cand) * be.max_records(n))) ||
+            !(dev.rchk = (uint64_t*)be.alloc(sizeof(uint64_t) * 2048)) ||
             !(dev.T = (double*)be.alloc(sizeof(double) * (nn + 8))) ||
             !(dev.srec = (float*)be.alloc(sizeof(float) * (2 * (size_t)screen_unit_count(n > 0 ? n : 1) + 16))) ||
             !(dev.stile = (float*)be.alloc(sizeof(float) * (2 * (size_t)screen_unit_count(n > 0 ? n : 1) / 4 + 16))) ||
@@ -135,7 +136,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.recs); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.wsend); be.free(dev.wrecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.rperm); be.free(dev.rl_stamp); be.free(dev.rl_cnt); be.free(dev.rl_list); be.free(dev.rl_val); be.free(dev.rl_mail); be.free(dev.ticks); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.recs); be.free(dev.rchk); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.wsend); be.free(dev.wrecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.rperm); be.free(dev.rl_stamp); be.free(dev.rl_cnt); be.free(dev.rl_list); be.free(dev.rl_val); be.free(dev.rl_mail); be.free(dev.ticks); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }

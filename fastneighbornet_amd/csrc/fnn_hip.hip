@@ -55,7 +55,16 @@ constexpr int SCAN_THREADS = 256;
 // they leave the XCD's L2) by ONE lane, which then waits for their acknowledgement and counts its arrival; the reader
 // loads them past its L1 after its own arrival returned last.  No cache write-back or invalidate on the event chain.
 static_assert(sizeof(Cand) == 24, "rec_publish / rec_fetch move a Cand as three 8-byte words");
-__device__ inline void rec_publish(Cand* p, const Cand& c) {
+// The hand-over is checked: a fourth word, a function of the record's three words and of the event number, goes out
+// with them; the reader recomputes it.  A record that is stale or torn (not observed; the write-through form is measured
+// behaviour of this part, not an architectural promise) makes the reader fence and read again, and if that does not
+// help the window gives the event up (it scans) - slower, never wrong.
+__device__ inline uint64_t rec_check_word(const Cand& c, uint32_t tag) {
+    return __builtin_bit_cast(uint64_t, c.q) ^ (c.key * 0x9E3779B97F4A7C15ULL) ^
+           ((uint64_t)(uint32_t)c.si | ((uint64_t)(uint32_t)c.sj << 32)) ^ (((uint64_t)tag + 1ULL) * 0xBF58476D1CE4E5B9ULL);
+}
+__device__ inline void rec_publish(Cand* p, const Cand& c, uint64_t* chk, uint32_t tag) {
+    __hip_atomic_store(chk, rec_check_word(c, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint64_t* w = (uint64_t*)p;
     __hip_atomic_store(w + 0, __builtin_bit_cast(uint64_t, c.q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(w + 1, c.key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1756,13 +1765,29 @@ __device__ __forceinline__ void st_sc1(uint64_t* p, uint64_t v) { __hip_atomic_s
 __device__ __forceinline__ uint64_t* rl_rec(const Dev& d, int w) { return d.rl_mail + 32 + 32 * w; }
 
 // a worker workgroup's record of the row minimum it has just taken part in (thread 0, after rl_rowmin_block)
+// 16-bit digests that travel in a record's head word, so that a value or tie list that does not belong to this command
+// (not observed; see rec_publish) is reported instead of used
+__device__ __forceinline__ uint32_t rl_h16(uint64_t x) {
+    x *= 0x9E3779B97F4A7C15ULL;
+    return (uint32_t)(x >> 48);
+}
+__device__ __forceinline__ uint64_t rl_head(int32_t cnt, uint32_t seq, uint64_t vbits, uint64_t txor) {
+    return ((uint64_t)(uint32_t)(cnt & 0xFF) << 56) | ((uint64_t)(seq & 0xFFFFFFu) << 32) | ((uint64_t)rl_h16(txor + 1ULL) << 16) |
+           (uint64_t)rl_h16(vbits ^ ((uint64_t)seq << 1));
+}
 __device__ __forceinline__ void rl_publish_part(const Dev& d, RlLds& L, uint32_t seq) {
     uint64_t* r = rl_rec(d, L.wg);
     int32_t cnt = L.tcnt;
     if (cnt > RL_TIES) cnt = RL_TIES + 1;  // (more ties than a list holds: the control wave reports it)
-    st_sc1(r + 0, __builtin_bit_cast(uint64_t, L.gmin));
-    for (int i = 0; i < cnt && i < RL_TIES; i++) st_sc1(r + 2 + i, ((uint64_t)(uint32_t)L.tpos[i] << 32) | (uint64_t)(uint32_t)L.tslot[i]);
-    st_sc1(r + 1, ((uint64_t)(uint32_t)cnt << 32) | (uint64_t)seq);
+    const uint64_t vbits = __builtin_bit_cast(uint64_t, L.gmin);
+    st_sc1(r + 0, vbits);
+    uint64_t txor = 0;
+    for (int i = 0; i < cnt && i < RL_TIES; i++) {
+        const uint64_t e = ((uint64_t)(uint32_t)L.tpos[i] << 32) | (uint64_t)(uint32_t)L.tslot[i];
+        txor ^= e * (uint64_t)(2 * i + 3);
+        st_sc1(r + 2 + i, e);
+    }
+    st_sc1(r + 1, rl_head(cnt, seq, vbits, txor));
     __builtin_amdgcn_s_waitcnt(0);
     atomicAdd(reinterpret_cast<uint32_t*>(d.rl_mail + 16), 1u);
 }
@@ -1850,13 +1875,16 @@ struct RlBlockEnv {
             ok = __builtin_amdgcn_readfirstlane(ok);
             double v = 1.7976931348623157e308;
             int32_t c = 0;
+            uint32_t th = 0;  // digest of the record's tie list
             if (lane == 0) { v = L.gmin; c = L.tcnt > RL_TIES ? RL_TIES + 1 : L.tcnt; }
             if (ok && lane >= 1 && lane < nwg) {
                 const uint64_t* r = rl_rec(d, lane);
                 const uint64_t head = ld_sc1(r + 1);
-                v = __builtin_bit_cast(double, ld_sc1(r + 0));
-                c = (int32_t)(head >> 32);
-                if ((uint32_t)head != seq) ok = 0;
+                const uint64_t vbits = ld_sc1(r + 0);
+                v = __builtin_bit_cast(double, vbits);
+                c = (int32_t)(head >> 56);
+                th = (uint32_t)(head >> 16) & 0xFFFFu;
+                if ((uint32_t)((head >> 32) & 0xFFFFFFu) != (seq & 0xFFFFFFu) || ((uint32_t)head & 0xFFFFu) != rl_h16(vbits ^ ((uint64_t)seq << 1))) ok = 0;
             }
             ok = __ballot(!ok) ? 0 : 1;
             double g = v;
@@ -1873,11 +1901,16 @@ struct RlBlockEnv {
                 const int w = (int)__builtin_ctzll(rest);
                 const int32_t cw = __builtin_amdgcn_readlane(c, w);
                 if (cw > RL_TIES || total + cw > RL_TIES) { total = RL_TIES + 1; break; }
+                uint64_t e = 0;
                 if (lane < cw) {
-                    const uint64_t e = ld_sc1(rl_rec(d, w) + 2 + lane);
+                    e = ld_sc1(rl_rec(d, w) + 2 + lane);
                     L.tpos[total + lane] = (int32_t)(e >> 32);
                     L.tslot[total + lane] = (int32_t)(uint32_t)e;
+                    e *= (uint64_t)(2 * lane + 3);
                 }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) e ^= (uint64_t)__shfl_xor((unsigned long long)e, off, 64);
+                if (rl_h16(e + 1ULL) != (uint32_t)__builtin_amdgcn_readlane((int)th, w)) ok = 0;
                 total += cw;
             }
             if (lane == 0) {
@@ -2159,8 +2192,8 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
             best = wave_reduce(b2);
             if (ta.approx) bestu = wave_reduce(bu2);
             if (lane_ == 0) {
-                rec_publish(&d.recs[wg], best);
-                if (ta.approx) rec_publish(&d.recs[TRK_REC_U + wg], bestu);
+                rec_publish(&d.recs[wg], best, d.rchk + wg, (uint32_t)st->n_events);
+                if (ta.approx) rec_publish(&d.recs[TRK_REC_U + wg], bestu, d.rchk + TRK_REC_U + wg, (uint32_t)st->n_events);
             }
         }
     }
@@ -2194,13 +2227,25 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         b = cand_none();
         bu = b;
         const unsigned badword = __hip_atomic_load(d.ticket + TRK_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int i = threadIdx.x; i < G; i += 64) {
-            Cand c = rec_fetch(&d.recs[i]);
-            if (cand_better(c, b)) b = c;
-            if (ta.approx) {
-                c = rec_fetch(&d.recs[TRK_REC_U + i]);
-                if (cand_better(c, bu)) bu = c;
+        const uint32_t tag = (uint32_t)st->n_events;
+        bool stale = false;
+        for (int pass = 0; pass < 2; pass++) {
+            b = cand_none();
+            bu = b;
+            stale = false;
+            for (int i = threadIdx.x; i < G; i += 64) {
+                Cand c = rec_fetch(&d.recs[i]);
+                if (rec_check_word(c, tag) != __hip_atomic_load(d.rchk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) stale = true;
+                if (cand_better(c, b)) b = c;
+                if (ta.approx) {
+                    c = rec_fetch(&d.recs[TRK_REC_U + i]);
+                    if (rec_check_word(c, tag) != __hip_atomic_load(d.rchk + TRK_REC_U + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) stale = true;
+                    if (cand_better(c, bu)) bu = c;
+                }
             }
+            stale = __ballot(stale) != 0ULL;
+            if (!stale) break;
+            __threadfence();  // (not expected: see rec_publish)
         }
         b = wave_reduce(b);
         if (ta.approx) bu = wave_reduce(bu);
@@ -2211,6 +2256,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
                 d.ticket[TRK_BAD] = 0u;
                 lastflag = 2;
             }
+            if (stale) lastflag = 2;  // (a record that could not be read back intact: the window gives this event up)
         }
     }
     __syncthreads();
