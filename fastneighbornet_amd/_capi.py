@@ -42,7 +42,7 @@ class FnnStats(C.Structure):
                 ("n_rx_certified", C.c_int64), ("n_rx_exact", C.c_int64), ("n_screen_events", C.c_int64),
                 ("n_rescan_units", C.c_int64), ("n_base_scans", C.c_int64), ("n_window_hits", C.c_int64),
                 ("n_window_fails", C.c_int64), ("window_pairs", C.c_int64), ("bytes_total", C.c_int64),
-                ("n_events_persistent", C.c_int64), ("n_sweeps_exact", C.c_int64), ("t_plain_s", C.c_double),
+                ("n_handover_retries", C.c_int64), ("n_sweeps_exact", C.c_int64), ("t_plain_s", C.c_double),
                 ("plain_launches", C.c_int64), ("plain_bytes", C.c_int64), ("n_stalled_events", C.c_int64),
                 ("n_relaxed_events", C.c_int64)]
 

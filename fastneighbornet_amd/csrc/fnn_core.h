@@ -139,7 +139,7 @@ struct State {
     int32_t ev_timed, la_k_prev;  // the host brackets this event's scan launch with HIP events
     int64_t bytes_timed;      // the part of bytes_streamed that belongs to timed screening launches (k_screen + rescans)
     int64_t bytes_plain;      // ... and to the plain fp64 scans (k_scan; always timed)
-    int64_t n_ev_persistent;  // (unused; was: events completed inside round 1's persistent event kernel)
+    int64_t n_ev_persistent;  // k_track's fan-in: events whose records had to be read a second time (check word mismatch; expected 0)
     int64_t n_su_exact;       // ... of which the sweep had to wait for the exact row sum of the new cluster
     // deferred row sum of the newest cluster: k_update closes the event, the exact sequential sum is
     // computed by a workgroup of the NEXT event's k_track (or by k_chain_flush before the host looks)

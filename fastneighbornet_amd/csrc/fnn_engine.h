@@ -478,7 +478,7 @@ class Engine {
         stats.n_window_hits = hst.n_la_hits;
         stats.n_window_fails = hst.n_la_fail;
         stats.window_pairs = hst.la_pairs_sum;
-        stats.n_events_persistent = 0;  // (the persistent event kernel of round 1 is gone; field kept for ABI stability)
+        stats.n_handover_retries = hst.n_ev_persistent;
         stats.n_sweeps_exact = hst.n_su_exact + hst.n_sweep_waits;
         stats.n_stalled_events = hst.n_stalled;
         stats.n_relaxed_events = hst.n_rl_events;

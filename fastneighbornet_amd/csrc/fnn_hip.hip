@@ -2228,7 +2228,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         bu = b;
         const unsigned badword = __hip_atomic_load(d.ticket + TRK_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t tag = (uint32_t)st->n_events;
-        bool stale = false;
+        bool stale = false, reread = false;
         for (int pass = 0; pass < 2; pass++) {
             b = cand_none();
             bu = b;
@@ -2245,6 +2245,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
             }
             stale = __ballot(stale) != 0ULL;
             if (!stale) break;
+            reread = true;
             __threadfence();  // (not expected: see rec_publish)
         }
         b = wave_reduce(b);
@@ -2257,6 +2258,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
                 lastflag = 2;
             }
             if (stale) lastflag = 2;  // (a record that could not be read back intact: the window gives this event up)
+            if (reread) S.lst.n_ev_persistent++;
         }
     }
     __syncthreads();

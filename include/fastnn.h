@@ -112,7 +112,9 @@ typedef struct fnn_stats {
     int64_t n_window_fails;  /* events whose window could not certify the minimum (they rescanned) */
     int64_t window_pairs;    /* tracked pairs summed over all windows */
     int64_t bytes_total;     /* matrix bytes read by ALL scan work of the run (timed or not, window items too) */
-    int64_t n_events_persistent; /* always 0 (round 1's experimental persistent event kernel was removed; kept for layout) */
+    int64_t n_handover_retries; /* window events whose per-workgroup records failed their check word on the first read
+                                (the hand-over inside k_track is checked: fence + second read, then the event scans);
+                                expected 0 */
     int64_t n_sweeps_exact;  /* ... whose sweep of the newest cluster's rows had to wait for its exact row sum */
     double  t_plain_s;       /* sum of the durations of the plain fp64 scan launches (k_scan; m below the screening threshold) */
     int64_t plain_launches;  /* number of those launches */

@@ -86,3 +86,6 @@ def test_default_mode_matches_oracle_golden(hip_api, n, dist, seed):
     assert hashlib.sha256(best.tobytes()).hexdigest() == c["best_bits_sha256"]
     if n >= 4096:
         assert st.n_base_scans > 0 and st.n_window_hits > 0, "the shipped mode (lookahead windows) did not run"
+        if st.n_handover_retries:  # (results are right either way - the trajectory was compared above; worth knowing)
+            import warnings
+            warnings.warn(f"{st.n_handover_retries} window events reread the records of k_track's fan-in (DESIGN.md section 3)")

@@ -46,4 +46,4 @@ for n in sizes:
               f"rescan_units_per_event={st.n_rescan_units / max(st.n_screen_events, 1):.1f} "
               f"base_scans={st.n_base_scans} window_hits={st.n_window_hits} window_fails={st.n_window_fails} "
               f"pairs_per_window={st.window_pairs / max(st.n_base_scans, 1):.0f} bytes_total={st.bytes_total / 1e12:.3f}TB "
-              f"timed_launches={st.scan_launches} timed_screen_bytes={st.scan_bytes} plain_launches={st.plain_launches} exact_sweeps={st.n_sweeps_exact} stalled={st.n_stalled_events}", flush=True)
+              f"timed_launches={st.scan_launches} timed_screen_bytes={st.scan_bytes} plain_launches={st.plain_launches} exact_sweeps={st.n_sweeps_exact} stalled={st.n_stalled_events} handover_retries={st.n_handover_retries}", flush=True)
