@@ -1115,6 +1115,14 @@ __device__ __forceinline__ ChRec chain_record_wave(double al, int cnt, double A0
     return r;
 }
 
+// The rare paths (a mispredicted binade in the record form; an uncertified 4-candidate choice) call the first form
+// out of line: inlined, its 32 addends per thread are part of the register allocation of k_track's tail.
+template <int EPT>
+__device__ __attribute__((noinline)) double block_chain_sum_rare(const double* __restrict__ buf, int m, int guard_bits, ChainLds<EPT>* L,
+                                                               ChainStats* stats) {
+    return block_chain_sum<EPT>(buf, m, guard_bits, *L, stats);
+}
+
 template <int EPT>
 __device__ __forceinline__ double block_chain_sum2(const double* __restrict__ buf, int m, int guard_bits, ChainLds<EPT>& L,
                                                    ChainStats* stats) {
@@ -1279,7 +1287,7 @@ __device__ __forceinline__ double block_chain_sum2(const double* __restrict__ bu
     __syncthreads();
     if (L.fail) {  // (rare: a mispredicted binade; the first form redoes the whole sum with its own fallbacks)
         ChainStats c1{0, 0, 0, 0};
-        const double r1 = block_chain_sum<EPT>(buf, m, guard_bits, L, stats ? &c1 : nullptr);
+        const double r1 = block_chain_sum_rare<EPT>(buf, m, guard_bits, &L, stats ? &c1 : nullptr);
         if (stats && tid == 0) { stats->runs = cs.runs + c1.runs; stats->mixed = cs.mixed + c1.mixed; stats->run_fail = 1 + c1.run_fail; stats->thread_fail = c1.thread_fail; }
         return r1;
     }
@@ -1599,7 +1607,7 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             double r = 0.0;
-            if (z[b] >= 0) r = block_chain_sum<CH_EPT>(d.chain + (size_t)b * d.cstride, m_old, CH_GUARD_BITS, L, nullptr);
+            if (z[b] >= 0) r = block_chain_sum_rare<CH_EPT>(d.chain + (size_t)b * d.cstride, m_old, CH_GUARD_BITS, &L, nullptr);
             if (tid == 0) S.rx[b] = r;
             __syncthreads();
         }
