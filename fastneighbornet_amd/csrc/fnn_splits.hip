@@ -29,11 +29,13 @@
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -327,64 +329,198 @@ __global__ __launch_bounds__(T) void k_to_live(const double* x, double* live, in
     live[k] = v;
 }
 
-// ---------------------------------------------------------------- "from below": Lawson-Hanson on the normal equations
+// ---------------------------------------------------------------- "from below": block active-set method on the normal equations
 // The reference's method starts from the unconstrained optimum (every split free) and contracts; on distances that are
-// far from circular (random matrices: only ~2 n of the n(n-1)/2 splits end up with a positive weight) almost all of its
+// far from circular (random matrices: only ~2.4 n of the n(n-1)/2 splits end up with a positive weight) almost all of its
 // work is conjugate-gradient iterations on huge, ill-conditioned free sets.  Lawson & Hanson's active-set method - what the
 // reference's LIVE path runs (edu.rit.numeric.NonNegativeLeastSquares, FastNN.java:401-454) - grows the free set F from
-// nothing, one split at a time, and solves each sub-problem exactly; here F's normal equations H_FF z = c_F are dense
-// (|F| ~ 2 n) with a Cholesky factor that is extended in place, and the only O(n^2) work per step is the gradient
-// A^T (d - A x) by the same prefix-sum operators.  H has a closed form: the number of position pairs that two circular
-// splits S, T both separate is |S n T| |S^c n T^c| + |S n T^c| |S^c n T|.
+// nothing and solves each sub-problem exactly.  Round 2 let ONE split enter per step (4.2 n steps, level-2 work and six
+// host round trips each: 2-3.5 h at 32768 taxa).  Here whole BLOCKS enter and leave:
+//   * candidates are the local maxima of the multiplier w = A^T (d - A x) on the (i, j) grid (w is smooth there: the
+//     largest values sit in clusters of nearly identical splits, of which at most one survives), the largest ~10 % |F| of them;
+//   * the free set's normal equations H_FF = L L^T are held as W = L^-1 (lower triangular): a block that enters appends
+//     rows to W and never touches existing entries (two triangular GEMMs, one small Cholesky) - numerically benign, unlike
+//     the explicitly updated inverse of round 2, whose errors compound per update;
+//   * a split that leaves is not eliminated but CONSTRAINED to zero: with Y = W[:, R] the columns of the splits R that
+//     left, the sub-problem's solution is x = W^T (z - Y (Y^T Y)^-1 Y^T z), z = W c - a projection, exact and stable;
+//     when R exceeds ~15 % of the factor the factor is rebuilt from H's closed form (Cholesky + triangular inverse);
+//   * all splits with a negative weight leave at once; the step is kept only if the objective -c_F.x_F/2 fell, otherwise
+//     the block is taken back (the appended rows are simply dropped), shrunk, and at a single split the Lawson-Hanson
+//     ratio step - whose descent is guaranteed - takes over.
+// H has a closed form: the number of position pairs that two circular splits S, T both separate is
+// |S n T| |S^c n T^c| + |S n T^c| |S^c n T|.
 __device__ __forceinline__ double h_entry(int n, int i, int j, int k, int l) {  // splits (i,j), (k,l): positions {i+1..j}, {k+1..l}
     const int lo = i > k ? i : k, hi = j < l ? j : l;
     const double st = hi > lo ? (double)(hi - lo) : 0.0, s = (double)(j - i), t = (double)(l - k);
     return st * ((double)n - s - t + st) + (s - st) * (t - st);
 }
-// the whole symmetric H_FF (F = list of splits), column-major, for a fresh inverse
-__global__ __launch_bounds__(T) void k_hfill(const int2* F, int f, int n, double* G, int64_t ldg) {
-    const int r = blockIdx.x * T + threadIdx.x, c = blockIdx.y;
-    if (r >= f) return;
-    G[(int64_t)c * ldg + r] = h_entry(n, F[r].x, F[r].y, F[c].x, F[c].y);
-}
-// h[p] = H[F[p], F[f]] for p <= f (the new split is the last of the list)
-__global__ __launch_bounds__(T) void k_hcol(const int2* F, int f, int n, double* h) {
-    const int p = blockIdx.x * T + threadIdx.x;
-    if (p > f) return;
-    h[p] = h_entry(n, F[p].x, F[p].y, F[f].x, F[f].y);
-}
-// the inverse of the bordered matrix: new row / column f = -s u, corner s (the leading block got + s u u^T by dger)
-__global__ __launch_bounds__(T) void k_border(double* G, int64_t ldg, int f, const double* u, double s_) {
-    const int p = blockIdx.x * T + threadIdx.x;
-    if (p < f) { const double v = -s_ * u[p]; G[(int64_t)f * ldg + p] = v; G[(int64_t)p * ldg + f] = v; }
-    else if (p == f) G[(int64_t)f * ldg + f] = s_;
-}
-// exchange rows / columns p and q (p < q) of the symmetric G (leading f x f block)
-__global__ __launch_bounds__(T) void k_swap_rc(double* G, int64_t ldg, int f, int p, int q) {
-    const int i = blockIdx.x * T + threadIdx.x;
-    if (i >= f) return;
-    if (i != p && i != q) {
-        const double a = G[(int64_t)p * ldg + i], b = G[(int64_t)q * ldg + i];
-        G[(int64_t)p * ldg + i] = b; G[(int64_t)q * ldg + i] = a;
-        G[(int64_t)i * ldg + p] = b; G[(int64_t)i * ldg + q] = a;
-    } else if (i == p) {
-        const double a = G[(int64_t)p * ldg + p], b = G[(int64_t)q * ldg + q];
-        G[(int64_t)p * ldg + p] = b; G[(int64_t)q * ldg + q] = a;  // (G[p][q] = G[q][p] stays)
+// out[r + c ldo] = H[Fa[r], Fb[c]] (column-major); lower_only: entries above the diagonal are written as zeros
+__global__ __launch_bounds__(T) void k_hblock(const int2* Fa, int64_t fa, const int2* Fb, int64_t fb, int n, double* out, int64_t ldo,
+                                              int lower_only) {
+    const int64_t r = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (r >= fa) return;
+    const int2 a = Fa[r];
+    for (int64_t c = blockIdx.y; c < fb; c += gridDim.y) {
+        const int2 b = Fb[c];
+        out[c * ldo + r] = (lower_only && r < c) ? 0.0 : h_entry(n, a.x, a.y, b.x, b.y);
     }
 }
-// copy the lower triangle of the leading f x f block onto the upper one (after potri)
-__global__ __launch_bounds__(T) void k_symmetrize(double* G, int64_t ldg, int f) {
-    const int r = blockIdx.x * T + threadIdx.x, c = blockIdx.y;
-    if (r >= f || c >= r) return;
-    G[(int64_t)r * ldg + c] = G[(int64_t)c * ldg + r];
-}
-__global__ __launch_bounds__(T) void k_gather(const int2* F, int f, const double* grid, int64_t ld, double* out) {
-    const int p = blockIdx.x * T + threadIdx.x;
+__global__ __launch_bounds__(T) void k_gather(const int2* F, int64_t f, const double* grid, int64_t ld, double* out) {
+    const int64_t p = (int64_t)blockIdx.x * T + threadIdx.x;
     if (p < f) out[p] = grid[(int64_t)F[p].x * ld + F[p].y];
 }
-__global__ __launch_bounds__(T) void k_scatter(const int2* F, int f, const double* v, double* grid, uint8_t* mask, int64_t ld) {
-    const int p = blockIdx.x * T + threadIdx.x;
-    if (p < f) { const int64_t k = (int64_t)F[p].x * ld + F[p].y; grid[k] = v[p]; mask[k] = 1; }
+__global__ __launch_bounds__(T) void k_scatter(const int2* F, int64_t f, const double* v, double* grid, int64_t ld) {
+    const int64_t p = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (p < f) grid[(int64_t)F[p].x * ld + F[p].y] = v[p];
+}
+__global__ __launch_bounds__(T) void k_mask(const int2* F, int64_t f, uint8_t* mask, int64_t ld, uint8_t v) {
+    const int64_t p = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (p < f) mask[(int64_t)F[p].x * ld + F[p].y] = v;
+}
+// Y[:, q] = W[0:f, list[q]] (columns of the splits that left)
+__global__ __launch_bounds__(T) void k_gather_cols(const double* W, int64_t ldw, int64_t f, const int32_t* list, int64_t cnt, double* Y, int64_t ldy) {
+    const int64_t r = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (r >= f) return;
+    for (int64_t q = blockIdx.y; q < cnt; q += gridDim.y) Y[q * ldy + r] = W[(int64_t)list[q] * ldw + r];
+}
+// Y[f0 + i, q] = W[f0 + i, list[q]], i < k (the appended rows of the columns that left)
+__global__ __launch_bounds__(T) void k_gather_rows(const double* W, int64_t ldw, int64_t f0, int64_t k, const int32_t* list, int64_t cnt, double* Y,
+                                                   int64_t ldy) {
+    const int64_t i = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (i >= k) return;
+    for (int64_t q = blockIdx.y; q < cnt; q += gridDim.y) Y[q * ldy + f0 + i] = W[(int64_t)list[q] * ldw + f0 + i];
+}
+// copy the lower triangle of a (m x m, lda) into b (ldb), zeros above the diagonal
+__global__ __launch_bounds__(T) void k_copy_lower(const double* a, int64_t lda, double* b, int64_t ldb, int64_t m) {
+    const int64_t r = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (r >= m) return;
+    for (int64_t c = blockIdx.y; c < m; c += gridDim.y) b[c * ldb + r] = r >= c ? a[c * lda + r] : 0.0;
+}
+// in-place inverse of lower-triangular m x m blocks (m <= 64), one workgroup per block (block b at A + b stride): thread t
+// solves column t by forward substitution on an LDS copy
+constexpr int TRI_NB = 64;
+__global__ __launch_bounds__(TRI_NB) void k_trinv_small(double* A, int64_t ld, int m, int64_t stride) {
+    __shared__ double L[TRI_NB][TRI_NB + 1];
+    __shared__ double X[TRI_NB][TRI_NB + 1];
+    double* a = A + (int64_t)blockIdx.x * stride;
+    const int t = threadIdx.x;
+    for (int c = 0; c < m; c++)
+        if (t < m) L[t][c] = t >= c ? a[(int64_t)c * ld + t] : 0.0;
+    __syncthreads();
+    if (t < m) {
+        for (int i = 0; i < m; i++) {
+            double v = 0.0;
+            if (i >= t) {
+                double acc = i == t ? 1.0 : 0.0;
+                for (int l = t; l < i; l++) acc -= L[i][l] * X[l][t];
+                v = acc / L[i][i];
+            }
+            X[i][t] = v;
+        }
+    }
+    __syncthreads();
+    for (int c = 0; c < m; c++)
+        if (t < m) a[(int64_t)c * ld + t] = X[t][c];
+}
+// local maxima of the multiplier on the (i, j) grid: entry (i, j), i < j, not masked, w > tol, and no unmasked neighbour
+// within `rad` (Chebyshev) is larger in the order (w, index).  Winners are appended to the candidate list.
+__global__ __launch_bounds__(T) void k_candidates(const double* w, const uint8_t* mask, int n, int64_t ld, double tol, int rad,
+                                                  double* key, int64_t* idx, unsigned long long* count, unsigned long long capacity) {
+    const int j = blockIdx.x * T + threadIdx.x, i = blockIdx.y;
+    bool win = false;
+    int64_t k = 0;
+    double v = 0.0;
+    if (j < n && i < j) {
+        k = (int64_t)i * ld + j;
+        v = w[k];
+        if (!mask[k] && v > tol) {
+            win = true;
+            for (int di = -rad; di <= rad && win; di++) {
+                const int ii = i + di;
+                if (ii < 0 || ii >= n) continue;
+                for (int dj = -rad; dj <= rad; dj++) {
+                    const int jj = j + dj;
+                    if ((di == 0 && dj == 0) || jj <= ii || jj >= n) continue;
+                    const int64_t kk = (int64_t)ii * ld + jj;
+                    const double u = w[kk];
+                    if (!mask[kk] && (u > v || (u == v && kk < k))) { win = false; break; }
+                }
+            }
+        }
+    }
+    const unsigned long long ball = __ballot(win);
+    if (ball == 0) return;
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (lane == __ffsll((long long)ball) - 1) base = atomicAdd(count, (unsigned long long)__popcll(ball));
+    base = __shfl(base, __ffsll((long long)ball) - 1, 64);
+    if (win) {
+        const unsigned long long at = base + __popcll(ball & ((1ULL << lane) - 1ULL));
+        if (at < capacity) { key[at] = v; idx[at] = k; }
+    }
+}
+// C (m x nn, ldc) = beta C + alpha * sum over the `parts` partial products at P + q * stride (each m x nn, ld m)
+__global__ __launch_bounds__(T) void k_sum_parts(const double* P, int64_t stride, int parts, int64_t m, int64_t nn, double alpha, double beta, double* C,
+                                                 int64_t ldc) {
+    const int64_t r = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (r >= m) return;
+    for (int64_t c = blockIdx.y; c < nn; c += gridDim.y) {
+        double acc = 0.0;
+        for (int q = 0; q < parts; q++) acc += P[(int64_t)q * stride + c * m + r];
+        C[c * ldc + r] = (beta == 0.0 ? 0.0 : beta * C[c * ldc + r]) + alpha * acc;
+    }
+}
+// A block of at most SMALLK columns: out (f x k) = Wl (lower triangular) * Bm, Wl read once.  One thread per row, a
+// workgroup per 256 rows and column chunk; partial sums per chunk, added up in chunk order by k_sum_parts.
+constexpr int SMALLK = 8;
+constexpr int SK_CHUNK = 2048;
+__global__ __launch_bounds__(T) void k_tri_times_small(const double* Wl, int64_t ldw, int64_t f, const double* Bm, int64_t ldb, int k, double* part) {
+    const int64_t row = (int64_t)blockIdx.x * T + threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.y * SK_CHUNK;
+    if ((int64_t)blockIdx.x * T + T - 1 < c0) return;  // the whole row block lies above the diagonal of this chunk: zeros (the buffer is cleared)
+    double acc[SMALLK];
+#pragma unroll
+    for (int a = 0; a < SMALLK; a++) acc[a] = 0.0;
+    if (row < f) {
+        int64_t c1 = c0 + SK_CHUNK < f ? c0 + SK_CHUNK : f;
+        if (row + 1 < c1) c1 = row + 1;
+        for (int64_t c = c0; c < c1; c++) {
+            const double w = Wl[c * ldw + row];
+#pragma unroll
+            for (int a = 0; a < SMALLK; a++)
+                if (a < k) acc[a] += w * Bm[(int64_t)a * ldb + c];
+        }
+#pragma unroll
+        for (int a = 0; a < SMALLK; a++)
+            if (a < k) part[((int64_t)blockIdx.y * k + a) * f + row] = acc[a];
+    }
+}
+// out (k x f, ldo) = Tm^T (f x k) * Wl (lower triangular): one workgroup per column of Wl, Wl read once
+__global__ __launch_bounds__(T) void k_t_times_tri_small(const double* Tm, int64_t ldt, int k, const double* Wl, int64_t ldw, int64_t f, double* out, int64_t ldo) {
+    __shared__ double sh[T / 64][SMALLK];
+    const int64_t j = blockIdx.x;
+    double acc[SMALLK];
+#pragma unroll
+    for (int a = 0; a < SMALLK; a++) acc[a] = 0.0;
+    for (int64_t l = j + threadIdx.x; l < f; l += T) {
+        const double w = Wl[j * ldw + l];
+#pragma unroll
+        for (int a = 0; a < SMALLK; a++)
+            if (a < k) acc[a] += w * Tm[(int64_t)a * ldt + l];
+    }
+#pragma unroll
+    for (int a = 0; a < SMALLK; a++) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc[a] += __shfl_down(acc[a], off, 64);
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int a = 0; a < SMALLK; a++) sh[threadIdx.x >> 6][a] = acc[a];
+    __syncthreads();
+    if (threadIdx.x < k) out[j * ldo + threadIdx.x] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+}
+__global__ __launch_bounds__(T) void k_idx_to_split(const int64_t* idx, int64_t cnt, int64_t ld, int2* out) {
+    const int64_t p = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (p < cnt) out[p] = make_int2((int)(idx[p] / ld), (int)(idx[p] % ld));
 }
 
 // ---------------------------------------------------------------- host driver
@@ -408,6 +544,13 @@ struct Solver {
         if (!SWOK(hipMalloc(&p_, sizeof(Tp) * (count ? count : 1)))) { ok = false; return nullptr; }
         allocs.push_back(p_);
         return (Tp*)p_;
+    }
+    size_t block_mark = SIZE_MAX;  // allocs[block_mark ..) belong to the block active-set method
+    void release_block_buffers() {
+        (void)hipStreamSynchronize(s);
+        if (block_mark == SIZE_MAX) return;
+        while (allocs.size() > block_mark) { (void)hipFree(allocs.back()); allocs.pop_back(); }
+        ok = true;
     }
     ~Solver() {
         for (void* p_ : allocs) (void)hipFree(p_);
@@ -529,194 +672,500 @@ struct Solver {
         return true;
     }
 
-    // Lawson-Hanson with the explicit inverse G = H_FF^-1 of the free set's normal equations, kept current by rank-one
-    // updates: a split that enters borders G (one matrix-vector product, one rank-one update), a split that leaves is
-    // swapped to the end and eliminated by the Schur complement of its diagonal entry (one rank-one update), the
-    // sub-problem's solution is one more matrix-vector product - every step is O(|F|^2) of fully parallel, bandwidth-bound
-    // work (a Cholesky factor would need sequential triangular solves and a fresh factorisation after every removal:
-    // measured 10 x slower at 2048 taxa).  Rounding drift of the updates is watched through the gradient on F, which
-    // the next step computes anyway: beyond 1e-9 (relative) G is rebuilt from H_FF's closed form (potrf + potri); the last
-    // step always ends on a freshly built inverse.  Returns false if the free set outgrows its capacity (distances close
-    // to a circular metric with many positive splits): the caller then runs the reference's method, from the other end.
-    int64_t st_lh_steps = 0, st_lh_refactor = 0;
-    bool lawson_hanson() {
-        const int64_t N = (int64_t)n * (n - 1) / 2;
-        const int64_t cap = std::min<int64_t>(N, std::max<int64_t>(8 * (int64_t)n + 64, 256));
+    // ------------------------------------------------------------ block active-set method (see the comment above h_entry)
+    int64_t st_lh_steps = 0, st_lh_refactor = 0, st_solves = 0, st_adds = 0, st_dels = 0, st_rejects = 0, st_ratio_steps = 0;
+    double t_ops = 0, t_sel = 0, t_append = 0, t_solve = 0, t_dead = 0, t_refactor = 0;  // host wall clock per phase (FNN_SW_LOG)
+    struct Blk {
         rocblas_handle bh = nullptr;
-        if (rocblas_create_handle(&bh) != rocblas_status_success) return false;
-        rocblas_set_stream(bh, s);
-        rocblas_set_pointer_mode(bh, rocblas_pointer_mode_host);
-        double* G = alloc<double>((size_t)cap * (size_t)cap);
-        int2* dF = alloc<int2>((size_t)cap);
-        double* dv = alloc<double>((size_t)cap);
-        double* dh = alloc<double>((size_t)cap);
-        double* du = alloc<double>((size_t)cap);
-        rocblas_int* dinfo = alloc<rocblas_int>(1);
-        bool good = ok;
-        std::vector<int2> F;
-        std::vector<double> xF, z, cF;
-        const double one = 1.0, zero = 0.0;
-        auto blocks = [](int64_t c) { return dim3((unsigned)((c + T - 1) / T)); };
-        auto upload_F = [&]() { if (!F.empty()) (void)hipMemcpyAsync(dF, F.data(), sizeof(int2) * F.size(), hipMemcpyHostToDevice, s); };
-        auto rebuild = [&]() {  // G = H_FF^-1 from the closed form
-            const int f = (int)F.size();
-            st_lh_refactor++;
-            if (f == 0) return true;
-            upload_F();
-            hipLaunchKernelGGL(k_hfill, dim3((unsigned)((f + T - 1) / T), (unsigned)f), dim3(T), 0, s, dF, f, n, G, cap);
-            if (rocsolver_dpotrf(bh, rocblas_fill_lower, f, G, (rocblas_int)cap, dinfo) != rocblas_status_success) return false;
-            rocblas_int info = 0;
-            (void)hipMemcpyAsync(&info, dinfo, sizeof(info), hipMemcpyDeviceToHost, s);
-            (void)hipStreamSynchronize(s);
-            if (info != 0) return false;
-            if (rocsolver_dpotri(bh, rocblas_fill_lower, f, G, (rocblas_int)cap, dinfo) != rocblas_status_success) return false;
-            hipLaunchKernelGGL(k_symmetrize, dim3((unsigned)((f + T - 1) / T), (unsigned)f), dim3(T), 0, s, G, cap, f);
-            return true;
-        };
-        auto solve = [&]() {  // z = G c_F
-            const int f = (int)F.size();
-            z.assign((size_t)f, 0.0);
-            if (f == 0) return true;
-            (void)hipMemcpyAsync(dv, cF.data(), sizeof(double) * (size_t)f, hipMemcpyHostToDevice, s);
-            if (rocblas_dgemv(bh, rocblas_operation_none, f, f, &one, G, (rocblas_int)cap, dv, 1, &zero, du, 1) != rocblas_status_success) return false;
-            (void)hipMemcpyAsync(z.data(), du, sizeof(double) * (size_t)f, hipMemcpyDeviceToHost, s);
-            (void)hipStreamSynchronize(s);
-            return true;
-        };
-        auto remove_at = [&](int p) {  // split F[p] leaves: swap it to the end, eliminate
-            const int f = (int)F.size(), q = f - 1;
-            if (p != q) {
-                hipLaunchKernelGGL(k_swap_rc, blocks(f), dim3(T), 0, s, G, cap, f, p, q);
-                std::swap(F[(size_t)p], F[(size_t)q]); std::swap(xF[(size_t)p], xF[(size_t)q]); std::swap(cF[(size_t)p], cF[(size_t)q]);
-            }
-            double gamma = 0.0;
-            (void)hipMemcpyAsync(&gamma, G + (int64_t)q * cap + q, sizeof(double), hipMemcpyDeviceToHost, s);
-            (void)hipStreamSynchronize(s);
-            F.pop_back(); xF.pop_back(); cF.pop_back();
-            if (!(gamma > 0.0)) return false;
-            const double a = -1.0 / gamma;
-            // (the column is copied first: dger must not read what it writes)
-            if (q > 0) {
-                (void)hipMemcpyAsync(dh, G + (int64_t)q * cap, sizeof(double) * (size_t)q, hipMemcpyDeviceToDevice, s);
-                if (rocblas_dger(bh, q, q, &a, dh, 1, dh, 1, G, (rocblas_int)cap) != rocblas_status_success) return false;
-            }
-            return true;
-        };
-        Atx(d, atwd);  // c = A^T d
-        double cmax = 0.0;
-        {
-            (void)hipMemsetAsync(act, 0, (size_t)n * (size_t)ld, s);
-            const Best b = reduce_best<RD_MAX_UNMASKED>(atwd, nullptr);
-            cmax = b.k == INT64_MAX ? 0.0 : -b.v;
+        int64_t cap = 0, kmax = 0, rcap = 0, f = 0, r = 0;
+        double *W = nullptr, *B = nullptr, *Tb = nullptr, *X = nullptr, *S = nullptr, *S0 = nullptr, *Li = nullptr, *tmp = nullptr;
+        double *Y = nullptr, *CR = nullptr, *LC = nullptr, *CRb = nullptr;
+        double *z = nullptr, *v = nullptr, *xs = nullptr, *cK = nullptr, *lam = nullptr, *gF = nullptr;
+        int2 *dF = nullptr, *dscr = nullptr;
+        int32_t* dlist = nullptr;
+        int64_t* dinfo = nullptr;
+        double* ckey = nullptr; double* ckey2 = nullptr; int64_t* cidx = nullptr; int64_t* cidx2 = nullptr;
+        unsigned long long* ccount = nullptr; void* sort_tmp = nullptr; size_t sort_bytes = 0; int64_t ccap = 0;
+        int64_t tmp_elems = 0;
+    } bk;
+    bool blas_ok = true;
+    static int64_t up64(int64_t v) { return (v + 63) / 64 * 64; }
+    static dim3 g1(int64_t c) { return dim3((unsigned)((c + T - 1) / T)); }
+    static dim3 g2(int64_t rows, int64_t cols) { return dim3((unsigned)((rows + T - 1) / T), (unsigned)std::max<int64_t>(1, std::min<int64_t>(cols, 16384))); }
+    void gemm(rocblas_operation ta, rocblas_operation tb, int64_t m, int64_t nn, int64_t k, double alpha, const double* A, int64_t lda, const double* Bm,
+              int64_t ldb, double beta, double* Cm, int64_t ldc) {
+        if (m <= 0 || nn <= 0) return;
+        if (rocblas_dgemm_64(bk.bh, ta, tb, m, nn, k, &alpha, A, lda, Bm, ldb, &beta, Cm, ldc) != rocblas_status_success) blas_ok = false;
+    }
+    void gemv(rocblas_operation ta, int64_t m, int64_t nn, double alpha, const double* A, int64_t lda, const double* xv, double beta, double* yv) {
+        if (m <= 0 || nn <= 0) return;
+        if (rocblas_dgemv_64(bk.bh, ta, m, nn, &alpha, A, lda, xv, 1, &beta, yv, 1) != rocblas_status_success) blas_ok = false;
+    }
+    // panels that skip the zero half of a lower-triangular operand
+    static int64_t panel(int64_t f) { return std::max<int64_t>(1024, up64((f + 7) / 8)); }
+    // out (f x k, ldo) = Wl (f x f lower, ldw) * Bm (f x k, ldb)
+    void tri_times(const double* Wl, int64_t ldw, int64_t f, const double* Bm, int64_t ldb, int64_t k, double* out, int64_t ldo) {
+        const int64_t chunks = (f + SK_CHUNK - 1) / SK_CHUNK;
+        if (k <= SMALLK && chunks * k * f <= bk.cap * bk.kmax) {  // a few columns: one pass over Wl (partial sums per column chunk in bk.X)
+            (void)hipMemsetAsync(bk.X, 0, sizeof(double) * (size_t)(chunks * k * f), s);
+            hipLaunchKernelGGL(k_tri_times_small, dim3((unsigned)((f + T - 1) / T), (unsigned)chunks), dim3(T), 0, s, Wl, ldw, f, Bm, ldb, (int)k, bk.X);
+            hipLaunchKernelGGL(k_sum_parts, g2(f, k), dim3(T), 0, s, bk.X, k * f, (int)chunks, f, k, 1.0, 0.0, out, ldo);
+            return;
         }
+        const int64_t pb = panel(f);
+        for (int64_t p0 = 0; p0 < f; p0 += pb) {
+            const int64_t p1 = std::min(f, p0 + pb);
+            gemm(rocblas_operation_none, rocblas_operation_none, p1 - p0, k, p1, 1.0, Wl + p0, ldw, Bm, ldb, 0.0, out + p0, ldo);
+        }
+    }
+    // out (k x f, ldo) = Tm^T (Tm: f x k, ldt) * Wl (f x f lower, ldw)
+    void t_times_tri(const double* Tm, int64_t ldt, int64_t k, const double* Wl, int64_t ldw, int64_t f, double* out, int64_t ldo) {
+        if (k <= SMALLK) {
+            hipLaunchKernelGGL(k_t_times_tri_small, dim3((unsigned)f), dim3(T), 0, s, Tm, ldt, (int)k, Wl, ldw, f, out, ldo);
+            return;
+        }
+        const int64_t pb = panel(f);
+        for (int64_t p0 = 0; p0 < f; p0 += pb) {
+            const int64_t p1 = std::min(f, p0 + pb);
+            gemm(rocblas_operation_transpose, rocblas_operation_none, k, p1 - p0, f - p0, 1.0, Tm + p0, ldt, Wl + p0 + p0 * ldw, ldw, 0.0, out + p0 * ldo, ldo);
+        }
+    }
+    // C (m x nn) = beta C + alpha A^T B with a long inner dimension kk (A: kk x m, B: kk x nn): rocBLAS has no split-K form of
+    // this shape (3 TF/s); here the inner dimension is cut into slices that run as one strided-batched GEMM into partial
+    // products (workspace bk.X), added up in slice order
+    void tn_splitk(int64_t m, int64_t nn, int64_t kk, double alpha, const double* A, int64_t lda, const double* Bm, int64_t ldb, double beta, double* Cm,
+                   int64_t ldc) {
+        if (m <= 0 || nn <= 0) return;
+        const int64_t room = (bk.cap * bk.kmax) / std::max<int64_t>(m * nn, 1);
+        int64_t parts = std::min<int64_t>({room, (int64_t)32, (kk + 1023) / 1024});
+        if (parts < 2 || m * nn > (int64_t)1 << 26) {
+            gemm(rocblas_operation_transpose, rocblas_operation_none, m, nn, kk, alpha, A, lda, Bm, ldb, beta, Cm, ldc);
+            return;
+        }
+        const int64_t slice = kk / parts, rest = kk - slice * parts;  // `parts` equal slices, the remainder as one more
+        const double one = 1.0, zero = 0.0;
+        if (rocblas_dgemm_strided_batched_64(bk.bh, rocblas_operation_transpose, rocblas_operation_none, m, nn, slice, &one, A, lda, slice, Bm, ldb, slice, &zero,
+                                             bk.X, m, m * nn, parts) != rocblas_status_success) blas_ok = false;
+        int np = (int)parts;
+        if (rest > 0 && parts < room) {
+            gemm(rocblas_operation_transpose, rocblas_operation_none, m, nn, rest, 1.0, A + slice * parts, lda, Bm + slice * parts, ldb, 0.0, bk.X + parts * m * nn, m);
+            np++;
+        } else if (rest > 0) {
+            gemm(rocblas_operation_transpose, rocblas_operation_none, m, nn, rest, 1.0, A + slice * parts, lda, Bm + slice * parts, ldb, 1.0, bk.X + (parts - 1) * m * nn, m);
+        }
+        hipLaunchKernelGGL(k_sum_parts, g2(m, nn), dim3(T), 0, s, bk.X, m * nn, np, m, nn, alpha, beta, Cm, ldc);
+    }
+    // in-place inverse of a lower-triangular matrix (zeros above the diagonal), recursive halves, GEMMs only:
+    // inv [[A, 0], [C, B]] = [[A^-1, 0], [-B^-1 C A^-1, B^-1]]; the two products run in chunks through bk.tmp
+    void trtri(double* A, int64_t m, int64_t ld) {
+        if (m <= TRI_NB) { hipLaunchKernelGGL(k_trinv_small, dim3(1), dim3(TRI_NB), 0, s, A, ld, (int)m, (int64_t)0); return; }
+        const int64_t m1 = std::min(m - 1, up64((m + 1) / 2)), m2 = m - m1;
+        double *A11 = A, *A21 = A + m1, *A22 = A + m1 + m1 * ld;
+        trtri(A11, m1, ld);
+        trtri(A22, m2, ld);
+        // C <- C A11^-1: column chunk [j0, j1) needs the columns >= j0 of C (not yet overwritten)
+        const int64_t cb = std::max<int64_t>(64, std::min<int64_t>(m1, bk.tmp_elems / std::max<int64_t>(m2, 1)));
+        for (int64_t j0 = 0; j0 < m1; j0 += cb) {
+            const int64_t j1 = std::min(m1, j0 + cb);
+            gemm(rocblas_operation_none, rocblas_operation_none, m2, j1 - j0, m1 - j0, 1.0, A21 + j0 * ld, ld, A11 + j0 + j0 * ld, ld, 0.0, bk.tmp, m2);
+            (void)hipMemcpy2DAsync(A21 + j0 * ld, sizeof(double) * (size_t)ld, bk.tmp, sizeof(double) * (size_t)m2, sizeof(double) * (size_t)m2,
+                                   (size_t)(j1 - j0), hipMemcpyDeviceToDevice, s);
+        }
+        // C <- -A22^-1 C: row chunk [i0, i1), from the bottom up, needs the rows <= i1 of C (not yet overwritten)
+        const int64_t rb = std::max<int64_t>(64, std::min<int64_t>(m2, bk.tmp_elems / std::max<int64_t>(m1, 1)));
+        for (int64_t i1 = m2; i1 > 0; i1 -= std::min(rb, i1)) {
+            const int64_t i0 = i1 - std::min(rb, i1);
+            gemm(rocblas_operation_none, rocblas_operation_none, i1 - i0, m1, i1, -1.0, A22 + i0, ld, A21, ld, 0.0, bk.tmp, i1 - i0);
+            (void)hipMemcpy2DAsync(A21 + i0, sizeof(double) * (size_t)ld, bk.tmp, sizeof(double) * (size_t)(i1 - i0), sizeof(double) * (size_t)(i1 - i0),
+                                   (size_t)m1, hipMemcpyDeviceToDevice, s);
+        }
+    }
+    int64_t potrf(double* A, int64_t m, int64_t ld) {  // lower Cholesky in place; 0, or the order of the leading minor that is not positive definite; -1: call failed
+        if (m <= 0) return 0;
+        if (rocsolver_dpotrf_64(bk.bh, rocblas_fill_lower, m, A, ld, bk.dinfo) != rocblas_status_success) { blas_ok = false; return -1; }
+        int64_t info = 0;
+        (void)hipMemcpyAsync(&info, bk.dinfo, sizeof(info), hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        return info;
+    }
+    double wall() { (void)hipStreamSynchronize(s); return fnn::now_s(); }
+    std::map<std::string, double> tsub;  // finer split of the phases (FNN_SW_LOG)
+    double t_lap = 0.0;
+    bool lap_on = false;
+    void lap(const char* name) {
+        if (!lap_on) return;
+        const double t = wall();
+        if (name) tsub[name] += t - t_lap;
+        t_lap = t;
+    }
+
+    bool block_active_set() {
+        const bool log = std::getenv("FNN_SW_LOG") != nullptr;
+        lap_on = log;
+        auto envd = [](const char* k, double dflt) { const char* e = std::getenv(k); return e ? std::atof(e) : dflt; };
+        const double kfrac = envd("FNN_SW_KFRAC", 0.10), rfrac = envd("FNN_SW_RFRAC", 0.15);
+        const int rad = (int)envd("FNN_SW_NMS", 3);
+        const int64_t N = (int64_t)n * (n - 1) / 2;
+        Blk& b = bk;
+        block_mark = allocs.size();
+        b.cap = up64(std::min<int64_t>(N, std::max<int64_t>({(int64_t)(envd("FNN_SW_CAP", 3.25) * n) + 1024, std::min<int64_t>(8 * (int64_t)n + 64, 20000), 512})));
+        b.kmax = std::min<int64_t>(b.cap, std::max<int64_t>(64, up64(b.cap / 12)));
+        b.rcap = std::min<int64_t>(b.cap, up64(b.cap / 5) + 64);
+        if (rocblas_create_handle(&b.bh) != rocblas_status_success) return false;
+        struct HandleGuard { rocblas_handle h; ~HandleGuard() { rocblas_destroy_handle(h); } } guard{b.bh};
+        rocblas_set_stream(b.bh, s);
+        rocblas_set_pointer_mode(b.bh, rocblas_pointer_mode_host);
+        b.W = alloc<double>((size_t)b.cap * b.cap);
+        b.B = alloc<double>((size_t)b.cap * b.kmax); b.Tb = alloc<double>((size_t)b.cap * b.kmax); b.X = alloc<double>((size_t)b.cap * b.kmax);
+        b.S = alloc<double>((size_t)b.kmax * b.kmax); b.S0 = alloc<double>((size_t)b.kmax * b.kmax); b.Li = alloc<double>((size_t)b.kmax * b.kmax);
+        b.tmp_elems = std::max<int64_t>((int64_t)b.cap * 2048, 1 << 20);
+        b.tmp = alloc<double>((size_t)b.tmp_elems);
+        b.Y = alloc<double>((size_t)b.cap * b.rcap);
+        b.CR = alloc<double>((size_t)b.rcap * b.rcap); b.LC = alloc<double>((size_t)b.rcap * b.rcap); b.CRb = alloc<double>((size_t)b.rcap * b.rcap);
+        b.z = alloc<double>((size_t)b.cap); b.v = alloc<double>((size_t)b.cap); b.xs = alloc<double>((size_t)b.cap); b.cK = alloc<double>((size_t)b.cap);
+        b.lam = alloc<double>((size_t)b.rcap); b.gF = alloc<double>((size_t)b.cap);
+        b.dF = alloc<int2>((size_t)b.cap); b.dscr = alloc<int2>((size_t)b.cap); b.dlist = alloc<int32_t>((size_t)b.cap); b.dinfo = alloc<int64_t>(1);
+        b.ccap = std::min<int64_t>(N, std::max<int64_t>(1 << 16, N / 16 + 1024));
+        b.ckey = alloc<double>((size_t)b.ccap); b.ckey2 = alloc<double>((size_t)b.ccap);
+        b.cidx = alloc<int64_t>((size_t)b.ccap); b.cidx2 = alloc<int64_t>((size_t)b.ccap);
+        b.ccount = alloc<unsigned long long>(1);
+        if (hipcub::DeviceRadixSort::SortPairsDescending(nullptr, b.sort_bytes, b.ckey, b.ckey2, b.cidx, b.cidx2, (int)std::min<int64_t>(b.ccap, INT32_MAX), 0,
+                                                         64, s) != hipSuccess) return false;
+        b.sort_tmp = alloc<uint8_t>(b.sort_bytes + 16);
+        if (!ok) return false;
+
+        // host state: the factor's splits in factor order, their weights, who left
+        std::vector<int2> F;
+        std::vector<double> xw;         // weight per factor position (0 for the splits that left)
+        std::vector<double> cF;         // c = A^T d at the factor positions
+        std::vector<uint8_t> dead;
+        std::vector<int32_t> deadlist;  // factor positions of the splits that left, in the order of Y's columns
+        std::vector<int2> banned;
+        double phi = 0.0;               // objective - c_F . x_F / 2 of the current point (a sub-problem's exact minimiser)
+
+        Atx(d, atwd);  // c = A^T d
+        (void)hipMemsetAsync(act, 0, (size_t)n * (size_t)ld, s);
+        double cmax = 0.0;
+        { const Best bb = reduce_best<RD_MAX_UNMASKED>(atwd, nullptr); cmax = bb.k == INT64_MAX ? 0.0 : -bb.v; }
         const double tol = 1e-12 * (cmax > 0.0 ? cmax : 1.0);
-        std::vector<int64_t> banned;
-        const int64_t max_steps = 8 * cap + 1000;
-        bool fresh = true, done = false;  // fresh: G was just rebuilt (the Kuhn-Tucker test only counts on a fresh inverse)
-        // move from xF towards z as far as feasibility allows; what reaches zero leaves F; repeat until z > 0
-        auto settle = [&]() {
+
+        auto upload_F = [&](int64_t from, int64_t to) {
+            if (to > from) (void)hipMemcpyAsync(b.dF + from, F.data() + from, sizeof(int2) * (size_t)(to - from), hipMemcpyHostToDevice, s);
+        };
+        auto set_mask = [&](const std::vector<int2>& list, uint8_t v) {  // (through the scratch list: the factor's own list stays as it is)
+            if (list.empty()) return;
+            (void)hipMemcpyAsync(b.dscr, list.data(), sizeof(int2) * list.size(), hipMemcpyHostToDevice, s);
+            hipLaunchKernelGGL(k_mask, g1((int64_t)list.size()), dim3(T), 0, s, b.dscr, (int64_t)list.size(), act, ld, v);
+            (void)hipStreamSynchronize(s);
+        };
+        // LC = Cholesky factor of the Gram matrix CR of the departed columns
+        auto factor_gram = [&]() -> bool {
+            if (b.r == 0) return true;
+            hipLaunchKernelGGL(k_copy_lower, g2(b.r, b.r), dim3(T), 0, s, b.CR, b.rcap, b.LC, b.rcap, b.r);
+            return potrf(b.LC, b.r, b.rcap) == 0;
+        };
+        // rebuild the factor from the closed form for the splits that are still in
+        auto refactor = [&]() -> bool {
+            const double t0 = log ? wall() : 0.0;
+            st_lh_refactor++;
+            std::vector<int2> gone;
+            size_t q = 0;
+            for (size_t p = 0; p < F.size(); p++) {
+                if (dead[p]) { gone.push_back(F[p]); continue; }
+                F[q] = F[p]; xw[q] = xw[p]; cF[q] = cF[p]; q++;
+            }
+            F.resize(q); xw.resize(q); cF.resize(q); dead.assign(q, 0); deadlist.clear();
+            set_mask(gone, 0);  // they may enter again
+            b.f = (int64_t)q; b.r = 0;
+            if (b.f == 0) return true;
+            upload_F(0, b.f);
+            lap(nullptr);
+            hipLaunchKernelGGL(k_hblock, g2(b.f, b.f), dim3(T), 0, s, b.dF, b.f, b.dF, b.f, n, b.W, b.cap, 1);
+            lap("refactor.hblock");
+            if (potrf(b.W, b.f, b.cap) != 0) return false;
+            lap("refactor.potrf");
+            trtri(b.W, b.f, b.cap);
+            lap("refactor.trtri");
+            (void)hipMemcpyAsync(b.cK, cF.data(), sizeof(double) * (size_t)b.f, hipMemcpyHostToDevice, s);
+            const int64_t pb = panel(b.f);
+            for (int64_t p0 = 0; p0 < b.f; p0 += pb) {  // z = W c_F
+                const int64_t p1 = std::min(b.f, p0 + pb);
+                gemv(rocblas_operation_none, p1 - p0, p1, 1.0, b.W + p0, b.cap, b.cK, 0.0, b.z + p0);
+            }
+            (void)hipStreamSynchronize(s);
+            if (log) t_refactor += wall() - t0;
+            return blas_ok;
+        };
+        // append the k splits at b.dF[f .. f + k); returns the number that entered (a block whose Schur complement is
+        // not positive definite is cut in front of the offending split), -1 on failure
+        auto append = [&](int64_t k) -> int64_t {
+            const double t0 = log ? wall() : 0.0;
+            const int64_t f = b.f;
+            const int2* dK = b.dF + f;
+            lap(nullptr);
+            hipLaunchKernelGGL(k_hblock, g2(k, k), dim3(T), 0, s, dK, k, dK, k, n, b.S, b.kmax, 0);
+            if (f > 0) {
+                hipLaunchKernelGGL(k_hblock, g2(f, k), dim3(T), 0, s, b.dF, f, dK, k, n, b.B, b.cap, 0);
+                lap("append.hblock");
+                tri_times(b.W, b.cap, f, b.B, b.cap, k, b.Tb, b.cap);  // T = L^-1 B = L21^T
+                lap("append.W*B");
+                tn_splitk(k, k, f, -1.0, b.Tb, b.cap, b.Tb, b.cap, 1.0, b.S, b.kmax);  // S = H_KK - L21 L21^T
+            }
+            lap("append.syrk");
+            (void)hipMemcpy2DAsync(b.S0, sizeof(double) * (size_t)b.kmax, b.S, sizeof(double) * (size_t)b.kmax, sizeof(double) * (size_t)k, (size_t)k,
+                                   hipMemcpyDeviceToDevice, s);
+            const int64_t info = potrf(b.S, k, b.kmax);
+            lap("append.potrf");
+            if (info < 0) return -1;
+            if (info > 0) {
+                k = info - 1;
+                if (k == 0) return 0;
+                (void)hipMemcpy2DAsync(b.S, sizeof(double) * (size_t)b.kmax, b.S0, sizeof(double) * (size_t)b.kmax, sizeof(double) * (size_t)k, (size_t)k,
+                                       hipMemcpyDeviceToDevice, s);
+                if (potrf(b.S, k, b.kmax) != 0) return -1;
+            }
+            hipLaunchKernelGGL(k_copy_lower, g2(k, k), dim3(T), 0, s, b.S, b.kmax, b.Li, b.kmax, k);
+            trtri(b.Li, k, b.kmax);  // L22^-1
+            lap("append.trtri");
+            hipLaunchKernelGGL(k_gather, g1(k), dim3(T), 0, s, dK, k, atwd, ld, b.cK);
+            if (f > 0) {
+                t_times_tri(b.Tb, b.cap, k, b.W, b.cap, f, b.X, b.kmax);                                                            // X = L21 W
+                lap("append.T'*W");
+                gemm(rocblas_operation_none, rocblas_operation_none, k, f, k, -1.0, b.Li, b.kmax, b.X, b.kmax, 0.0, b.W + f, b.cap);  // new rows -L22^-1 X
+                (void)hipMemset2DAsync(b.W + f * b.cap, sizeof(double) * (size_t)b.cap, 0, sizeof(double) * (size_t)f, (size_t)k);     // zeros above them
+                gemv(rocblas_operation_transpose, f, k, -1.0, b.Tb, b.cap, b.z, 1.0, b.cK);                                           // c_K - L21 z
+            }
+            (void)hipMemcpy2DAsync(b.W + f + f * b.cap, sizeof(double) * (size_t)b.cap, b.Li, sizeof(double) * (size_t)b.kmax, sizeof(double) * (size_t)k,
+                                   (size_t)k, hipMemcpyDeviceToDevice, s);
+            gemv(rocblas_operation_none, k, k, 1.0, b.Li, b.kmax, b.cK, 0.0, b.z + f);  // z_K = L22^-1 (c_K - L21 z)
+            lap("append.rows");
+            if (b.r > 0) {  // the departed columns grow by the new rows; so does their Gram matrix
+                hipLaunchKernelGGL(k_gather_rows, g2(k, b.r), dim3(T), 0, s, b.W, b.cap, f, k, b.dlist, b.r, b.Y, b.cap);
+                const double one = 1.0;
+                if (rocblas_dsyrk_64(b.bh, rocblas_fill_lower, rocblas_operation_transpose, b.r, k, &one, b.Y + f, b.cap, &one, b.CR, b.rcap) != rocblas_status_success)
+                    blas_ok = false;
+                lap("append.gram_syrk");
+                if (!factor_gram()) return -1;
+                lap("append.gram_potrf");
+            }
+            b.f = f + k;
+            if (log) t_append += wall() - t0;
+            return blas_ok ? k : -1;
+        };
+        // the splits at the factor positions `idxs` leave: their columns join Y, the Gram matrix grows
+        auto depart = [&](const std::vector<int32_t>& idxs) -> bool {
+            const double t0 = log ? wall() : 0.0;
+            const int64_t nn = (int64_t)idxs.size(), r = b.r, f = b.f;
+            lap(nullptr);
+            (void)hipMemcpyAsync(b.dlist + r, idxs.data(), sizeof(int32_t) * (size_t)nn, hipMemcpyHostToDevice, s);
+            hipLaunchKernelGGL(k_gather_cols, g2(f, nn), dim3(T), 0, s, b.W, b.cap, f, b.dlist + r, nn, b.Y + r * b.cap, b.cap);
+            // CR[r : r + nn, 0 : r + nn] = YN^T [Y, YN]
+            tn_splitk(nn, r + nn, f, 1.0, b.Y + r * b.cap, b.cap, b.Y, b.cap, 0.0, b.CR + r, b.rcap);
+            (void)hipStreamSynchronize(s);  // (idxs may be a temporary)
+            lap("depart.gather+gram_gemm");
+            for (int32_t p : idxs) { dead[(size_t)p] = 1; xw[(size_t)p] = 0.0; deadlist.push_back(p); }
+            b.r = r + nn;
+            const bool fine = factor_gram();
+            lap("depart.gram_potrf");
+            if (log) t_dead += wall() - t0;
+            return fine && blas_ok;
+        };
+        // minimiser of the sub-problem on the splits that are in: xs = W^T (z - Y (Y^T Y)^-1 Y^T z), copied to `out`
+        auto solve = [&](std::vector<double>& out) -> bool {
+            const double t0 = log ? wall() : 0.0;
+            st_solves++;
+            const int64_t f = b.f, r = b.r;
+            out.assign((size_t)f, 0.0);
+            if (f == 0) return true;
+            const double* vv = b.z;
+            if (r > 0) {
+                gemv(rocblas_operation_transpose, f, r, 1.0, b.Y, b.cap, b.z, 0.0, b.lam);
+                if (rocsolver_dpotrs_64(b.bh, rocblas_fill_lower, r, 1, b.LC, b.rcap, b.lam, b.rcap) != rocblas_status_success) blas_ok = false;
+                (void)hipMemcpyAsync(b.v, b.z, sizeof(double) * (size_t)f, hipMemcpyDeviceToDevice, s);
+                gemv(rocblas_operation_none, f, r, -1.0, b.Y, b.cap, b.lam, 1.0, b.v);
+                vv = b.v;
+            }
+            const int64_t pb = panel(f);
+            for (int64_t p0 = 0; p0 < f; p0 += pb) {
+                const int64_t p1 = std::min(f, p0 + pb);
+                gemv(rocblas_operation_transpose, f - p0, p1 - p0, 1.0, b.W + p0 + p0 * b.cap, b.cap, vv + p0, 0.0, b.xs + p0);
+            }
+            (void)hipMemcpyAsync(out.data(), b.xs, sizeof(double) * (size_t)f, hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            for (size_t p = 0; p < (size_t)f; p++) if (dead[p]) out[p] = 0.0;
+            if (log) t_solve += wall() - t0;
+            return blas_ok;
+        };
+        auto objective = [&](const std::vector<double>& xs) {
+            double acc = 0.0;
+            for (size_t p = 0; p < xs.size(); p++) if (!dead[p]) acc += cF[p] * xs[p];
+            return -0.5 * acc;
+        };
+        std::vector<double> sbuf;
+        // every weight that is not positive leaves, until the sub-problem's minimiser is feasible (false: out of room / failure)
+        auto settle_all = [&]() -> bool {
             for (;;) {
-                double alpha = 2.0;
-                for (size_t p = 0; p < F.size(); p++)
-                    if (z[p] <= 0.0) { const double al = xF[p] / (xF[p] - z[p]); if (al < alpha) alpha = al; }
-                if (alpha > 1.0) { xF = z; return true; }
-                std::vector<int2> out;
-                for (size_t p = 0; p < F.size(); p++) {
-                    const double v = xF[p] + alpha * (z[p] - xF[p]);
-                    const bool keep = v > 0.0 && !(z[p] <= 0.0 && xF[p] / (xF[p] - z[p]) <= alpha);
-                    if (keep) xF[p] = v; else out.push_back(F[p]);
-                }
-                for (const int2& t : out) {
-                    int p = -1;
-                    for (size_t q = 0; q < F.size(); q++) if (F[q].x == t.x && F[q].y == t.y) { p = (int)q; break; }
-                    if (p < 0 || !remove_at(p)) return false;
-                }
-                fresh = false;
-                if (!solve()) return false;
+                if (!solve(sbuf)) return false;
+                std::vector<int32_t> out;
+                for (size_t p = 0; p < sbuf.size(); p++) if (!dead[p] && !(sbuf[p] > 0.0)) out.push_back((int32_t)p);
+                if (out.empty()) return true;
+                if (b.r + (int64_t)out.size() > b.rcap) return false;
+                st_dels += (int64_t)out.size();
+                if (!depart(out)) return false;
             }
         };
-        while (good && !done && st_lh_steps < max_steps) {
+
+        const int64_t kmin = std::max<int64_t>(8, n / 32);
+        int64_t k_limit = b.kmax;
+        bool ratio_mode = false, done = false, good = ok, fresh = false;
+        const int64_t max_outer = 40 * (int64_t)n + 1000;
+        while (good && !done && st_lh_steps < max_outer) {
             st_lh_steps++;
-            // x on the grid (zero outside F), mask = F (+ the splits that were rejected since the last successful step)
-            const int f = (int)F.size();
-            (void)hipMemsetAsync(x, 0, sizeof(double) * (size_t)n * (size_t)ld, s);
-            (void)hipMemsetAsync(act, 0, (size_t)n * (size_t)ld, s);
-            if (f) {
-                upload_F();
-                (void)hipMemcpyAsync(dv, xF.data(), sizeof(double) * (size_t)f, hipMemcpyHostToDevice, s);
-                hipLaunchKernelGGL(k_scatter, blocks(f), dim3(T), 0, s, dF, f, dv, x, act, ld);
+            // ---- multipliers: r = c - A^T A x on the grid; the entries at the factor's splits go to the host
+            double t0 = log ? wall() : 0.0;
+            (void)hipMemsetAsync(this->x, 0, sizeof(double) * (size_t)n * (size_t)ld, s);
+            if (b.f) {
+                (void)hipMemcpyAsync(b.xs, xw.data(), sizeof(double) * (size_t)b.f, hipMemcpyHostToDevice, s);
+                hipLaunchKernelGGL(k_scatter, g1(b.f), dim3(T), 0, s, b.dF, b.f, b.xs, this->x, ld);
             }
-            for (int64_t k : banned) { const uint8_t one8 = 1; (void)hipMemcpyAsync(act + k, &one8, 1, hipMemcpyHostToDevice, s); }
-            // r = A^T A x: on F, c - r shows the drift of the updated inverse; outside, c - r is the multiplier w
-            Ab(x, y);
+            Ab(this->x, y);
             Atx(y, r);
-            double drift = 0.0;
-            if (f) {
-                hipLaunchKernelGGL(k_gather, blocks(f), dim3(T), 0, s, dF, f, r, ld, dh);
-                std::vector<double> rf((size_t)f);
-                (void)hipMemcpyAsync(rf.data(), dh, sizeof(double) * (size_t)f, hipMemcpyDeviceToHost, s);
-                (void)hipStreamSynchronize(s);
-                for (int p = 0; p < f; p++) drift = std::max(drift, std::fabs(cF[(size_t)p] - rf[(size_t)p]));
+            std::vector<double> gF((size_t)b.f);
+            if (b.f) {
+                hipLaunchKernelGGL(k_gather, g1(b.f), dim3(T), 0, s, b.dF, b.f, r, ld, b.gF);
+                (void)hipMemcpyAsync(gF.data(), b.gF, sizeof(double) * (size_t)b.f, hipMemcpyDeviceToHost, s);
             }
             vec<OP_R_INIT>(r, nullptr, atwd, nullptr);  // r = masked ? 0 : c - r
-            const Best b = reduce_best<RD_MAX_UNMASKED>(r, nullptr);
-            const bool kkt = b.k == INT64_MAX || -b.v <= tol;
-            if ((drift > 1e-9 * cmax || kkt) && !fresh) {
-                // the updated inverse has drifted, or this looks like the end: the same free set once more on a freshly
-                // built inverse, then look again
-                if (!rebuild() || !solve()) { good = false; break; }
-                fresh = true;
-                if (!settle()) { good = false; break; }
-                continue;
-            }
-            if (kkt) { done = true; break; }  // Kuhn-Tucker on a fresh inverse: no split outside F wants in
-            if ((int64_t)F.size() + 1 > cap) { good = false; break; }
-            // the split with the largest multiplier enters: border the inverse
-            const int2 t = make_int2((int)(b.k / ld), (int)(b.k % ld));
-            double ct = 0.0;
-            (void)hipMemcpyAsync(&ct, atwd + b.k, sizeof(double), hipMemcpyDeviceToHost, s);
-            F.push_back(t); xF.push_back(0.0);
-            upload_F();
-            hipLaunchKernelGGL(k_hcol, blocks(f + 1), dim3(T), 0, s, dF, f, n, dh);
-            double eta = 0.0, hu = 0.0;
-            (void)hipMemcpyAsync(&eta, dh + f, sizeof(double), hipMemcpyDeviceToHost, s);
-            if (f > 0) {
-                if (rocblas_dgemv(bh, rocblas_operation_none, f, f, &one, G, (rocblas_int)cap, dh, 1, &zero, du, 1) != rocblas_status_success ||
-                    rocblas_ddot(bh, f, dh, 1, du, 1, &hu) != rocblas_status_success) { good = false; break; }
-            }
+            if (log) t_ops += wall() - t0;
+            t0 = log ? wall() : 0.0;
+            (void)hipMemsetAsync(b.ccount, 0, sizeof(unsigned long long), s);
+            hipLaunchKernelGGL(k_candidates, grid2, dim3(T), 0, s, r, act, n, ld, tol, rad, b.ckey, b.cidx, b.ccount, (unsigned long long)b.ccap);
+            unsigned long long ncand64 = 0;
+            (void)hipMemcpyAsync(&ncand64, b.ccount, sizeof(ncand64), hipMemcpyDeviceToHost, s);
             (void)hipStreamSynchronize(s);
-            cF.push_back(ct);
-            const double schur = eta - hu;
-            bool accepted = schur > 1e-10 * eta;
-            if (accepted) {
-                const double sinv = 1.0 / schur;
-                if (f > 0 && rocblas_dger(bh, f, f, &sinv, du, 1, du, 1, G, (rocblas_int)cap) != rocblas_status_success) { good = false; break; }
-                hipLaunchKernelGGL(k_border, blocks(f + 1), dim3(T), 0, s, G, cap, f, du, sinv);
-                fresh = false;
-                if (!solve()) { good = false; break; }
-                accepted = z.back() > 0.0;  // (Lawson & Hanson's check on the entering variable)
-                if (!accepted && !remove_at(f)) { good = false; break; }
-            } else { F.pop_back(); xF.pop_back(); cF.pop_back(); }
-            if (!accepted) {  // numerically dependent on F, or not a descent direction after all: leave it out for now
-                banned.push_back(b.k);
-                if (!solve()) { good = false; break; }
+            const int64_t ncand = (int64_t)std::min<unsigned long long>(ncand64, (unsigned long long)b.ccap);
+            // (gF holds A^T A x at the factor's splits: c - gF is the multiplier of a split that left, the drift at one that is in)
+            double drift = 0.0, wdead = 0.0;
+            for (size_t p = 0; p < (size_t)b.f; p++) {
+                const double g = cF[p] - gF[p];
+                if (dead[p]) wdead = std::max(wdead, g); else drift = std::max(drift, std::fabs(g));
+            }
+            const int64_t nlive = b.f - b.r;
+            int64_t k = (int64_t)std::min<double>((double)b.kmax, std::max<double>((double)kmin, kfrac * (double)std::max<int64_t>(nlive, 1)));
+            k = std::max<int64_t>(1, std::min<int64_t>({k, ncand, k_limit}));
+            const bool no_cand = ncand == 0;
+            if ((no_cand && (wdead > tol || (drift > 1e-10 * cmax && !fresh))) || (!no_cand && (b.f + k > b.cap || (double)b.r > rfrac * (double)b.f))) {
+                // a split that left wants back in, the factor has drifted or is full of departed splits: rebuild it, solve, look again
+                if (!no_cand && b.r == 0) { good = false; break; }  // the free set outgrows the dense factor: the caller takes the reference's route
+                if (!refactor() || !settle_all()) { good = false; break; }
+                xw = sbuf; phi = objective(xw); fresh = true;
                 continue;
             }
-            banned.clear();
-            if (!settle()) { good = false; break; }
+            if (no_cand) { done = true; break; }
+            // ---- the block: the largest local maxima of the multiplier
+            if (hipcub::DeviceRadixSort::SortPairsDescending(b.sort_tmp, b.sort_bytes, b.ckey, b.ckey2, b.cidx, b.cidx2, (int)ncand, 0, 64, s) != hipSuccess) {
+                good = false; break;
+            }
+            hipLaunchKernelGGL(k_idx_to_split, g1(k), dim3(T), 0, s, b.cidx2, k, ld, b.dF + b.f);
+            F.resize((size_t)(b.f + k));
+            (void)hipMemcpyAsync(F.data() + b.f, b.dF + b.f, sizeof(int2) * (size_t)k, hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            if (log) t_sel += wall() - t0;
+            // ---- it enters, the weights that are not positive leave, the objective decides
+            const int64_t f0 = b.f, r0 = b.r;
+            const int2 first = F[(size_t)f0];
+            const std::vector<uint8_t> dead0 = dead;
+            const std::vector<double> x0 = xw;
+            const std::vector<int32_t> deadlist0 = deadlist;
+            if (r0 > 0) (void)hipMemcpy2DAsync(b.CRb, sizeof(double) * (size_t)b.rcap, b.CR, sizeof(double) * (size_t)b.rcap, sizeof(double) * (size_t)r0, (size_t)r0,
+                                               hipMemcpyDeviceToDevice, s);
+            const int64_t kin = append(k);
+            if (kin < 0) { good = false; break; }
+            if (kin == 0) {  // the first split is numerically dependent on the factor: set it aside until progress is made
+                F.resize((size_t)f0);
+                banned.push_back(first); set_mask({first}, 1);
+                continue;
+            }
+            F.resize((size_t)(f0 + kin));
+            hipLaunchKernelGGL(k_mask, g1(kin), dim3(T), 0, s, b.dF + f0, kin, act, ld, (uint8_t)1);
+            st_adds += kin;
+            xw.resize((size_t)b.f, 0.0); dead.resize((size_t)b.f, 0); cF.resize((size_t)b.f);
+            hipLaunchKernelGGL(k_gather, g1(kin), dim3(T), 0, s, b.dF + f0, kin, atwd, ld, b.xs);
+            (void)hipMemcpyAsync(cF.data() + f0, b.xs, sizeof(double) * (size_t)kin, hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            bool feasible = true;
+            if (!ratio_mode) feasible = settle_all();
+            else {  // Lawson & Hanson: as far towards the sub-problem's minimiser as feasibility allows; what reaches zero leaves
+                std::vector<double> xcur = xw;
+                for (;;) {
+                    if (!solve(sbuf)) { feasible = false; break; }
+                    double alpha = 2.0;
+                    for (size_t p = 0; p < sbuf.size(); p++)
+                        if (!dead[p] && !(sbuf[p] > 0.0)) alpha = std::min(alpha, xcur[p] / (xcur[p] - sbuf[p]));
+                    if (alpha > 1.0) break;
+                    st_ratio_steps++;
+                    std::vector<int32_t> out;
+                    for (size_t p = 0; p < sbuf.size(); p++) {
+                        if (dead[p]) continue;
+                        const bool neg = !(sbuf[p] > 0.0);
+                        const bool hit = neg && !(xcur[p] / (xcur[p] - sbuf[p]) > alpha);  // (0 / 0 counts as a hit)
+                        xcur[p] = hit ? 0.0 : xcur[p] + alpha * (sbuf[p] - xcur[p]);
+                        if (hit || (neg && !(xcur[p] > 0.0))) out.push_back((int32_t)p);
+                    }
+                    if (b.r + (int64_t)out.size() > b.rcap) { feasible = false; break; }
+                    st_dels += (int64_t)out.size();
+                    if (!depart(out)) { feasible = false; break; }
+                }
+            }
+            if (!blas_ok) { good = false; break; }
+            const double phi_new = feasible ? objective(sbuf) : INFINITY;
+            if (!(phi_new < phi)) {  // no descent: the factor as it was before this block
+                st_rejects++;
+                if (log) std::fprintf(stderr, "  [sw] step %lld: block of %lld at |F| = %lld taken back (%.17g vs %.17g)%s\n", (long long)st_lh_steps, (long long)kin,
+                                      (long long)(f0 - r0), phi_new, phi, ratio_mode ? " [ratio step]" : "");
+                hipLaunchKernelGGL(k_mask, g1(b.f - f0), dim3(T), 0, s, b.dF + f0, b.f - f0, act, ld, (uint8_t)0);
+                b.f = f0; b.r = r0;
+                F.resize((size_t)f0); dead = dead0; xw = x0; deadlist = deadlist0; cF.resize((size_t)f0);
+                if (r0 > 0) {
+                    (void)hipMemcpy2DAsync(b.CR, sizeof(double) * (size_t)b.rcap, b.CRb, sizeof(double) * (size_t)b.rcap, sizeof(double) * (size_t)r0, (size_t)r0,
+                                           hipMemcpyDeviceToDevice, s);
+                    (void)hipMemcpyAsync(b.dlist, deadlist.data(), sizeof(int32_t) * (size_t)r0, hipMemcpyHostToDevice, s);
+                    (void)hipStreamSynchronize(s);
+                    if (!factor_gram()) { good = false; break; }
+                }
+                // the same block once more with Lawson & Hanson's step, which cannot ascend; if that made no progress either (rounding
+                // noise at this level): a quarter of the block, and a single split that does not move is set aside
+                if (ratio_mode) {
+                    if (kin == 1) { banned.push_back(first); set_mask({first}, 1); }
+                    k_limit = std::max<int64_t>(1, kin / 4);
+                } else {
+                    ratio_mode = true; k_limit = kin;
+                }
+                continue;
+            }
+            phi = phi_new; xw = sbuf; fresh = false;
+            k_limit = k_limit > b.kmax / 2 ? b.kmax : 2 * k_limit;
+            ratio_mode = ratio_mode && ncand <= 2 * kmin;  // near the end (few candidates, each displacing one split) the guaranteed step stays on
+            if (!banned.empty()) { set_mask(banned, 0); banned.clear(); }  // progress: the splits set aside may be looked at again
+            if (log && (st_lh_steps % 10 == 0 || st_lh_steps < 5))
+                std::fprintf(stderr, "  [sw] step %lld: |F| = %lld (+%lld departed in the factor) candidates %lld block %lld solves %lld objective %.12g | ops %.2f sel %.2f "
+                             "append %.2f solve %.2f depart %.2f refactor %.2f s\n", (long long)st_lh_steps, (long long)(b.f - b.r), (long long)b.r, (long long)ncand,
+                             (long long)kin, (long long)st_solves, phi, t_ops, t_sel, t_append, t_solve, t_dead, t_refactor);
         }
         if (!done) good = false;
         if (good) {  // the optimum on the grid
-            const int f = (int)F.size();
-            (void)hipMemsetAsync(x, 0, sizeof(double) * (size_t)n * (size_t)ld, s);
-            if (f) {
-                upload_F();
-                (void)hipMemcpyAsync(dv, xF.data(), sizeof(double) * (size_t)f, hipMemcpyHostToDevice, s);
-                hipLaunchKernelGGL(k_scatter, blocks(f), dim3(T), 0, s, dF, f, dv, x, act, ld);
+            (void)hipMemsetAsync(this->x, 0, sizeof(double) * (size_t)n * (size_t)ld, s);
+            if (b.f) {
+                (void)hipMemcpyAsync(b.xs, xw.data(), sizeof(double) * (size_t)b.f, hipMemcpyHostToDevice, s);
+                hipLaunchKernelGGL(k_scatter, g1(b.f), dim3(T), 0, s, b.dF, b.f, b.xs, this->x, ld);
             }
             (void)hipStreamSynchronize(s);
         }
-        rocblas_destroy_handle(bh);
+        if (log) std::fprintf(stderr, "  [sw] %s: %lld steps, %lld solves, %lld entered, %lld left, %lld taken back, %lld ratio steps, %lld factorisations; |F| = %lld | ops %.2f "
+                              "sel %.2f append %.2f solve %.2f depart %.2f refactor %.2f s\n", good ? "done" : "gave up", (long long)st_lh_steps, (long long)st_solves,
+                              (long long)st_adds, (long long)st_dels, (long long)st_rejects, (long long)st_ratio_steps, (long long)st_lh_refactor, (long long)(b.f - b.r),
+                              t_ops, t_sel, t_append, t_solve, t_dead, t_refactor);
+        if (log) for (const auto& kv : tsub) std::fprintf(stderr, "  [sw]   %-28s %8.3f s\n", kv.first.c_str(), kv.second);
         return good;
     }
 
@@ -777,8 +1226,9 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
     S.ld = ((int64_t)n + 31) / 32 * 32 + 32;
     if (!SWOK(hipStreamCreateWithFlags(&S.s, hipStreamNonBlocking))) return fnn::fail(FNN_EHIP, "hipStreamCreate failed");
     const size_t NN = (size_t)n * (size_t)S.ld;
-    S.d = S.alloc<double>(NN); S.x = S.alloc<double>(NN); S.r = S.alloc<double>(NN); S.w = S.alloc<double>(NN);
-    S.p = S.alloc<double>(NN); S.y = S.alloc<double>(NN); S.old_x = S.alloc<double>(NN); S.atwd = S.alloc<double>(NN);
+    // (w, p, old_x belong to the reference's method only and are allocated when it runs)
+    S.d = S.alloc<double>(NN); S.x = S.alloc<double>(NN); S.r = S.alloc<double>(NN);
+    S.y = S.alloc<double>(NN); S.atwd = S.alloc<double>(NN);
     S.P = S.alloc<double>(NN); S.Pt = S.alloc<double>(NN); S.rs = S.alloc<double>((size_t)n + 8);
     S.act = S.alloc<uint8_t>(NN);
     S.Dm = S.alloc<double>((size_t)n * (size_t)n);
@@ -790,7 +1240,7 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
     S.sc = S.alloc<double>(SC_WORDS);
     S.bpartial = S.alloc<Best>((size_t)S.gred.x * S.gred.y);
     if (!S.ok) return fnn::fail(FNN_ENOMEM, "fnn_split_weights_f64: device allocation failed");
-    for (double* v : {S.d, S.x, S.r, S.w, S.p, S.y, S.old_x, S.atwd, S.P, S.Pt}) (void)hipMemsetAsync(v, 0, sizeof(double) * NN, S.s);
+    for (double* v : {S.d, S.x, S.r, S.y, S.atwd, S.P, S.Pt}) (void)hipMemsetAsync(v, 0, sizeof(double) * NN, S.s);
     if (!SWOK(hipMemcpy2DAsync(S.Dm, sizeof(double) * (size_t)n, D, sizeof(double) * (size_t)ldD, sizeof(double) * (size_t)n, (size_t)n,
                                hipMemcpyHostToDevice, S.s)) ||
         !SWOK(hipMemcpyAsync(S.ord, ordering, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, S.s)) ||
@@ -805,8 +1255,15 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
     bool from_below = false;
     hipLaunchKernelGGL(k_unconstrained, dim3((unsigned)((n + T - 1) / T), (unsigned)n), dim3(T), 0, S.s, S.d, S.x, n, S.ld);
     if (S.reduce_sum<RD_COUNT_NEG>(S.x, nullptr) != 0.0) {
-        from_below = !std::getenv("FNN_SW_REFERENCE_METHOD") && S.lawson_hanson();
-        if (!from_below) { S.st_lh_steps = 0; S.active_conjugate(); }
+        from_below = !std::getenv("FNN_SW_REFERENCE_METHOD") && S.block_active_set();
+        if (!from_below) {
+            S.release_block_buffers();
+            S.w = S.alloc<double>(NN); S.p = S.alloc<double>(NN); S.old_x = S.alloc<double>(NN);
+            if (!S.ok) return fnn::fail(FNN_ENOMEM, "fnn_split_weights_f64: device allocation failed");
+            for (double* v : {S.w, S.p, S.old_x}) (void)hipMemsetAsync(v, 0, sizeof(double) * NN, S.s);
+            S.st_lh_steps = 0; S.st_solves = 0;
+            S.active_conjugate();
+        }
     }
     hipLaunchKernelGGL(k_to_live, S.grid2, dim3(T), 0, S.s, S.x, S.live, n, S.ld);
     (void)hipEventRecord(e1, S.s);
@@ -824,6 +1281,7 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
         stats->cg_iterations = S.st_it;
         stats->reserved[0] = from_below ? 1 : 0;        // method: 1 = from below (Lawson-Hanson, dense factor), 0 = the reference's (or the closed form)
         stats->reserved[1] = S.st_lh_refactor;
+        stats->reserved[2] = S.st_solves;               // sub-problems solved (from below)
         stats->t_solve_s = ms * 1e-3;
         int64_t pos = 0;
         for (int64_t k = 0; k < (int64_t)n * (n - 1) / 2; k++) pos += weights_out[k] > 0.000001 ? 1 : 0;  // FastNN.java:455 threshold

@@ -24,31 +24,30 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import nnet_oracle as O  # noqa: E402
+import inputs  # noqa: E402  (tests/inputs.py: the input classes)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 JSON = os.path.join(GOLD, "oracle_big.json")
 TRAJ_FIELDS = ["m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id"]
 DEFAULT = ["4096:uniform53:1", "4096:dec4:1", "16384:uniform53:1", "32768:uniform53:1"]
-
-
-def sha_big(a: np.ndarray) -> str:
-    h = hashlib.sha256()
-    flat = a.reshape(-1).view(np.uint8)
-    step = 1 << 28
-    for o in range(0, flat.size, step):
-        h.update(flat[o:o + step].tobytes())
-    return h.hexdigest()
+# round 3: the other primary seeds of BASELINE.md section 3 and the input classes of tests/inputs.py
+ROUND3 = ["4096:uniform53:2", "4096:uniform53:3", "4096:tree:5", "4096:treenoise:6", "4096:neg:1",
+          "8192:tree:7", "8192:treenoise:8", "8192:neg:2", "16384:uniform53:2", "16384:uniform53:3"]
+sha_big = inputs.sha_big
 
 
 def main(argv):
     threads = int(os.environ.get("GOLDEN_THREADS", os.cpu_count() or 1))
     doc = json.load(open(JSON)) if os.path.exists(JSON) else {
         "generator": "oracle/nnet_oracle.c (OpenMP scan) via tests/golden/make_golden_big.py", "cases": []}
+    if argv == ["round3"]:
+        argv = ROUND3
     for spec in (argv or DEFAULT):
         n, dist, seed = spec.split(":")
         n, seed = int(n), int(seed)
-        D = O.synth(n, seed, dist)
+        D = inputs.make(n, dist, seed, O)
         t0 = time.time()
         order, ev, se = O.run(D, threads=threads)
         dt = time.time() - t0
