@@ -38,7 +38,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured copy rate
-PMC_SUMMARY = os.path.join("profiles", "r02", "pmc_screen_windows_summary_n32768.json")
+PMC_SUMMARY = os.path.join("profiles", "r03", "r03_pmc_screen_windows_summary_n32768.json")
+ISA_RESOURCES = os.path.join("profiles", "r03", "isa_resources.json")
+
+
+def source_sha256():
+    return hashlib.sha256(open(os.path.join(ROOT, "fastneighbornet_amd", "csrc", "fnn_hip.hip"), "rb").read()).hexdigest()
+
+
 KCLASS = ["k_scan", "k_screen", "k_track", "k_decide", "k_update", "k_emit", "k_resolve", "k_finalize"]
 
 
@@ -103,6 +110,33 @@ def cpu_measured_small(api, dev_index, n=4096, seed=1):
     return {"n_taxa": n, "seed": seed, "oracle_1_thread_s": round(t_one, 2), "oracle_all_cores_s": round(t_all, 2),
             "cores": cores, "engine_s": round(st.t_total_s, 4), "sum_entries": int(se),
             "orders_identical": bool((o_all == o_one).all() and (order == o_one).all())}
+
+
+def chain_kernel(st, chain, sec):
+    """A roofline-style object for k_track, the kernel that dominates the run: algorithmic bytes per launch (the tracked
+    pairs' 48-byte records + 64 B of node state each, and 16 B per swept entry: DESIGN.md section 3), its average duration
+    from the extra run with HIP events around every launch, and its ISA resources from profiles/ (quoted only when they
+    were extracted from this very source)."""
+    if not chain or "k_track" not in chain["kernels"]:
+        return None
+    k = chain["kernels"]["k_track"]
+    bytes_per_launch = (float(st.bytes_total) - float(st.scan_bytes) - float(st.plain_bytes)) / max(k["launches"], 1)
+    out = {"kernel": "fnn::k_track", "bound": "instruction stream / fan-in latency (one wave's issue rate), not HBM",
+           "launches": k["launches"], "avg_us": k["avg_us"], "share_of_kernel_time": k["share_of_kernel_time"],
+           "bytes_per_launch": round(bytes_per_launch, 1),
+           "achieved": round(bytes_per_launch / (k["avg_us"] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": round(bytes_per_launch / (k["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)}
+    try:
+        doc = json.load(open(os.path.join(ROOT, ISA_RESOURCES)))
+        if doc.get("fnn_hip_sha256") == source_sha256():
+            r = doc["kernels"]["fnn::k_track"]
+            out.update({"vgpr": r["vgpr"], "scratch_bytes_per_lane": r["scratch_bytes_per_lane"], "lds_bytes_per_block": r["lds_bytes_per_block"],
+                        "sgpr_spills": r["sgpr_spills"], "vgpr_spills": r["vgpr_spills"], "resources_from": ISA_RESOURCES})
+        else:
+            out["resources_from"] = f"{ISA_RESOURCES} is from another source (sha256 differs): not quoted"
+    except OSError:
+        out["resources_from"] = None
+    return out
 
 
 def golden_check(n, seed, order):
@@ -252,10 +286,15 @@ def main():
         k_time = st.t_scan_s if have_screen else st.t_plain_s
         k_launches = int(st.scan_launches if have_screen else st.plain_launches)
         scan_gbps = k_bytes / share / max(k_time, 1e-12) / 1e9
-        traffic = None
+        # `traffic` is a PMC figure collected in separate rocprofv3 passes (the guide's recipe) and kept under profiles/: it is
+        # quoted only while the kernels it was collected from are the ones this run executes (same sha256 of fnn_hip.hip)
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, PMC_SUMMARY)
         if n == 32768 and args.gpus == 1 and have_screen and os.path.exists(pmc):
-            traffic = round(json.load(open(pmc))["hbm_bytes_per_launch_avg"], 1)
+            doc = json.load(open(pmc))
+            if doc.get("fnn_hip_sha256") == source_sha256():
+                traffic = round(doc["hbm_bytes_per_launch_avg"], 1)
+                traffic_src = doc["fnn_hip_sha256"][:16]
         if replicas:
             head = {"metric": f"orders per second, n={n} taxa, {world} independent replicas (NOT the BASELINE metric)",
                     "value": round(world / sec, 4), "unit": "orders/s", "higher_is_better": True, "scaling": "weak"}
@@ -306,8 +345,9 @@ def main():
                 "frac": round(scan_gbps / HBM_PEAK_GBPS, 4),
                 "traffic": traffic,
                 "traffic_note": (f"HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel "
-                                 f"(FETCH_SIZE x2 per the gfx950 correction), measured this round: {PMC_SUMMARY}"
-                                 if traffic else None),
+                                 f"(FETCH_SIZE x2 per the gfx950 correction): {PMC_SUMMARY}, collected from fnn_hip.hip sha256 {traffic_src}... "
+                                 f"= the source of this run" if traffic else
+                                 "null: no PMC summary under profiles/ was collected from the kernels of this build (sha256 of fnn_hip.hip differs or the file is absent)"),
                 # the kernel this roofline describes is a small part of the run: the rest is the latency-bound event
                 # chain (see `chain`), for which seconds-to-order and us per event are the yardsticks
                 "time_share": round(k_time / max(sec, 1e-12), 4),
@@ -323,6 +363,13 @@ def main():
                                     "avg_launch_us": round(st.t_plain_s / max(st.plain_launches, 1) * 1e6, 2)},
             },
             "chain": chain,
+            # the latency-bound kernel that dominates the run (not HBM-bound: priced here only so that the line describes it)
+            "chain_kernel": chain_kernel(st, chain, sec),
+            "n_handover_retries": int(st.n_handover_retries),
+            "n_stalled_events": int(st.n_stalled_events),
+            "n_sweeps_exact": int(st.n_sweeps_exact),
+            "windows_that_could_not_certify": int(st.n_window_fails),
+            "source_sha256": {"fnn_hip.hip": source_sha256()[:16]},
         }
         try:
             g = C.c_double(0.0)

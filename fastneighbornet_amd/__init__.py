@@ -49,6 +49,7 @@ def api() -> _capi.Api:
               [_C.c_int32, _C.POINTER(_C.c_double), _C.c_int32, _C.c_int32, _C.c_int32,
                _C.POINTER(_C.c_double), _C.POINTER(_C.c_int32)])
         a._fn("comm_unique_id", _C.c_int32, [_C.POINTER(_C.c_uint8), _C.c_char_p])
+        a._fn("comm_probe", _C.c_int32, [_C.c_char_p])
         a._fn("comm_init_rccl", _C.c_int32, [_C.c_void_p, _C.c_int32, _C.c_int32, _C.POINTER(_C.c_uint8), _C.c_char_p])
         a._fn("stream_probe", _C.c_int32, [_C.c_int32, _C.c_int64, _C.c_int32, _C.POINTER(_C.c_double)])
         a._fn("split_weights_f64", _C.c_int32,

@@ -34,10 +34,15 @@
 #define FNN_HD inline
 #endif
 // post-increment of a counter shared by the threads of a launch (a plain ++ in the CPU emulation)
+// FNN_COUNTER_READ: the value of such a counter as seen by a workgroup that has observed the arrival of every
+// workgroup that adds to it: a read-modify-write of zero at agent scope, i.e. performed where the other workgroups'
+// atomic adds were performed (a plain or even an L1-bypassing load may be served from a stale line of this XCD's L2).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FNN_ATOMIC_INC(p) atomicAdd((p), 1)
+#define FNN_COUNTER_READ(p) __hip_atomic_fetch_add((p), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
 #define FNN_ATOMIC_INC(p) ((*(p))++)
+#define FNN_COUNTER_READ(p) (*(p))
 #endif
 
 namespace fnn {
@@ -217,6 +222,9 @@ struct Dev {
     int32_t rank, world;  // scan sharding: rank scans the tiles with index = rank (mod world)
     int32_t gather;       // non-zero: candidate records are exchanged between ranks (go to gsend)
     int32_t wx;           // non-zero: several ranks WITH lookahead windows - only the base scans are sharded and exchanged
+    int32_t strict;       // non-zero (several ranks): a window event that gives up for a reason other ranks cannot see - a record of
+                          // k_track's fan-in that could not be read back - is an ERROR: the ranks must take identical decisions
+    int32_t fault_event;  // test hook (FNN_FAULT_GIVEUP=rank:event, -1 = none): this rank's window gives that event up
     // Relaxed mode: NeighborNetLocal.rowPermutation (positions), and the per-call HashMap foundRowMinimums as per-slot
     // entries {stamp == n_events + 1 of the call, value, number of tied rows, their slots in position order}
     int32_t* rperm;
@@ -675,6 +683,7 @@ FNN_HD void wx_merge(const Dev& d) {
     int64_t total = 0, units = 0;
     for (int32_t r = 0; r < d.world; r++) {
         const int32_t* h = reinterpret_cast<const int32_t*>(d.wrecv + r * bb);
+        if (!st.done && h[3] != st.n_events) st.error = 12;  // a block of ANOTHER event: the ranks have taken different decisions
         if (h[0] > capr) overflow = true;
         total += h[0] < capr ? h[0] : capr;
         units += h[2];
@@ -849,7 +858,7 @@ FNN_HD void track_item(const Dev& d, int64_t item, const TrackArgs& a, Cand& bes
 FNN_HD void la_track_hit(const Dev& d, const TrackArgs& a);
 FNN_HD void la_track_done(const Dev& d, Cand best, const TrackArgs& a) {
     State& st = *d.st;
-    if (best.q <= st.la_theta_eff) {
+    if (best.q <= st.la_theta_eff && st.n_events != d.fault_event) {
         d.recs[0] = best;
         la_track_hit(d, a);
     } else {
@@ -867,7 +876,10 @@ FNN_HD void la_track_hit(const Dev& d, const TrackArgs& a) {
         st.la_items_sum += items;
         st.bytes_streamed += 32 * items;
         st.la_nf_done = a.nf;
-        const int32_t cnt = *d.lacnt;
+        // (the sweep's workgroups of THIS launch added to the counter: read it where they added, FNN_COUNTER_READ; every
+        //  append's add had returned before its workgroup's arrival was counted, so the value is complete)
+        const int32_t cnt = FNN_COUNTER_READ(d.lacnt);
+        if (cnt < st.la_np) st.error = 11;  // (the list only grows within a window: a smaller count would be a stale read)
         if (cnt > st.la_pcap) {  // the sweep found more pairs than the list can take: this
             st.la_valid = 0;             // event is served, the next one opens a new window
             st.la_k_prev = st.la_k;

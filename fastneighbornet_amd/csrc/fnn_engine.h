@@ -80,6 +80,7 @@ class Engine {
         ldh = ld;
         if (const char* e = std::getenv("FNN_LDH_PAD")) { int v = std::atoi(e); if (v >= 32 && v % 8 == 0 && v <= 65536) ldh = round_up(n > 0 ? n : 1, B::kColPad) + v; }
         dev.n = n;
+        dev.fault_event = -1;
         dev.ld = ld;
         dev.ldh = ldh;
         dev.cstride = round_up(n > 0 ? n : 1, CH_SC);
@@ -262,6 +263,12 @@ class Engine {
             be.set_relaxed(hst.rl_on ? hst.rl_min : 0);
             dev.la = hst.la_on;
             dev.wx = (comm_mode != 0 && hst.la_on) ? 1 : 0;
+            dev.strict = dev.wx;
+            dev.fault_event = -1;
+            if (const char* e = std::getenv("FNN_FAULT_GIVEUP")) {  // test hook: "rank:event"
+                int fr = -1, fe = -1;
+                if (std::sscanf(e, "%d:%d", &fr, &fe) == 2 && fr == rank) dev.fault_event = fe;
+            }
             ev_counter = 0;
             sched_at = 0;
             hst.la_pcap = LA_PCAP;
@@ -334,7 +341,7 @@ class Engine {
             // Only a BASE SCAN of the screened regime is shared out (tiles by index mod world) and followed by ONE
             // exchange: candidate records of the exact rescans + the pairs each rank emitted for the new window.
             Dev solo = dev;
-            solo.world = 1; solo.rank = 0; solo.gather = 0; solo.wx = 0;
+            solo.world = 1; solo.rank = 0; solo.gather = 0; solo.wx = 0;  // (solo.strict stays on)
             if (!sched || !be.use_screen(dev, m_bound))  // a window event, or the end game's small plain scans: no exchange
                 return be.launch_event(solo, m_bound, sched) == FNN_OK ? FNN_OK : fail(FNN_EHIP, "launch failed (" + be.err() + ")");
             if (be.launch_wx_scan(dev, m_bound) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");

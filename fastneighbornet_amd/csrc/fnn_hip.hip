@@ -8,25 +8,28 @@
 // all control state lives in device memory so the host never has to wait for a decision):
 //   k_track     lookahead windows (fnn_core.h "Lookahead"): the event's minimum from the tracked pairs
 //               + one sweep of the newest cluster's rows, exact fp64, when the open window can certify
-//               it (no scan then); workgroup 0 computes the previous event's exact u.Sx beside it
+//               it (no scan then); workgroup 0 computes the previous event's exact u.Sx beside it; the
+//               workgroup that arrives last runs the decide step (below) for a window event
 //   k_scan      all-pairs Q-criterion argmin over the lower triangle of the live
 //               m x m block (NeighborNetCanonical.java:151-178).  HBM-bound: reads
 //               each live matrix entry once, 16 B per lane, 1 KiB per wave-load.
-//   k_screen    events with >= 4096 live nodes that scan: the same scan as a bracketing pass over the
+//   k_screen    events with >= 2048 live nodes that scan: the same scan as a bracketing pass over the
 //               bf16 copy of the matrix (2 B per entry); k_emit: the pairs a new window tracks;
 //               k_resolve: exact fp64 rescan of the few 32 x 512 units that can hold the minimum
-//   k_rx_fill   reduce the per-block records, form Cx/Cy (NetMakerOriginal.java:376-380); ComputeRx
-//               terms in reference position order (:549-561) + tree partial sums
-//   k_decide4   candidate choice (:413-452) certified from the partial sums, else from the <=4
-//               exact sequential Rx sums; merge plan (:462-488)
+//   k_decide    events that scanned: reduces the per-workgroup (or all ranks') candidate records, then the
+//               decide step: Cx / Cy (NetMakerOriginal.java:376-380), the 4-candidate choice (:413-452)
+//               certified from the maintained row sums T, else from the <= 4 exact sequential ComputeRx
+//               sums (:549-561); the merge plan (:462-488) and its symbolic replay
 //   k_update    fused: subtractClusterDistance x2 per node (:455-461, 681-696), the net effect of
 //               the plan's micro-ops (agg3way row/column rewrite :653-656, slot swaps / moves)
 //               and updateClusterDistances' per-node part (:520-531); closes the event when the
 //               exact u.Sx sum is deferred to the next k_track
 //   k_finalize  exact sequential u.Sx sum (:532), event log, loop condition (:339) - stepping API and
 //               configurations without windows; k_chain_flush: a deferred sum before the host looks
-// Several GPUs: every rank scans 1/world of the tiles; the candidate records are all-gathered
-// (k_reduce_local + ncclAllGather) between the scan and k_rx_fill.
+//   k_relaxed   -mode Relaxed: the randomised search for mutual row minima (NeighborNetLocal.java:88-264)
+//   k_init, k_synth, k_unpack / k_mirror, k_validate, k_prep_screen, k_stream: set-up, ingest, probes
+// Several GPUs: every rank screens 1/world of the tiles of a base scan; the candidate records and the new
+// window's pairs are all-gathered (k_reduce_local + ncclAllGather, then k_merge) before k_decide.
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
@@ -138,7 +141,7 @@ __device__ __forceinline__ Cand block_reduce(Cand c, Cand* sh) {
 // Tiles of SCAN_TH rows x SCAN_TW columns cover the lower triangle of the live m x m block.
 // Row tiles come in bands of R = SCAN_TW / SCAN_TH; every row tile of band g owns g + 1 column
 // tiles (fnn_core.h: tri_tile_count / tri_tile_decode).  A fixed-size grid strides over the
-// linear tile index (no empty workgroups, at most gridDim.x records for k_rx_fill).
+// linear tile index (no empty workgroups, at most gridDim.x records for k_decide).
 constexpr int SCAN_R = SCAN_TW / SCAN_TH;
 
 __host__ __device__ inline int scan_tile_count(int m) { return tri_tile_count(m, SCAN_TH, SCAN_R); }
@@ -675,7 +678,7 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d) {
     const int count = cnt;
     if (count > RES_LIST) all = true;
     const int total = all ? 4 * ntiles : count;
-    // 3. exact rescans shared by all workgroups (k_rx_fill reduces the per-workgroup results)
+    // 3. exact rescans shared by all workgroups (k_decide reduces the per-workgroup results)
     {
         const int twoP = 2 * st->P;
         const double cm2 = (double)st->c - 2.0;
@@ -700,7 +703,7 @@ __global__ __launch_bounds__(1024) void k_resolve(Dev d) {
             h[0] = st->la_emit ? *d.lacnt : 0;
             h[1] = all ? 1 : 0;
             h[2] = all ? (4 * ntiles) / d.world : count;
-            h[3] = 0;
+            h[3] = st->n_events;  // the event this block belongs to: k_merge refuses blocks of different events
         } else if (blockIdx.x == 0) {
             st->rescan_all = all ? 1 : 0;
             st->ncand = all ? 0 : count;
@@ -723,7 +726,12 @@ __global__ __launch_bounds__(1024) void k_merge(Dev d) {
     const int tid = threadIdx.x;
     const int32_t capr = wx_pair_cap(d.world);
     const int64_t bb = wx_block_bytes(d.world);
-    if (tid < d.world) cnt[tid] = reinterpret_cast<const int32_t*>(d.wrecv + tid * bb)[0];
+    if (tid < d.world) {
+        cnt[tid] = reinterpret_cast<const int32_t*>(d.wrecv + tid * bb)[0];
+        // a block of ANOTHER event: the ranks have taken different decisions (must not happen: every decision is a
+        // deterministic function of identical state) - an error on every rank that sees it, never a silent divergence
+        if (!st->done && reinterpret_cast<const int32_t*>(d.wrecv + tid * bb)[3] != st->n_events) st->error = 12;
+    }
     __syncthreads();
     if (tid == 0) {
         int64_t total = 0;
@@ -2272,7 +2280,10 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     __syncthreads();
     best = sh[0];
     bestu = shu[0];
-    if (lastflag == 2) giveup = true;
+    if (lastflag == 2) {
+        giveup = true;
+        if (d.strict && threadIdx.x == 0) S.lst.error = 13;  // several ranks: a give-up the other ranks cannot see would desynchronise them
+    }
     __syncthreads();
     TRK_TICK(5);
     if (ta.approx && !giveup) {
@@ -2817,7 +2828,9 @@ struct HipBackend {
     std::string err() const { return comm_err.empty() ? std::string(hipGetErrorString(last)) : comm_err; }
 
     static void* open_rccl(const char* path, std::string& why) {
-        const char* cands[4] = {path, std::getenv("FNN_RCCL_PATH"), "librccl.so.1", "librccl.so"};
+        // an explicit path is binding (a caller that names a library must not silently get another one)
+        const char* cands[4] = {path, path && *path ? nullptr : std::getenv("FNN_RCCL_PATH"), path && *path ? nullptr : "librccl.so.1",
+                                path && *path ? nullptr : "librccl.so"};
         for (const char* c : cands) {
             if (!c || !*c) continue;
             if (void* h = dlopen(c, RTLD_NOW | RTLD_LOCAL)) return h;
@@ -3330,6 +3343,14 @@ int32_t fnn_comm_unique_id(uint8_t* id_out, const char* rccl_path) {
     int rc = get(&uid);
     if (rc != 0) return fnn::fail(FNN_ERCCL, "ncclGetUniqueId failed");
     std::memcpy(id_out, uid.internal, FNN_COMM_ID_BYTES);
+    return FNN_OK;
+}
+int32_t fnn_comm_probe(const char* rccl_path) {
+    std::string why;
+    void* lib = fnn::HipBackend::open_rccl(rccl_path, why);
+    if (!lib) return fnn::fail(FNN_ERCCL, "cannot load librccl: " + why);
+    for (const char* sym : {"ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclCommDestroy"})
+        if (!dlsym(lib, sym)) return fnn::fail(FNN_ERCCL, std::string("librccl lacks ") + sym);
     return FNN_OK;
 }
 int32_t fnn_comm_init_rccl(fnn_handle* h, int32_t world, int32_t rank, const uint8_t* id, const char* rccl_path) {

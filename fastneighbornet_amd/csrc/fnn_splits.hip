@@ -28,7 +28,6 @@
 // to the known weights of generated circular metrics up to 4096 taxa, and to the Kuhn-Tucker conditions beyond.
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
-#include <rocsolver/rocsolver.h>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -390,23 +389,62 @@ __global__ __launch_bounds__(T) void k_gather_rows(const double* W, int64_t ldw,
     if (i >= k) return;
     for (int64_t q = blockIdx.y; q < cnt; q += gridDim.y) Y[q * ldy + f0 + i] = W[(int64_t)list[q] * ldw + f0 + i];
 }
+// out (m x m, ldo) = a[idx, idx] (a: lda), the sub-block of the kept rows / columns
+__global__ __launch_bounds__(T) void k_gather_sym(const double* a, int64_t lda, const int32_t* idx, int64_t m, double* out, int64_t ldo) {
+    const int64_t r = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (r >= m) return;
+    const int64_t ri = idx[r];
+    for (int64_t c = blockIdx.y; c < m; c += gridDim.y) out[c * ldo + r] = a[(int64_t)idx[c] * lda + ri];
+}
+__global__ __launch_bounds__(T) void k_gather_vec(const double* a, const int32_t* idx, int64_t m, double* out) {
+    const int64_t r = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (r < m) out[r] = a[idx[r]];
+}
+__global__ __launch_bounds__(T) void k_gather_int2(const int2* a, const int32_t* idx, int64_t m, int2* out) {
+    const int64_t r = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (r < m) out[r] = a[idx[r]];
+}
+// out (nn x m, ldo) = a^T (a: m x nn, lda)
+__global__ __launch_bounds__(T) void k_transpose_small(const double* a, int64_t lda, int64_t m, int64_t nn, double* out, int64_t ldo) {
+    const int64_t r = (int64_t)blockIdx.x * T + threadIdx.x;  // row of a
+    if (r >= m) return;
+    for (int64_t c = blockIdx.y; c < nn; c += gridDim.y) out[r * ldo + c] = a[c * lda + r];
+}
 // copy the lower triangle of a (m x m, lda) into b (ldb), zeros above the diagonal
 __global__ __launch_bounds__(T) void k_copy_lower(const double* a, int64_t lda, double* b, int64_t ldb, int64_t m) {
     const int64_t r = (int64_t)blockIdx.x * T + threadIdx.x;
     if (r >= m) return;
     for (int64_t c = blockIdx.y; c < m; c += gridDim.y) b[c * ldb + r] = r >= c ? a[c * lda + r] : 0.0;
 }
-// in-place inverse of lower-triangular m x m blocks (m <= 64), one workgroup per block (block b at A + b stride): thread t
-// solves column t by forward substitution on an LDS copy
 constexpr int TRI_NB = 64;
-__global__ __launch_bounds__(TRI_NB) void k_trinv_small(double* A, int64_t ld, int m, int64_t stride) {
+// inverse of the Cholesky factor of a symmetric positive definite m x m block (m <= 64; lower triangle of S read):
+// Li (lower triangular, zeros above) with Li^T Li = S^-1.  One workgroup: Cholesky column by column on an LDS copy, then
+// each thread one column of the inverse by forward substitution.  A pivot that is not positive reports its (1-based,
+// offset by `off`) position through atomicMin on *info.
+__global__ __launch_bounds__(TRI_NB) void k_invchol_small(const double* S, int64_t lds, double* Li, int64_t ldl, int m, long long off, long long* info) {
     __shared__ double L[TRI_NB][TRI_NB + 1];
     __shared__ double X[TRI_NB][TRI_NB + 1];
-    double* a = A + (int64_t)blockIdx.x * stride;
+    __shared__ int bad;
     const int t = threadIdx.x;
+    if (t == 0) bad = 0;
     for (int c = 0; c < m; c++)
-        if (t < m) L[t][c] = t >= c ? a[(int64_t)c * ld + t] : 0.0;
+        if (t < m) L[t][c] = t >= c ? S[(int64_t)c * lds + t] : 0.0;
     __syncthreads();
+    for (int j = 0; j < m; j++) {
+        if (t == j) {
+            double dgl = L[j][j];
+            for (int l = 0; l < j; l++) dgl -= L[j][l] * L[j][l];
+            if (!(dgl > 0.0)) { if (!bad) { bad = 1; atomicMin(info, off + j + 1); } dgl = 1.0; }
+            L[j][j] = sqrt(dgl);
+        }
+        __syncthreads();
+        if (t > j && t < m) {
+            double v = L[t][j];
+            for (int l = 0; l < j; l++) v -= L[t][l] * L[j][l];
+            L[t][j] = v / L[j][j];
+        }
+        __syncthreads();
+    }
     if (t < m) {
         for (int i = 0; i < m; i++) {
             double v = 0.0;
@@ -420,7 +458,7 @@ __global__ __launch_bounds__(TRI_NB) void k_trinv_small(double* A, int64_t ld, i
     }
     __syncthreads();
     for (int c = 0; c < m; c++)
-        if (t < m) a[(int64_t)c * ld + t] = X[t][c];
+        if (t < m) Li[(int64_t)c * ldl + t] = X[t][c];
 }
 // local maxima of the multiplier on the (i, j) grid: entry (i, j), i < j, not masked, w > tol, and no unmasked neighbour
 // within `rad` (Chebyshev) is larger in the order (w, index).  Winners are appended to the candidate list.
@@ -673,28 +711,30 @@ struct Solver {
     }
 
     // ------------------------------------------------------------ block active-set method (see the comment above h_entry)
-    int64_t st_lh_steps = 0, st_lh_refactor = 0, st_solves = 0, st_adds = 0, st_dels = 0, st_rejects = 0, st_ratio_steps = 0;
+    int64_t st_lh_steps = 0, st_lh_refactor = 0, st_solves = 0, st_adds = 0, st_dels = 0, st_rejects = 0, st_ratio_steps = 0, st_screened = 0;
     double t_ops = 0, t_sel = 0, t_append = 0, t_solve = 0, t_dead = 0, t_refactor = 0;  // host wall clock per phase (FNN_SW_LOG)
     struct Blk {
         rocblas_handle bh = nullptr;
         int64_t cap = 0, kmax = 0, rcap = 0, f = 0, r = 0;
-        double *W = nullptr, *B = nullptr, *Tb = nullptr, *X = nullptr, *S = nullptr, *S0 = nullptr, *Li = nullptr, *tmp = nullptr;
-        double *Y = nullptr, *CR = nullptr, *LC = nullptr, *CRb = nullptr;
+        double *W = nullptr, *B = nullptr, *Tb = nullptr, *X = nullptr, *S = nullptr, *S0 = nullptr, *Li = nullptr, *tmp2 = nullptr;
+        double *Y = nullptr, *CR = nullptr, *LC = nullptr, *CRb = nullptr, *CRw = nullptr;
         double *z = nullptr, *v = nullptr, *xs = nullptr, *cK = nullptr, *lam = nullptr, *gF = nullptr;
         int2 *dF = nullptr, *dscr = nullptr;
-        int32_t* dlist = nullptr;
+        int32_t *dlist = nullptr, *dlist2 = nullptr;
+        double *wk = nullptr, *sk1 = nullptr, *sk2 = nullptr;
         int64_t* dinfo = nullptr;
         double* ckey = nullptr; double* ckey2 = nullptr; int64_t* cidx = nullptr; int64_t* cidx2 = nullptr;
         unsigned long long* ccount = nullptr; void* sort_tmp = nullptr; size_t sort_bytes = 0; int64_t ccap = 0;
-        int64_t tmp_elems = 0;
     } bk;
     bool blas_ok = true;
+    double gemm_flops = 0.0;
     static int64_t up64(int64_t v) { return (v + 63) / 64 * 64; }
     static dim3 g1(int64_t c) { return dim3((unsigned)((c + T - 1) / T)); }
     static dim3 g2(int64_t rows, int64_t cols) { return dim3((unsigned)((rows + T - 1) / T), (unsigned)std::max<int64_t>(1, std::min<int64_t>(cols, 16384))); }
     void gemm(rocblas_operation ta, rocblas_operation tb, int64_t m, int64_t nn, int64_t k, double alpha, const double* A, int64_t lda, const double* Bm,
               int64_t ldb, double beta, double* Cm, int64_t ldc) {
         if (m <= 0 || nn <= 0) return;
+        gemm_flops += 2.0 * (double)m * (double)nn * (double)k;
         if (rocblas_dgemm_64(bk.bh, ta, tb, m, nn, k, &alpha, A, lda, Bm, ldb, &beta, Cm, ldc) != rocblas_status_success) blas_ok = false;
     }
     void gemv(rocblas_operation ta, int64_t m, int64_t nn, double alpha, const double* A, int64_t lda, const double* xv, double beta, double* yv) {
@@ -755,38 +795,36 @@ struct Solver {
         }
         hipLaunchKernelGGL(k_sum_parts, g2(m, nn), dim3(T), 0, s, bk.X, m * nn, np, m, nn, alpha, beta, Cm, ldc);
     }
-    // in-place inverse of a lower-triangular matrix (zeros above the diagonal), recursive halves, GEMMs only:
-    // inv [[A, 0], [C, B]] = [[A^-1, 0], [-B^-1 C A^-1, B^-1]]; the two products run in chunks through bk.tmp
-    void trtri(double* A, int64_t m, int64_t ld) {
-        if (m <= TRI_NB) { hipLaunchKernelGGL(k_trinv_small, dim3(1), dim3(TRI_NB), 0, s, A, ld, (int)m, (int64_t)0); return; }
+    // Li = inverse of the Cholesky factor of S (m x m, lower triangle read, destroyed), zeros above the diagonal: recursive halves,
+    // GEMMs and the in-LDS kernel for blocks of <= 64.  Everything is enqueued; a block that is not positive definite leaves the
+    // 1-based position of its first bad pivot in *bk.dinfo (read it with invchol_info() after the call).
+    void invchol_rec(double* S, int64_t lds, double* Li, int64_t ldl, int64_t m, int64_t off) {
+        if (m <= TRI_NB) {
+            hipLaunchKernelGGL(k_invchol_small, dim3(1), dim3(TRI_NB), 0, s, S, lds, Li, ldl, (int)m, (long long)off, (long long*)bk.dinfo);
+            return;
+        }
         const int64_t m1 = std::min(m - 1, up64((m + 1) / 2)), m2 = m - m1;
-        double *A11 = A, *A21 = A + m1, *A22 = A + m1 + m1 * ld;
-        trtri(A11, m1, ld);
-        trtri(A22, m2, ld);
-        // C <- C A11^-1: column chunk [j0, j1) needs the columns >= j0 of C (not yet overwritten)
-        const int64_t cb = std::max<int64_t>(64, std::min<int64_t>(m1, bk.tmp_elems / std::max<int64_t>(m2, 1)));
-        for (int64_t j0 = 0; j0 < m1; j0 += cb) {
-            const int64_t j1 = std::min(m1, j0 + cb);
-            gemm(rocblas_operation_none, rocblas_operation_none, m2, j1 - j0, m1 - j0, 1.0, A21 + j0 * ld, ld, A11 + j0 + j0 * ld, ld, 0.0, bk.tmp, m2);
-            (void)hipMemcpy2DAsync(A21 + j0 * ld, sizeof(double) * (size_t)ld, bk.tmp, sizeof(double) * (size_t)m2, sizeof(double) * (size_t)m2,
-                                   (size_t)(j1 - j0), hipMemcpyDeviceToDevice, s);
-        }
-        // C <- -A22^-1 C: row chunk [i0, i1), from the bottom up, needs the rows <= i1 of C (not yet overwritten)
-        const int64_t rb = std::max<int64_t>(64, std::min<int64_t>(m2, bk.tmp_elems / std::max<int64_t>(m1, 1)));
-        for (int64_t i1 = m2; i1 > 0; i1 -= std::min(rb, i1)) {
-            const int64_t i0 = i1 - std::min(rb, i1);
-            gemm(rocblas_operation_none, rocblas_operation_none, i1 - i0, m1, i1, -1.0, A22 + i0, ld, A21, ld, 0.0, bk.tmp, i1 - i0);
-            (void)hipMemcpy2DAsync(A21 + i0, sizeof(double) * (size_t)ld, bk.tmp, sizeof(double) * (size_t)(i1 - i0), sizeof(double) * (size_t)(i1 - i0),
-                                   (size_t)m1, hipMemcpyDeviceToDevice, s);
-        }
+        double *S21 = S + m1, *S22 = S + m1 + m1 * lds, *Li21 = Li + m1, *Li22 = Li + m1 + m1 * ldl;
+        double *t1 = bk.tmp2, *t2 = bk.tmp2 + m2 * m1;
+        invchol_rec(S, lds, Li, ldl, m1, off);
+        gemm(rocblas_operation_none, rocblas_operation_transpose, m2, m1, m1, 1.0, S21, lds, Li, ldl, 0.0, t1, m2);           // L21 = S21 Li11^T
+        const double mone = -1.0, one = 1.0;
+        if (rocblas_dsyrk_64(bk.bh, rocblas_fill_lower, rocblas_operation_none, m2, m1, &mone, t1, m2, &one, S22, lds) != rocblas_status_success) blas_ok = false;
+        gemm(rocblas_operation_none, rocblas_operation_none, m2, m1, m1, 1.0, t1, m2, Li, ldl, 0.0, t2, m2);                    // L21 Li11
+        invchol_rec(S22, lds, Li22, ldl, m2, off + m1);
+        gemm(rocblas_operation_none, rocblas_operation_none, m2, m1, m2, -1.0, Li22, ldl, t2, m2, 0.0, Li21, ldl);              // Li21 = -Li22 L21 Li11
+        (void)hipMemset2DAsync(Li + m1 * ldl, sizeof(double) * (size_t)ldl, 0, sizeof(double) * (size_t)m1, (size_t)m2);
     }
-    int64_t potrf(double* A, int64_t m, int64_t ld) {  // lower Cholesky in place; 0, or the order of the leading minor that is not positive definite; -1: call failed
+    int64_t invchol(double* S, int64_t lds, double* Li, int64_t ldl, int64_t m) {  // 0, or the 1-based position of the first pivot that is not positive
         if (m <= 0) return 0;
-        if (rocsolver_dpotrf_64(bk.bh, rocblas_fill_lower, m, A, ld, bk.dinfo) != rocblas_status_success) { blas_ok = false; return -1; }
+        const int64_t big = INT64_MAX;
+        (void)hipMemcpyAsync(bk.dinfo, &big, sizeof(big), hipMemcpyHostToDevice, s);
+        (void)hipStreamSynchronize(s);
+        invchol_rec(S, lds, Li, ldl, m, 0);
         int64_t info = 0;
         (void)hipMemcpyAsync(&info, bk.dinfo, sizeof(info), hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
-        return info;
+        return info == INT64_MAX ? 0 : info;
     }
     double wall() { (void)hipStreamSynchronize(s); return fnn::now_s(); }
     std::map<std::string, double> tsub;  // finer split of the phases (FNN_SW_LOG)
@@ -818,13 +856,13 @@ struct Solver {
         b.W = alloc<double>((size_t)b.cap * b.cap);
         b.B = alloc<double>((size_t)b.cap * b.kmax); b.Tb = alloc<double>((size_t)b.cap * b.kmax); b.X = alloc<double>((size_t)b.cap * b.kmax);
         b.S = alloc<double>((size_t)b.kmax * b.kmax); b.S0 = alloc<double>((size_t)b.kmax * b.kmax); b.Li = alloc<double>((size_t)b.kmax * b.kmax);
-        b.tmp_elems = std::max<int64_t>((int64_t)b.cap * 2048, 1 << 20);
-        b.tmp = alloc<double>((size_t)b.tmp_elems);
+        b.tmp2 = alloc<double>((size_t)(std::max(b.rcap, b.kmax) * std::max(b.rcap, b.kmax) / 2 + 4096));
         b.Y = alloc<double>((size_t)b.cap * b.rcap);
-        b.CR = alloc<double>((size_t)b.rcap * b.rcap); b.LC = alloc<double>((size_t)b.rcap * b.rcap); b.CRb = alloc<double>((size_t)b.rcap * b.rcap);
+        b.CR = alloc<double>((size_t)b.rcap * b.rcap); b.LC = alloc<double>((size_t)b.rcap * b.rcap); b.CRb = alloc<double>((size_t)b.rcap * b.rcap); b.CRw = alloc<double>((size_t)b.rcap * b.rcap);
         b.z = alloc<double>((size_t)b.cap); b.v = alloc<double>((size_t)b.cap); b.xs = alloc<double>((size_t)b.cap); b.cK = alloc<double>((size_t)b.cap);
         b.lam = alloc<double>((size_t)b.rcap); b.gF = alloc<double>((size_t)b.cap);
-        b.dF = alloc<int2>((size_t)b.cap); b.dscr = alloc<int2>((size_t)b.cap); b.dlist = alloc<int32_t>((size_t)b.cap); b.dinfo = alloc<int64_t>(1);
+        b.dF = alloc<int2>((size_t)b.cap); b.dscr = alloc<int2>((size_t)b.cap); b.dlist = alloc<int32_t>((size_t)b.cap); b.dlist2 = alloc<int32_t>((size_t)b.cap);
+        b.wk = alloc<double>((size_t)b.cap); b.sk1 = alloc<double>((size_t)b.cap); b.sk2 = alloc<double>((size_t)b.cap); b.dinfo = alloc<int64_t>(1);
         b.ccap = std::min<int64_t>(N, std::max<int64_t>(1 << 16, N / 16 + 1024));
         b.ckey = alloc<double>((size_t)b.ccap); b.ckey2 = alloc<double>((size_t)b.ccap);
         b.cidx = alloc<int64_t>((size_t)b.ccap); b.cidx2 = alloc<int64_t>((size_t)b.ccap);
@@ -858,16 +896,119 @@ struct Solver {
             hipLaunchKernelGGL(k_mask, g1((int64_t)list.size()), dim3(T), 0, s, b.dscr, (int64_t)list.size(), act, ld, v);
             (void)hipStreamSynchronize(s);
         };
-        // LC = Cholesky factor of the Gram matrix CR of the departed columns
+        // LC = inverse of the Cholesky factor of the Gram matrix CR of the departed columns (lower triangular), from scratch
         auto factor_gram = [&]() -> bool {
             if (b.r == 0) return true;
-            hipLaunchKernelGGL(k_copy_lower, g2(b.r, b.r), dim3(T), 0, s, b.CR, b.rcap, b.LC, b.rcap, b.r);
-            return potrf(b.LC, b.r, b.rcap) == 0;
+            hipLaunchKernelGGL(k_copy_lower, g2(b.r, b.r), dim3(T), 0, s, b.CR, b.rcap, b.CRw, b.rcap, b.r);
+            return invchol(b.CRw, b.rcap, b.LC, b.rcap, b.r) == 0;
         };
-        // rebuild the factor from the closed form for the splits that are still in
+        // The core of an append, shared by the factor W (rows for splits that enter) and by LC (rows for columns that depart).
+        // phase 1: T = Wi Bc, S = S - T^T T for a lower-triangular inverse factor Wi (f x f); phase 2: rows f .. f + k of Wi
+        // from T, the Cholesky factor's inverse Li of S:  [-Li T^T Wi | Li], zeros above.
+        auto rows_phase1 = [&](const double* Wi, int64_t ldw, int64_t f, const double* Bc, int64_t ldb, int64_t k, double* Tm, int64_t ldt, double* Sm, int64_t lds) {
+            if (f == 0) return;
+            tri_times(Wi, ldw, f, Bc, ldb, k, Tm, ldt);
+            tn_splitk(k, k, f, -1.0, Tm, ldt, Tm, ldt, 1.0, Sm, lds);
+        };
+        auto rows_phase2 = [&](double* Wi, int64_t ldw, int64_t f, const double* Tm, int64_t ldt, const double* Lim, int64_t ldl, int64_t k) {
+            if (f > 0) {
+                t_times_tri(Tm, ldt, k, Wi, ldw, f, b.X, b.kmax);                                                              // X = T^T Wi
+                gemm(rocblas_operation_none, rocblas_operation_none, k, f, k, -1.0, Lim, ldl, b.X, b.kmax, 0.0, Wi + f, ldw);    // new rows -Li X
+                (void)hipMemset2DAsync(Wi + f * ldw, sizeof(double) * (size_t)ldw, 0, sizeof(double) * (size_t)f, (size_t)k);  // zeros above them
+            }
+            (void)hipMemcpy2DAsync(Wi + f + f * ldw, sizeof(double) * (size_t)ldw, Lim, sizeof(double) * (size_t)ldl, sizeof(double) * (size_t)k, (size_t)k,
+                                   hipMemcpyDeviceToDevice, s);
+        };
+        // append the k splits at b.dF[f .. f + k) with multipliers wK (device, may be null: no screening).  Screening: the block's
+        // weights in the joint sub-problem are S^-1 w_K with S the block's Schur complement - known before the rows are formed;
+        // splits whose weight would not be positive are dropped here, at half the price and without ever entering the factor.
+        // `kept` receives the indices (into the block) of the splits that entered; returns their number, -1 on failure.
+        auto append = [&](int64_t k, const double* wK, std::vector<int32_t>& kept) -> int64_t {
+            const double t0 = log ? wall() : 0.0;
+            const int64_t f = b.f;
+            int2* dK = b.dF + f;
+            kept.resize((size_t)k);
+            for (int64_t q = 0; q < k; q++) kept[(size_t)q] = (int32_t)q;
+            lap(nullptr);
+            hipLaunchKernelGGL(k_hblock, g2(k, k), dim3(T), 0, s, dK, k, dK, k, n, b.S, b.kmax, 0);
+            if (f > 0) hipLaunchKernelGGL(k_hblock, g2(f, k), dim3(T), 0, s, b.dF, f, dK, k, n, b.B, b.cap, 0);
+            lap("append.hblock");
+            rows_phase1(b.W, b.cap, f, b.B, b.cap, k, b.Tb, b.cap, b.S, b.kmax);  // T = L^-1 B = L21^T, S = H_KK - L21 L21^T
+            lap("append.W*B+syrk");
+            (void)hipMemcpy2DAsync(b.S0, sizeof(double) * (size_t)b.kmax, b.S, sizeof(double) * (size_t)b.kmax, sizeof(double) * (size_t)k, (size_t)k,
+                                   hipMemcpyDeviceToDevice, s);
+            const double* wcur = wK;
+            std::vector<double> sK;
+            bool changed = false;
+            for (int round = 0;; round++) {
+                const int64_t kk = (int64_t)kept.size();
+                const int64_t info = invchol(b.S, b.kmax, b.Li, b.kmax, kk);  // Li = L22^-1
+                if (info > 0) {  // not positive definite at split `info`: the block ends in front of it
+                    kept.resize((size_t)(info - 1)); changed = true;
+                    if (kept.empty()) return 0;
+                    (void)hipMemcpyAsync(b.dlist2, kept.data(), sizeof(int32_t) * kept.size(), hipMemcpyHostToDevice, s);
+                    hipLaunchKernelGGL(k_gather_sym, g2((int64_t)kept.size(), (int64_t)kept.size()), dim3(T), 0, s, b.S0, b.kmax, b.dlist2, (int64_t)kept.size(), b.S, b.kmax);
+                    if (wK) { hipLaunchKernelGGL(k_gather_vec, g1((int64_t)kept.size()), dim3(T), 0, s, wK, b.dlist2, (int64_t)kept.size(), b.wk); wcur = b.wk; }
+                    (void)hipStreamSynchronize(s);
+                    continue;
+                }
+                if (!wK || round >= 12) break;
+                // the block's weights in the joint sub-problem: S^-1 w_K = Li^T (Li w_K)
+                gemv(rocblas_operation_none, kk, kk, 1.0, b.Li, b.kmax, wcur, 0.0, b.sk1);
+                gemv(rocblas_operation_transpose, kk, kk, 1.0, b.Li, b.kmax, b.sk1, 0.0, b.sk2);
+                sK.resize((size_t)kk);
+                (void)hipMemcpyAsync(sK.data(), b.sk2, sizeof(double) * (size_t)kk, hipMemcpyDeviceToHost, s);
+                (void)hipStreamSynchronize(s);
+                std::vector<int32_t> nk;
+                for (int64_t q = 0; q < kk; q++) if (sK[(size_t)q] > 0.0) nk.push_back(kept[(size_t)q]);
+                if ((int64_t)nk.size() == kk) break;
+                st_screened += kk - (int64_t)nk.size();
+                if (nk.empty()) nk.push_back(kept[0]);  // (a single split with a positive multiplier always gets a positive weight)
+                kept.swap(nk); changed = true;
+                (void)hipMemcpyAsync(b.dlist2, kept.data(), sizeof(int32_t) * kept.size(), hipMemcpyHostToDevice, s);
+                hipLaunchKernelGGL(k_gather_sym, g2((int64_t)kept.size(), (int64_t)kept.size()), dim3(T), 0, s, b.S0, b.kmax, b.dlist2, (int64_t)kept.size(), b.S, b.kmax);
+                hipLaunchKernelGGL(k_gather_vec, g1((int64_t)kept.size()), dim3(T), 0, s, wK, b.dlist2, (int64_t)kept.size(), b.wk);
+                wcur = b.wk;
+                (void)hipStreamSynchronize(s);
+            }
+            lap("append.potrf+trtri+screen");
+            k = (int64_t)kept.size();
+            const double* Tuse = b.Tb;
+            if (changed) {  // T's columns and the split list follow the kept ones (b.B is free now)
+                (void)hipMemcpyAsync(b.dlist2, kept.data(), sizeof(int32_t) * kept.size(), hipMemcpyHostToDevice, s);
+                if (f > 0) { hipLaunchKernelGGL(k_gather_cols, g2(f, k), dim3(T), 0, s, b.Tb, b.cap, f, b.dlist2, k, b.B, b.cap); Tuse = b.B; }
+                hipLaunchKernelGGL(k_gather_int2, g1(k), dim3(T), 0, s, dK, b.dlist2, k, b.dscr);
+                (void)hipMemcpyAsync(dK, b.dscr, sizeof(int2) * (size_t)k, hipMemcpyDeviceToDevice, s);
+                (void)hipStreamSynchronize(s);
+            }
+            hipLaunchKernelGGL(k_gather, g1(k), dim3(T), 0, s, dK, k, atwd, ld, b.cK);
+            rows_phase2(b.W, b.cap, f, Tuse, b.cap, b.Li, b.kmax, k);
+            if (f > 0) gemv(rocblas_operation_transpose, f, k, -1.0, Tuse, b.cap, b.z, 1.0, b.cK);  // c_K - L21 z
+            gemv(rocblas_operation_none, k, k, 1.0, b.Li, b.kmax, b.cK, 0.0, b.z + f);                // z_K = L22^-1 (c_K - L21 z)
+            lap("append.rows");
+            if (b.r > 0) {  // the departed columns grow by the new rows; so does their Gram matrix
+                hipLaunchKernelGGL(k_gather_rows, g2(k, b.r), dim3(T), 0, s, b.W, b.cap, f, k, b.dlist, b.r, b.Y, b.cap);
+                const double one = 1.0;
+                if (rocblas_dsyrk_64(b.bh, rocblas_fill_lower, rocblas_operation_transpose, b.r, k, &one, b.Y + f, b.cap, &one, b.CR, b.rcap) != rocblas_status_success)
+                    blas_ok = false;
+                if (!factor_gram()) return -1;
+                lap("append.gram");
+            }
+            b.f = f + k;
+            if (log) t_append += wall() - t0;
+            return blas_ok ? k : -1;
+        };
+        // rebuild the factor from H's closed form for the splits that are still in: the compacted list appended in blocks
         auto refactor = [&]() -> bool {
             const double t0 = log ? wall() : 0.0;
             st_lh_refactor++;
+            if (log) {  // where in the factor did the departed splits sit?
+                std::vector<double> pos;
+                for (size_t p = 0; p < F.size(); p++) if (dead[p]) pos.push_back((double)p / (double)F.size());
+                if (!pos.empty())
+                    std::fprintf(stderr, "  [sw] rebuild at %zu with %zu departed; their positions: 10%% %.2f 25%% %.2f 50%% %.2f 75%% %.2f\n", F.size(), pos.size(),
+                                 pos[pos.size() / 10], pos[pos.size() / 4], pos[pos.size() / 2], pos[pos.size() * 3 / 4]);
+            }
             std::vector<int2> gone;
             size_t q = 0;
             for (size_t p = 0; p < F.size(); p++) {
@@ -876,83 +1017,19 @@ struct Solver {
             }
             F.resize(q); xw.resize(q); cF.resize(q); dead.assign(q, 0); deadlist.clear();
             set_mask(gone, 0);  // they may enter again
-            b.f = (int64_t)q; b.r = 0;
-            if (b.f == 0) return true;
-            upload_F(0, b.f);
-            lap(nullptr);
-            hipLaunchKernelGGL(k_hblock, g2(b.f, b.f), dim3(T), 0, s, b.dF, b.f, b.dF, b.f, n, b.W, b.cap, 1);
-            lap("refactor.hblock");
-            if (potrf(b.W, b.f, b.cap) != 0) return false;
-            lap("refactor.potrf");
-            trtri(b.W, b.f, b.cap);
-            lap("refactor.trtri");
-            (void)hipMemcpyAsync(b.cK, cF.data(), sizeof(double) * (size_t)b.f, hipMemcpyHostToDevice, s);
-            const int64_t pb = panel(b.f);
-            for (int64_t p0 = 0; p0 < b.f; p0 += pb) {  // z = W c_F
-                const int64_t p1 = std::min(b.f, p0 + pb);
-                gemv(rocblas_operation_none, p1 - p0, p1, 1.0, b.W + p0, b.cap, b.cK, 0.0, b.z + p0);
+            b.f = 0; b.r = 0;
+            if (q == 0) return true;
+            upload_F(0, (int64_t)q);
+            std::vector<int32_t> kept;
+            while (b.f < (int64_t)q) {
+                const int64_t k = std::min<int64_t>(b.kmax, (int64_t)q - b.f);
+                if (append(k, nullptr, kept) != k) return false;
             }
             (void)hipStreamSynchronize(s);
-            if (log) t_refactor += wall() - t0;
+            if (log) { const double dt = wall() - t0; t_refactor += dt; t_append -= dt; }
             return blas_ok;
         };
-        // append the k splits at b.dF[f .. f + k); returns the number that entered (a block whose Schur complement is
-        // not positive definite is cut in front of the offending split), -1 on failure
-        auto append = [&](int64_t k) -> int64_t {
-            const double t0 = log ? wall() : 0.0;
-            const int64_t f = b.f;
-            const int2* dK = b.dF + f;
-            lap(nullptr);
-            hipLaunchKernelGGL(k_hblock, g2(k, k), dim3(T), 0, s, dK, k, dK, k, n, b.S, b.kmax, 0);
-            if (f > 0) {
-                hipLaunchKernelGGL(k_hblock, g2(f, k), dim3(T), 0, s, b.dF, f, dK, k, n, b.B, b.cap, 0);
-                lap("append.hblock");
-                tri_times(b.W, b.cap, f, b.B, b.cap, k, b.Tb, b.cap);  // T = L^-1 B = L21^T
-                lap("append.W*B");
-                tn_splitk(k, k, f, -1.0, b.Tb, b.cap, b.Tb, b.cap, 1.0, b.S, b.kmax);  // S = H_KK - L21 L21^T
-            }
-            lap("append.syrk");
-            (void)hipMemcpy2DAsync(b.S0, sizeof(double) * (size_t)b.kmax, b.S, sizeof(double) * (size_t)b.kmax, sizeof(double) * (size_t)k, (size_t)k,
-                                   hipMemcpyDeviceToDevice, s);
-            const int64_t info = potrf(b.S, k, b.kmax);
-            lap("append.potrf");
-            if (info < 0) return -1;
-            if (info > 0) {
-                k = info - 1;
-                if (k == 0) return 0;
-                (void)hipMemcpy2DAsync(b.S, sizeof(double) * (size_t)b.kmax, b.S0, sizeof(double) * (size_t)b.kmax, sizeof(double) * (size_t)k, (size_t)k,
-                                       hipMemcpyDeviceToDevice, s);
-                if (potrf(b.S, k, b.kmax) != 0) return -1;
-            }
-            hipLaunchKernelGGL(k_copy_lower, g2(k, k), dim3(T), 0, s, b.S, b.kmax, b.Li, b.kmax, k);
-            trtri(b.Li, k, b.kmax);  // L22^-1
-            lap("append.trtri");
-            hipLaunchKernelGGL(k_gather, g1(k), dim3(T), 0, s, dK, k, atwd, ld, b.cK);
-            if (f > 0) {
-                t_times_tri(b.Tb, b.cap, k, b.W, b.cap, f, b.X, b.kmax);                                                            // X = L21 W
-                lap("append.T'*W");
-                gemm(rocblas_operation_none, rocblas_operation_none, k, f, k, -1.0, b.Li, b.kmax, b.X, b.kmax, 0.0, b.W + f, b.cap);  // new rows -L22^-1 X
-                (void)hipMemset2DAsync(b.W + f * b.cap, sizeof(double) * (size_t)b.cap, 0, sizeof(double) * (size_t)f, (size_t)k);     // zeros above them
-                gemv(rocblas_operation_transpose, f, k, -1.0, b.Tb, b.cap, b.z, 1.0, b.cK);                                           // c_K - L21 z
-            }
-            (void)hipMemcpy2DAsync(b.W + f + f * b.cap, sizeof(double) * (size_t)b.cap, b.Li, sizeof(double) * (size_t)b.kmax, sizeof(double) * (size_t)k,
-                                   (size_t)k, hipMemcpyDeviceToDevice, s);
-            gemv(rocblas_operation_none, k, k, 1.0, b.Li, b.kmax, b.cK, 0.0, b.z + f);  // z_K = L22^-1 (c_K - L21 z)
-            lap("append.rows");
-            if (b.r > 0) {  // the departed columns grow by the new rows; so does their Gram matrix
-                hipLaunchKernelGGL(k_gather_rows, g2(k, b.r), dim3(T), 0, s, b.W, b.cap, f, k, b.dlist, b.r, b.Y, b.cap);
-                const double one = 1.0;
-                if (rocblas_dsyrk_64(b.bh, rocblas_fill_lower, rocblas_operation_transpose, b.r, k, &one, b.Y + f, b.cap, &one, b.CR, b.rcap) != rocblas_status_success)
-                    blas_ok = false;
-                lap("append.gram_syrk");
-                if (!factor_gram()) return -1;
-                lap("append.gram_potrf");
-            }
-            b.f = f + k;
-            if (log) t_append += wall() - t0;
-            return blas_ok ? k : -1;
-        };
-        // the splits at the factor positions `idxs` leave: their columns join Y, the Gram matrix grows
+        // the splits at the factor positions `idxs` leave: their columns join Y, the Gram matrix and its factor grow
         auto depart = [&](const std::vector<int32_t>& idxs) -> bool {
             const double t0 = log ? wall() : 0.0;
             const int64_t nn = (int64_t)idxs.size(), r = b.r, f = b.f;
@@ -962,11 +1039,22 @@ struct Solver {
             // CR[r : r + nn, 0 : r + nn] = YN^T [Y, YN]
             tn_splitk(nn, r + nn, f, 1.0, b.Y + r * b.cap, b.cap, b.Y, b.cap, 0.0, b.CR + r, b.rcap);
             (void)hipStreamSynchronize(s);  // (idxs may be a temporary)
-            lap("depart.gather+gram_gemm");
+            lap("depart.gather+gram");
             for (int32_t p : idxs) { dead[(size_t)p] = 1; xw[(size_t)p] = 0.0; deadlist.push_back(p); }
-            b.r = r + nn;
-            const bool fine = factor_gram();
-            lap("depart.gram_potrf");
+            bool fine = true;
+            if (r == 0 || nn > b.kmax) { b.r = r + nn; fine = factor_gram(); }
+            else {  // border the inverse factor: cross block CR[r:, 0:r]^T, diagonal block CR[r:, r:]
+                hipLaunchKernelGGL(k_transpose_small, g2(nn, r), dim3(T), 0, s, b.CR + r, b.rcap, nn, r, b.B, b.cap);  // (r x nn)
+                (void)hipMemcpy2DAsync(b.S, sizeof(double) * (size_t)b.kmax, b.CR + r + r * b.rcap, sizeof(double) * (size_t)b.rcap, sizeof(double) * (size_t)nn,
+                                       (size_t)nn, hipMemcpyDeviceToDevice, s);
+                rows_phase1(b.LC, b.rcap, r, b.B, b.cap, nn, b.Tb, b.cap, b.S, b.kmax);
+                if (invchol(b.S, b.kmax, b.Li, b.kmax, nn) != 0) { b.r = r + nn; fine = factor_gram(); }
+                else {
+                    rows_phase2(b.LC, b.rcap, r, b.Tb, b.cap, b.Li, b.kmax, nn);
+                    b.r = r + nn;
+                }
+            }
+            lap("depart.gram_factor");
             if (log) t_dead += wall() - t0;
             return fine && blas_ok;
         };
@@ -980,7 +1068,8 @@ struct Solver {
             const double* vv = b.z;
             if (r > 0) {
                 gemv(rocblas_operation_transpose, f, r, 1.0, b.Y, b.cap, b.z, 0.0, b.lam);
-                if (rocsolver_dpotrs_64(b.bh, rocblas_fill_lower, r, 1, b.LC, b.rcap, b.lam, b.rcap) != rocblas_status_success) blas_ok = false;
+                gemv(rocblas_operation_none, r, r, 1.0, b.LC, b.rcap, b.lam, 0.0, b.sk1);       // (Y^T Y)^-1 = LC^T LC
+                gemv(rocblas_operation_transpose, r, r, 1.0, b.LC, b.rcap, b.sk1, 0.0, b.lam);
                 (void)hipMemcpyAsync(b.v, b.z, sizeof(double) * (size_t)f, hipMemcpyDeviceToDevice, s);
                 gemv(rocblas_operation_none, f, r, -1.0, b.Y, b.cap, b.lam, 1.0, b.v);
                 vv = b.v;
@@ -1079,13 +1168,15 @@ struct Solver {
             const std::vector<int32_t> deadlist0 = deadlist;
             if (r0 > 0) (void)hipMemcpy2DAsync(b.CRb, sizeof(double) * (size_t)b.rcap, b.CR, sizeof(double) * (size_t)b.rcap, sizeof(double) * (size_t)r0, (size_t)r0,
                                                hipMemcpyDeviceToDevice, s);
-            const int64_t kin = append(k);
+            std::vector<int32_t> kept;
+            const int64_t kin = append(k, b.ckey2, kept);
             if (kin < 0) { good = false; break; }
             if (kin == 0) {  // the first split is numerically dependent on the factor: set it aside until progress is made
                 F.resize((size_t)f0);
                 banned.push_back(first); set_mask({first}, 1);
                 continue;
             }
+            for (int64_t q = 0; q < kin; q++) F[(size_t)(f0 + q)] = F[(size_t)(f0 + kept[(size_t)q])];
             F.resize((size_t)(f0 + kin));
             hipLaunchKernelGGL(k_mask, g1(kin), dim3(T), 0, s, b.dF + f0, kin, act, ld, (uint8_t)1);
             st_adds += kin;
@@ -1161,10 +1252,11 @@ struct Solver {
             }
             (void)hipStreamSynchronize(s);
         }
-        if (log) std::fprintf(stderr, "  [sw] %s: %lld steps, %lld solves, %lld entered, %lld left, %lld taken back, %lld ratio steps, %lld factorisations; |F| = %lld | ops %.2f "
+        if (log) std::fprintf(stderr, "  [sw] %s: %lld steps, %lld solves, %lld entered (%lld screened out before), %lld left, %lld taken back, %lld ratio steps, %lld factorisations; |F| = %lld | ops %.2f "
                               "sel %.2f append %.2f solve %.2f depart %.2f refactor %.2f s\n", good ? "done" : "gave up", (long long)st_lh_steps, (long long)st_solves,
-                              (long long)st_adds, (long long)st_dels, (long long)st_rejects, (long long)st_ratio_steps, (long long)st_lh_refactor, (long long)(b.f - b.r),
+                              (long long)st_adds, (long long)st_screened, (long long)st_dels, (long long)st_rejects, (long long)st_ratio_steps, (long long)st_lh_refactor, (long long)(b.f - b.r),
                               t_ops, t_sel, t_append, t_solve, t_dead, t_refactor);
+        if (log) std::fprintf(stderr, "  [sw]   GEMM work through gemm(): %.3e flop\n", gemm_flops);
         if (log) for (const auto& kv : tsub) std::fprintf(stderr, "  [sw]   %-28s %8.3f s\n", kv.first.c_str(), kv.second);
         return good;
     }

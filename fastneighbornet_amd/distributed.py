@@ -4,7 +4,7 @@ ONE problem on all ranks: every rank keeps the whole matrix and runs the whole e
 because every decision is a deterministic function of identical state).  With lookahead windows - the shipped mode
 from 4096 taxa on - only the base scans are sharded (tile index mod world) and each is followed by ONE all-gather
 (RCCL on the engine's stream): per rank 64 candidate records of 24 bytes plus the tracked-pair records it emitted,
-a fixed block of 16 + 1536 + 16 * 65536 / world bytes.  Without windows every event's scan is sharded and exchanges
+a fixed block of 16 + 1536 + 48 * 65536 / world bytes (48-byte tracked-pair records).  Without windows every event's scan is sharded and exchanges
 at most 64 candidate records per rank.  See include/fastnn.h.
 """
 from __future__ import annotations
@@ -32,43 +32,44 @@ def rccl_path() -> str | None:
     return None
 
 
-def init_rccl(handle, dist, device) -> None:
-    """Collective over the default process group: rank 0 creates the RCCL id, everybody joins.
+def bootstrap_rccl(dist, device):
+    """The collective part of the RCCL bootstrap that needs no engine handle: returns (id bytes, library path).
 
-    Symmetric by construction: every rank performs the same collectives in the same order whatever fails
-    where - (1) broadcast of {status, id} from rank 0, (2) all-reduce of "my library loaded and has the
-    symbols", and only if every rank is fine (3) ncclCommInitRank - so a failure on one rank surfaces as
-    an exception on ALL ranks instead of a hang."""
+    Symmetric by construction: every rank performs the same collectives in the same order whatever fails where -
+    (1) every rank probes its librccl (dlopen + symbol check: no call into the library, nothing to tear down) and rank 0
+    also creates the id; (2) ONE all-gather of {ok, reason} - so a failure on any rank is an exception on ALL ranks,
+    naming the rank and its reason, instead of a hang; (3) broadcast of the id from rank 0."""
     import ctypes as C
 
     import torch
 
     from . import api
     a = api()
-    world, rank = dist.get_world_size(), dist.get_rank()
-    path = rccl_path()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    path = os.environ.get("FNN_RCCL_PATH") or rccl_path()
     buf = (C.c_uint8 * 128)()
-    status, why = 1, ""
-    if rank == 0:
-        try:
+    ok_local, why = 1, ""
+    try:
+        a.check(a.comm_probe(path.encode() if path else None))
+        if rank == 0:
             a.check(a.comm_unique_id(buf, path.encode() if path else None))
-        except Exception as e:  # noqa: BLE001 - reported through the broadcast below
-            status, why = 0, str(e)
-    t = torch.tensor([status] + list(bytes(buf)), dtype=torch.uint8, device=device)
+    except Exception as e:  # noqa: BLE001 - reported through the all-gather below
+        ok_local, why = 0, str(e)
+    reports = [None] * world
+    dist.all_gather_object(reports, (ok_local, why))
+    bad = [(r, w) for r, (o, w) in enumerate(reports) if not o]
+    if bad:
+        raise RuntimeError("RCCL bootstrap failed on rank " + "; rank ".join(f"{r}: {w}" for r, w in bad))
+    t = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device=device)
     dist.broadcast(t, src=0)
-    host = t.cpu().tolist()
-    ok_local = 1 if host[0] == 1 else 0
-    if ok_local:
-        try:  # can this rank load librccl at all?  (dlopen + symbol check, no communicator yet)
-            probe = (C.c_uint8 * 128)()
-            a.check(a.comm_unique_id(probe, path.encode() if path else None))
-        except Exception as e:  # noqa: BLE001
-            ok_local, why = 0, str(e)
-    flag = torch.tensor([ok_local], dtype=torch.int32, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) != 1:
-        raise RuntimeError(f"RCCL bootstrap failed on at least one rank ({why or 'on another rank'})")
-    handle.comm_init_rccl(world, rank, bytes(host[1:]), path)
+    return bytes(t.cpu().tolist()), path
+
+
+def init_rccl(handle, dist, device) -> None:
+    """Collective over the default process group: rank 0 creates the RCCL id, everybody joins (bootstrap_rccl, then
+    ncclCommInitRank on every rank)."""
+    uid, path = bootstrap_rccl(dist, device)
+    handle.comm_init_rccl(dist.get_world_size(), dist.get_rank(), uid, path)
 
 
 def init_gloo(handle, dist) -> None:

@@ -219,7 +219,7 @@ int32_t fnn_canonical_order_f64(const double* D, int32_t n, int64_t ld, const fn
  * returns the same order.  What is shared out:
  *   - with lookahead windows (a screening copy exists: n >= 4096, lookahead not off): only the BASE SCANS of the
  *     windows, by screening-tile index mod world; each is followed by ONE all-gather of a fixed block per rank -
- *     16 B header + 64 candidate records of 24 B + 65536 / world tracked-pair records of 16 B - after which every
+ *     16 B header + 64 candidate records of 24 B + 65536 / world tracked-pair records of 48 B - after which every
  *     rank builds the same tracked list and reduces the same candidate records;
  *   - without windows: the scan of every event, by tile index mod world, with one all-gather of <= 64 candidate
  *     records (24 B each) per rank and event.
@@ -234,6 +234,9 @@ int32_t fnn_canonical_order_f64(const double* D, int32_t n, int64_t ld, const fn
 #define FNN_COMM_ID_BYTES 128
 typedef int32_t (*fnn_allgather_fn)(void* ctx, const void* send, void* recv, int32_t bytes_per_rank);
 int32_t fnn_comm_unique_id(uint8_t* id_out, const char* rccl_path);
+/* Can this process load librccl (dlopen + the four symbols the engine uses)?  No call is made into the library: no
+ * bootstrap listener is started, nothing needs tearing down.  FNN_OK or FNN_ERCCL with fnn_last_error(). */
+int32_t fnn_comm_probe(const char* rccl_path);
 int32_t fnn_comm_init_rccl(fnn_handle* h, int32_t world, int32_t rank, const uint8_t* id, const char* rccl_path);
 int32_t fnn_comm_init_host(fnn_handle* h, int32_t world, int32_t rank, fnn_allgather_fn fn, void* ctx);
 

@@ -217,7 +217,7 @@ struct EmuBackend {
         }
         if (d.wx) {  // the base scan is closed after the exchange (wx_merge)
             int32_t* h = reinterpret_cast<int32_t*>(d.wsend);
-            h[0] = st.la_emit ? *d.lacnt : 0; h[1] = st.rescan_all; h[2] = (int32_t)rescanned; h[3] = 0;
+            h[0] = st.la_emit ? *d.lacnt : 0; h[1] = st.rescan_all; h[2] = (int32_t)rescanned; h[3] = st.n_events;
             fnn::Cand* recs = reinterpret_cast<fnn::Cand*>(d.wsend + fnn::wx_recs_off());
             for (int j = 0; j < fnn::GATHER_RECS; j++) recs[j] = fnn::cand_none();
             recs[(d.rank * 7 + 3) % fnn::GATHER_RECS] = best;  // (any of the records may carry it)

@@ -17,6 +17,17 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     from fastneighbornet_amd import distributed as fd
     from fastneighbornet_amd._capi import Handle
+    if backend == "bootstrap":  # the symmetric RCCL bootstrap alone (no device needed): every rank must raise if any rank cannot load the library
+        import torch
+        try:
+            fd.bootstrap_rccl(dist, torch.device("cpu"))
+            res = {"raised": False}
+        except RuntimeError as e:
+            res = {"raised": True, "message": str(e)}
+        json.dump(res, open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     from oracle import nnet_oracle as O
     if backend == "emu":
         import ctypes as C

@@ -13,11 +13,21 @@ import os
 import numpy as np
 import pytest
 
+import inputs
 from common import check_order
 from fastneighbornet_amd._capi import Handle
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRAJ_FIELDS = ["m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind", "u_id"]
+
+
+# BASELINE.md section 3's primary seeds 1-3, the 4-decimal generator, and (round 3) the input classes of tests/inputs.py:
+# additive tree metrics with exact ties of the Q criterion everywhere, tree + noise, matrices with negative entries (for
+# which the engine keeps screening every event: the windows' monotonicity argument needs non-negative entries)
+BIG_CASES = [(4096, "uniform53", 1), (4096, "dec4", 1), (16384, "uniform53", 1), (32768, "uniform53", 1),
+             (4096, "uniform53", 2), (4096, "uniform53", 3), (4096, "tree", 5), (4096, "treenoise", 6), (4096, "neg", 1),
+             (8192, "tree", 7), (8192, "treenoise", 8), (8192, "neg", 2), (16384, "uniform53", 2), (16384, "uniform53", 3)]
+
 
 
 def cases():
@@ -28,7 +38,7 @@ def cases():
 def test_big_golden_fixtures_are_consistent():
     """(CPU) every npz matches the hashes recorded next to it; the three BASELINE sizes are present."""
     cs = cases()
-    for key in [(4096, "uniform53", 1), (4096, "dec4", 1), (16384, "uniform53", 1), (32768, "uniform53", 1)]:
+    for key in BIG_CASES:
         assert key in cs, f"golden for {key} missing: run tests/golden/make_golden_big.py"
     for (n, dist, seed), c in cs.items():
         z = np.load(os.path.join(GOLD, c["npz"]))
@@ -62,15 +72,20 @@ def test_small_oracle_run_matches_its_big_golden(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,dist,seed", [(4096, "uniform53", 1), (4096, "dec4", 1), (16384, "uniform53", 1),
-                                         (32768, "uniform53", 1)])
-def test_default_mode_matches_oracle_golden(hip_api, n, dist, seed):
+@pytest.mark.parametrize("n,dist,seed", BIG_CASES)
+def test_default_mode_matches_oracle_golden(hip_api, oracle, n, dist, seed):
     if (n, dist, seed) not in cases():
         pytest.skip("golden not generated yet (tests/golden/make_golden_big.py)")
     c = cases()[(n, dist, seed)]
     z = np.load(os.path.join(GOLD, c["npz"]))
     with Handle(hip_api, n, record_events=True) as h:
-        h.synth(seed, dist)
+        if dist in inputs.DEVICE_DISTS:
+            h.synth(seed, dist)
+        else:  # host-generated class: the matrix must be the one the golden was made from
+            D = inputs.make(n, dist, seed, oracle)
+            assert inputs.sha_big(D) == c["matrix_sha256"], "the input generator drifted from the committed golden"
+            h.set_matrix(D)
+            del D
         order, st = h.run()
         ev = h.events()
     traj = np.stack([ev[f] for f in TRAJ_FIELDS], axis=1)
@@ -84,8 +99,10 @@ def test_default_mode_matches_oracle_golden(hip_api, n, dist, seed):
     assert hashlib.sha256(order.tobytes()).hexdigest() == c["order_sha256"]
     assert hashlib.sha256(np.ascontiguousarray(traj).tobytes()).hexdigest() == c["trajectory_sha256"]
     assert hashlib.sha256(best.tobytes()).hexdigest() == c["best_bits_sha256"]
-    if n >= 4096:
+    if dist == "neg":
+        assert st.n_window_hits == 0, "windows must stay off on a matrix with negative entries"
+    else:
         assert st.n_base_scans > 0 and st.n_window_hits > 0, "the shipped mode (lookahead windows) did not run"
-        if st.n_handover_retries:  # (results are right either way - the trajectory was compared above; worth knowing)
-            import warnings
-            warnings.warn(f"{st.n_handover_retries} window events reread the records of k_track's fan-in (DESIGN.md section 3)")
+    # the write-through hand-over of k_track's fan-in is measured behaviour of the part: a reread means
+    # that form failed here and its cause has to be found, even though the result above is right
+    assert st.n_handover_retries == 0, f"{st.n_handover_retries} window events reread the records of k_track's fan-in"

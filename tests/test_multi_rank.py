@@ -64,6 +64,49 @@ def test_emulation_over_gloo_modes(emu_api, oracle, tmp_path, world, n, seed, en
     check(res, oracle, n, seed, "uniform53")
 
 
+def test_a_give_up_on_one_rank_is_an_error_on_all_ranks(emu_api, tmp_path):
+    """Several ranks with windows rely on identical decisions everywhere.  A window event that ONE rank gives up (on the GPU:
+    a record of k_track's fan-in that could not be read back; here injected, FNN_FAULT_GIVEUP=rank:event) makes that rank
+    scan and exchange at an event where the others do not: the exchange blocks carry their event number, and a block
+    of another event is an error on every rank - never a silently different order, never a hang."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29893", WORLD_SIZE="2", FNN_FAULT_GIVEUP="1:40")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), "emu", "300", "4", "uniform53", str(tmp_path)],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("the ranks hang after a one-sided give-up")
+        outs.append(o)
+    assert all(p.returncode != 0 for p in procs), outs
+    assert all("code 12" in o for o in outs), outs
+
+
+def test_rccl_bootstrap_fails_on_every_rank_when_one_rank_cannot_load_the_library(tmp_path):
+    """distributed.bootstrap_rccl is symmetric: rank 1 is pointed at a library that does not exist; BOTH ranks must raise,
+    and the message must name rank 1 (no rank may go on to ncclCommInitRank and hang there)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29877", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        if r == 1:
+            e["FNN_RCCL_PATH"] = "/nonexistent/librccl.so"
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), "bootstrap", "0", "0", "-", str(tmp_path)],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        o, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, o
+    res = [json.load(open(os.path.join(str(tmp_path), f"rank{r}.json"))) for r in range(2)]
+    assert all(r["raised"] for r in res), res
+    assert all("rank 1" in r["message"] and "/nonexistent/librccl.so" in r["message"] for r in res), res
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,n,seed,dist_name,screen", [(2, 600, 1, "uniform53", False), (3, 300, 2, "dec4", False),
                                                         (2, 1500, 3, "uniform53", True), (3, 700, 4, "dec4", True)])

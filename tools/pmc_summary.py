@@ -6,7 +6,9 @@ Corrections follow MI355X_MICROARCH.md (HBM): FETCH_SIZE / WRITE_SIZE are in KiB
 FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so
 the read side is doubled; WRITE_SIZE is exact for streaming stores."""
 import csv
+import hashlib
 import json
+import os
 import sys
 
 
@@ -46,6 +48,9 @@ def main():
         "algorithmic_bytes_per_launch_avg": algo_total / max(n, 1),
         "traffic_over_algorithmic": (fetch_b + write_b) / algo_total if algo_total else None,
         "first_launch_read_bytes": fetch[0] * 2048.0 if fetch else None,
+        # the kernels these counters were collected from: bench.py quotes `traffic` only while this still is the source it runs
+        "fnn_hip_sha256": hashlib.sha256(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fastneighbornet_amd", "csrc",
+                                                           "fnn_hip.hip"), "rb").read()).hexdigest(),
     }
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
