@@ -711,7 +711,7 @@ struct Solver {
     }
 
     // ------------------------------------------------------------ block active-set method (see the comment above h_entry)
-    int64_t st_lh_steps = 0, st_lh_refactor = 0, st_solves = 0, st_adds = 0, st_dels = 0, st_rejects = 0, st_ratio_steps = 0, st_screened = 0;
+    int64_t st_lh_steps = 0, st_lh_refactor = 0, st_solves = 0, st_adds = 0, st_dels = 0, st_rejects = 0, st_ratio_steps = 0, st_screened = 0, st_dead_wanting = 0;
     double t_ops = 0, t_sel = 0, t_append = 0, t_solve = 0, t_dead = 0, t_refactor = 0;  // host wall clock per phase (FNN_SW_LOG)
     struct Blk {
         rocblas_handle bh = nullptr;
@@ -841,7 +841,7 @@ struct Solver {
         const bool log = std::getenv("FNN_SW_LOG") != nullptr;
         lap_on = log;
         auto envd = [](const char* k, double dflt) { const char* e = std::getenv(k); return e ? std::atof(e) : dflt; };
-        const double kfrac = envd("FNN_SW_KFRAC", 0.10), rfrac = envd("FNN_SW_RFRAC", 0.15);
+        const double kfrac = envd("FNN_SW_KFRAC", 0.20), rfrac = envd("FNN_SW_RFRAC", 0.15);
         const int rad = (int)envd("FNN_SW_NMS", 3);
         const int64_t N = (int64_t)n * (n - 1) / 2;
         Blk& b = bk;
@@ -1135,10 +1135,12 @@ struct Solver {
             const int64_t ncand = (int64_t)std::min<unsigned long long>(ncand64, (unsigned long long)b.ccap);
             // (gF holds A^T A x at the factor's splits: c - gF is the multiplier of a split that left, the drift at one that is in)
             double drift = 0.0, wdead = 0.0;
+            int64_t dead_wanting = 0;
             for (size_t p = 0; p < (size_t)b.f; p++) {
                 const double g = cF[p] - gF[p];
-                if (dead[p]) wdead = std::max(wdead, g); else drift = std::max(drift, std::fabs(g));
+                if (dead[p]) { wdead = std::max(wdead, g); dead_wanting += g > tol ? 1 : 0; } else drift = std::max(drift, std::fabs(g));
             }
+            st_dead_wanting += dead_wanting;
             const int64_t nlive = b.f - b.r;
             int64_t k = (int64_t)std::min<double>((double)b.kmax, std::max<double>((double)kmin, kfrac * (double)std::max<int64_t>(nlive, 1)));
             k = std::max<int64_t>(1, std::min<int64_t>({k, ncand, k_limit}));
@@ -1256,7 +1258,8 @@ struct Solver {
                               "sel %.2f append %.2f solve %.2f depart %.2f refactor %.2f s\n", good ? "done" : "gave up", (long long)st_lh_steps, (long long)st_solves,
                               (long long)st_adds, (long long)st_screened, (long long)st_dels, (long long)st_rejects, (long long)st_ratio_steps, (long long)st_lh_refactor, (long long)(b.f - b.r),
                               t_ops, t_sel, t_append, t_solve, t_dead, t_refactor);
-        if (log) std::fprintf(stderr, "  [sw]   GEMM work through gemm(): %.3e flop\n", gemm_flops);
+        if (log) std::fprintf(stderr, "  [sw]   GEMM work through gemm(): %.3e flop; departed splits with a positive multiplier, summed over the steps: %lld\n", gemm_flops,
+                              (long long)st_dead_wanting);
         if (log) for (const auto& kv : tsub) std::fprintf(stderr, "  [sw]   %-28s %8.3f s\n", kv.first.c_str(), kv.second);
         return good;
     }
