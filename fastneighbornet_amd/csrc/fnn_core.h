@@ -193,7 +193,8 @@ struct Dev {
     int32_t* sid;    // per slot: NetNode.id
     int32_t* spos;   // per slot: NetNode.positionID
     int32_t* pslot;  // reference position -> slot (-1 if empty)
-    double* chain;   // 4 buffers of cstride doubles, addressed through chain_addr(position)
+    double* chain;   // 5 buffers of cstride doubles, addressed through chain_addr(position): [0] the addends of the new cluster's row sum
+                     // (consumed by the NEXT event's k_track while that event may already fill [1..4], the <= 4 ComputeRx sums of its own decision)
     int64_t cstride; // n rounded up to a whole super-chunk
     Cand* recs;      // per-block scan records
     uint64_t* rchk;  // k_track's fan-in: a check word per record (2 x 1024), see rec_publish
@@ -1158,7 +1159,7 @@ FNN_HD void rx_fill_thread(const Dev& d, int32_t s, int32_t m, int32_t twoP, con
     for (int k = 0; k < 4; k++) {
         if (z[k] < 0) continue;
         double v = d.D[(int64_t)z[k] * d.ld + s];
-        d.chain[(int64_t)k * d.cstride + chain_addr(pos)] = full ? v : v / 2.0;
+        d.chain[(int64_t)(k + 1) * d.cstride + chain_addr(pos)] = full ? v : v / 2.0;
     }
 }
 

@@ -93,7 +93,7 @@ class Engine {
             !(dev.sid = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
             !(dev.spos = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
             !(dev.pslot = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
-            !(dev.chain = (double*)be.alloc(sizeof(double) * 4 * (size_t)dev.cstride)) ||
+            !(dev.chain = (double*)be.alloc(sizeof(double) * 5 * (size_t)dev.cstride)) ||
             !(dev.recs = (Cand*)be.alloc(sizeof(Cand) * be.max_records(n))) ||
             !(dev.rchk = (uint64_t*)be.alloc(sizeof(uint64_t) * 2048)) ||
             !(dev.T = (double*)be.alloc(sizeof(double) * (nn + 8))) ||

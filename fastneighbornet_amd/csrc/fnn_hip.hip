@@ -1615,7 +1615,7 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
 #pragma unroll
         for (int b = 0; b < 4; b++) {
             double r = 0.0;
-            if (z[b] >= 0) r = block_chain_sum_rare<CH_EPT>(d.chain + (size_t)b * d.cstride, m_old, CH_GUARD_BITS, &L, nullptr);
+            if (z[b] >= 0) r = block_chain_sum_rare<CH_EPT>(d.chain + (size_t)(b + 1) * d.cstride, m_old, CH_GUARD_BITS, &L, nullptr);  // (buffer 0 belongs to the pending row sum)
             if (tid == 0) S.rx[b] = r;
             __syncthreads();
         }

@@ -81,3 +81,19 @@ def tree_metric(n, seed):
                     break
                 dj += blen[v]
     return D
+
+
+def live_to_fast(n, live):
+    """Split weights in the live path's index order (FastNN.java:405-419) -> the fast algorithm's packed upper triangle
+    (SURVEY.md App. D), one vector operation per row (the element-wise form is tests/test_split_weights.py: fast_x)."""
+    x = np.zeros(n * (n - 1) // 2)
+    k = 0
+    for i in range(n - 1):
+        j = np.arange(i + 1, n, dtype=np.int64)
+        if i >= 1:
+            fi, fj = i - 1, j - 1
+        else:
+            fi, fj = j - 1, n - 1
+        x[(2 * n - fi - 3) * fi // 2 + fj - 1] = live[k:k + len(j)]
+        k += len(j)
+    return x

@@ -375,7 +375,7 @@ struct EmuBackend {
                 else {  // the exact sequential sums (ComputeRx, NetMakerOriginal.java:549-561)
                     const int32_t z[4] = {st.sa, st.sap, st.sb, st.sbp};
                     for (int32_t t : thread_order(st.m_old)) fnn::rx_fill_thread(d, t, st.m_old, 2 * st.P_old, z);
-                    for (int k = 0; k < 4; k++) rx[k] = z[k] >= 0 ? fnn::chain_sum(d.chain + (int64_t)k * d.cstride, st.m_old) : 0.0;
+                    for (int k = 0; k < 4; k++) rx[k] = z[k] >= 0 ? fnn::chain_sum(d.chain + (int64_t)(k + 1) * d.cstride, st.m_old) : 0.0;
                     st.n_rx_exact++;
                 }
             }

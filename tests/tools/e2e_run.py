@@ -16,22 +16,8 @@ import numpy as np
 import fastneighbornet_amd as fa
 from oracle import csw_oracle as W
 from oracle import nnet_oracle as O
-
-
-def live_to_fast(n, live):
-    """live index order (FastNN.java:405-419) -> the fast algorithm's packed upper triangle, vectorised"""
-    x = np.zeros(W.npairs(n))
-    k = 0
-    for i in range(n - 1):
-        j = np.arange(i + 1, n, dtype=np.int64)
-        if i >= 1:
-            fi, fj = i - 1, j - 1
-            x[(2 * n - fi - 3) * fi // 2 + fj - 1] = live[k:k + len(j)]
-        else:
-            fi, fj = j - 1, n - 1
-            x[(2 * n - fi - 3) * fi // 2 + fj - 1] = live[k:k + len(j)]
-        k += len(j)
-    return x
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from common import live_to_fast  # noqa: E402
 
 
 def kkt_violation(D, order, live):

@@ -9,7 +9,7 @@ from scipy.ndimage import maximum_filter
 from block_nnls import At_mul, A_mul, Hblock, O
 
 
-DELPOS = []; DELAGE = []
+DELPOS = []; DELAGE = []; SMAX = [int(os.environ.get('SMAX', 0))]
 class Factor:
     def __init__(self, n, c):
         self.n = n; self.c = c
@@ -76,7 +76,11 @@ def solve(n, seed=1, kfrac=0.1, kmin=8, nms=3, rfrac=0.2, verbose=True):
         wm = w.copy(); wm[lower] = -np.inf
         wdead = wm[fac.F[fac.dead, 0], fac.F[fac.dead, 1]] if fac.dead.any() else np.zeros(0)
         wm[fac.F[:, 0], fac.F[:, 1]] = -np.inf
+        if SMAX[0]:
+            ii, jj = np.indices((n, n)); szm = np.minimum(jj - ii, n - (jj - ii)); wm = np.where(szm <= SMAX[0], wm, -np.inf)
         pos = wm > tol
+        if not pos.any() and SMAX[0]:
+            print(f'  phase with splits of size <= {SMAX[0]} done at outer {outer}: live {int((~fac.dead).sum())} adds {adds} dels {dels}'); SMAX[0] = SMAX[0] * 4 if SMAX[0] * 4 < n // 2 else 0; continue
         if not pos.any():
             if (wdead > tol).any():
                 born = born[~fac.dead]; fac.refactor(); x = fac.solve(); continue
