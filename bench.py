@@ -139,6 +139,27 @@ def chain_kernel(st, chain, sec):
     return out
 
 
+def amdahl(chain, sec, n_ranks):
+    if not chain:
+        return None
+    k = chain["kernels"]
+    shard = sum(k[c]["launches"] * k[c]["avg_us"] for c in ("k_screen", "k_emit", "k_resolve") if c in k) * 1e-6
+    ex = chain.get("exchange")
+    per_exchange = ((ex["allgather_us_avg"] + ex["merge_us_avg"]) * 1e-6) if ex else None
+    # (this run's sharded kernels already ran on 1 / n_ranks of the tiles)
+    out = {"sharded_kernel_seconds_of_this_run": round(shard, 4), "ranks_of_this_run": n_ranks}
+    serial = sec - shard - (ex["allgather_calls"] * per_exchange if ex else 0.0)
+    full = shard * n_ranks
+    for n in (1, 2, 4, 8):
+        t = serial + full / n
+        if n > 1:
+            t += (ex["allgather_calls"] if ex else k.get("k_screen", {"launches": 0})["launches"]) * (per_exchange if per_exchange else 40e-6)
+        out[f"n{n}"] = round(t, 4)
+    out["note"] = ("serial part + sharded part / N + exchanges x (all-gather + merge); the exchange cost is this run's measurement when N > 1, "
+                   "else assumed 40 us (RCCL small-message latency over xGMI has not been measured on this pool)")
+    return out
+
+
 def golden_check(n, seed, order):
     """The order against the oracle's golden for this (n, seed), generated in the build container."""
     try:
@@ -259,6 +280,9 @@ def main():
         api.get_kernel_times(h._h, ms, cnt)
         api.set_scan_timing(h._h, 1)
         tot = sum(ms)
+        xms = (C.c_double * 2)()
+        xcnt = (C.c_int64 * 2)()
+        api.get_exchange_times(h._h, xms, xcnt)
         chain = {
             "note": ("an extra, untimed run with HIP events around every launch (slower than the timed run by the event "
                      "records); a window event = k_track (tracked pairs + sweep, the exact row sum of the previous "
@@ -267,6 +291,9 @@ def main():
             "run_s_with_event_records": round(st2.t_total_s, 4),
             "kernels": {KCLASS[c]: {"launches": int(cnt[c]), "avg_us": round(ms[c] * 1e3 / cnt[c], 2),
                                     "share_of_kernel_time": round(ms[c] / tot, 4)} for c in range(8) if cnt[c] > 0},
+            # several ranks: the one collective of the path (all-gather after a sharded base scan) and the merge behind it
+            "exchange": ({"allgather_calls": int(xcnt[0]), "allgather_us_avg": round(xms[0] * 1e3 / xcnt[0], 2),
+                          "merge_us_avg": round(xms[1] * 1e3 / max(xcnt[1], 1), 2)} if xcnt[0] > 0 else None),
         }
     if dist is not None:
         dist.barrier()
@@ -363,6 +390,9 @@ def main():
                                     "avg_launch_us": round(st.t_plain_s / max(st.plain_launches, 1) * 1e6, 2)},
             },
             "chain": chain,
+            # what N ranks can gain at best (Amdahl): only the base scans' kernels (k_screen, k_emit, k_resolve) are sharded; every
+            # exchange adds its all-gather + merge.  From this run's own per-kernel times; the curve is flat by construction.
+            "expected_amdahl_s": amdahl(chain, sec, args.gpus if sharded else 1),
             # the latency-bound kernel that dominates the run (not HBM-bound: priced here only so that the line describes it)
             "chain_kernel": chain_kernel(st, chain, sec),
             "n_handover_retries": int(st.n_handover_retries),

@@ -42,6 +42,7 @@ def api() -> _capi.Api:
         a._fn("set_matrix_device", _C.c_int32, [_C.c_void_p, _C.c_void_p, _C.c_int64])
         a._fn("set_scan_timing", _C.c_int32, [_C.c_void_p, _C.c_int32])
         a._fn("get_kernel_times", _C.c_int32, [_C.c_void_p, _C.POINTER(_C.c_double), _C.POINTER(_C.c_int64)])
+        a._fn("get_exchange_times", _C.c_int32, [_C.c_void_p, _C.POINTER(_C.c_double), _C.POINTER(_C.c_int64)])
         a._fn("canonical_order_f64", _C.c_int32,
               [_C.POINTER(_C.c_double), _C.c_int32, _C.c_int64, _C.POINTER(_capi.FnnOpts),
                _C.POINTER(_C.c_int32), _C.POINTER(_capi.FnnStats)])

@@ -9,6 +9,7 @@
 #define FNN_ENGINE_H
 
 #include <chrono>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -54,6 +55,7 @@ class Engine {
     int32_t batch = 64;    // events enqueued between host round trips in run()
     int64_t ev_counter = 0;  // events enqueued since begin(): drives the schedule of the lookahead windows' base scans
     int64_t sched_at = 0;    // event count at which the host expects the open window to have served its K events
+    bool state_seen = false; // the host has read the device state since begin() (nonneg / screen_ok are the prep kernel's verdict)
     // several GPUs: 0 = single, 1 = RCCL all-gather on the stream, 2 = host callback (tests)
     int32_t comm_mode = 0, world = 1, rank = 0;
     fnn_allgather_fn host_fn = nullptr;
@@ -286,6 +288,21 @@ class Engine {
                 return fail(FNN_EHIP, "fnn_begin: bf16 copy failed (" + be.err() + ")");
             if (be.launch_init(dev) != FNN_OK || be.sync() != FNN_OK)
                 return fail(FNN_EHIP, "fnn_begin: init failed (" + be.err() + ")");
+            // the prep kernel's verdict on the matrix (nonneg, screen_ok, max |D|): the schedule of the scans depends on it
+            const int32_t rcp = pull_state();
+            if (rcp != FNN_OK) return rcp;
+            state_seen = true;
+            be.screen_off = false;
+            // A matrix with a negative entry (or one the bf16 bound does not cover) can open no window, and its mixed-sign
+            // brackets admit so many candidate units that the screened scan costs more than the plain one (measured, round 3:
+            // 3.9 ms per event at 32768 taxa against 0.4 ms): such a run takes the plain fp64 scan for every event.
+            // (FNN_SCREEN_MIN_N / FNN_SCREEN_MIN_M - the tests' way to force the screening pass on - keep it.)
+            if (dev.H && (!hst.nonneg || !hst.screen_ok) && !B::kKeepGenericScreen && !std::getenv("FNN_SCREEN_MIN_N") && !std::getenv("FNN_SCREEN_MIN_M")) {
+                hst.la_on = 0;
+                dev.la = 0; dev.wx = 0; dev.strict = 0;
+                be.screen_off = true;
+                if (be.h2d(dev.st, &hst, sizeof(State)) != FNN_OK) return fail(FNN_EHIP, "fnn_begin: state upload failed (" + be.err() + ")");
+            }
         }
         m_bound = n;
         have_matrix = false;  // consumed
@@ -331,7 +348,11 @@ class Engine {
         // one knows the previous minimum) and then every la_K events; in between a scan only runs
         // if the window fails, which the device finds out by itself
         const int64_t cnt = ev_counter++;
-        bool sched = !dev.la || cnt <= 1 || cnt >= sched_at;
+        // (a matrix with a negative entry, or one the bf16 bound does not cover, can never open a window - la_prepare_base -: every
+        //  event scans, and the host must SCHEDULE that scan; left to the window schedule such a run stalled 63 of 64 launch
+        //  sequences: 310 s instead of 3 s at 16384 taxa, found with the round-3 input classes)
+        const bool no_windows = dev.la && state_seen && (!hst.nonneg || !hst.screen_ok);
+        bool sched = !dev.la || no_windows || cnt <= 1 || cnt >= sched_at;
         if (force_sched >= 0) sched = force_sched != 0;
         if (sched) sched_at = cnt + (hst.la_Kcur > 0 ? hst.la_Kcur : hst.la_K) + 1;
         if (comm_mode == 0) return be.launch_event(dev, m_bound, sched) == FNN_OK ? FNN_OK : fail(FNN_EHIP, "launch failed (" + be.err() + ")");

@@ -2675,12 +2675,33 @@ __global__ __launch_bounds__(CH_T) void k_chain_flush(Dev d) {
 }
 
 // ------------------------------------------------------------------ k_finalize
+// The sequential sum as the reference writes it, for matrices with negative entries: the parallel forms (fnn_chain.h) rest on
+// non-negative addends (a running sum that only grows) and fall back to ordinary additions piece by piece otherwise - 260 us
+// per sum at 8192 taxa.  Here the addends are staged through LDS in position order, 8192 at a time, and ONE lane adds them
+// (the loads do not depend on the sum, the additions do: ~8 cycles each).  Valid in thread 0.
+constexpr int SER_CHUNK = 8192;
+__device__ __forceinline__ double serial_chain_sum(const double* buf, int m, double* ser) {
+    double s = 0.0;
+    for (int base = 0; base < m; base += SER_CHUNK) {
+        const int cnt = m - base < SER_CHUNK ? m - base : SER_CHUNK;
+        for (int i = threadIdx.x; i < cnt; i += CH_T) ser[i] = buf[chain_addr(base + i)];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll 8
+            for (int i = 0; i < cnt; i++) s += ser[i];
+        }
+        __syncthreads();
+    }
+    return s;
+}
+
 __global__ __launch_bounds__(CH_T) void k_finalize(Dev d) {
     __shared__ ChainLds<CH_EPT> L;
+    __shared__ double ser[SER_CHUNK];
     State* st = d.st;
     if (!st->ev_active || st->stall) return;
     double usx = 0.0;
-    if (!st->ev_finish) usx = block_chain_sum2<CH_EPT>(d.chain, st->m, CH_GUARD_BITS, L, nullptr);
+    if (!st->ev_finish) usx = st->nonneg ? block_chain_sum2<CH_EPT>(d.chain, st->m, CH_GUARD_BITS, L, nullptr) : serial_chain_sum(d.chain, st->m, ser);
     if (threadIdx.x == 0) finalize(d, usx);
 }
 
@@ -2797,8 +2818,8 @@ struct HipBackend {
     // HIP-event timing of launches: 0 off, 1 the streaming scan kernels (bench.py's roofline figure), 2 every kernel of the
     // launch sequences (bench.py's `chain` object, an extra untimed run)
     int timing = 0;
-    double class_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // by kernel class: TC_*
-    int64_t class_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double class_ms[16] = {0};   // by kernel class: TC_*
+    int64_t class_n[16] = {0};
     std::vector<hipEvent_t> ev_pool;
     std::vector<char> ev_kind;   // per event pair: 1 = screening pass (k_screen), 0 = plain fp64 scan (k_scan)
     size_t ev_used = 0;
@@ -2881,6 +2902,11 @@ struct HipBackend {
         if (const char* e = std::getenv("FNN_EMIT_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) emit_grid = v; }
         if (const char* e = std::getenv("FNN_TRACK_GROUP")) { int v = std::atoi(e); if (v >= 2 && v <= 1024) track_group = v; }
         if (const char* e = std::getenv("FNN_TRACK_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 1024) track_grid = v; }
+        // the first-level arrival counters sit at d.ticket + 32 (g + 1), g < ceil(grid / group); word 32 * 65 is TRK_FLAG, 32 * 67
+        // TRK_BAD and the array holds 32 * 72 words: at most 64 groups (the two switches are development aids, but an
+        // inconsistent pair must not run the atomics into the flag words or out of bounds)
+        static_assert(TRK_FLAG == 32 * 65 && TRK_BAD == 32 * 67, "ticket layout: groups 1..64, then the flag words");
+        while ((track_grid + track_group - 1) / track_group > 64) track_group *= 2;
         if (const char* e = std::getenv("FNN_RELAXED_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= RL_GMAX) relaxed_grid = v; }
         if (const char* e = std::getenv("FNN_SCREEN_MIN_M")) { int v = std::atoi(e); if (v >= 8) { screen_min_m = v; screen_min_m_fixed = true; } }
         opened = true;
@@ -2937,12 +2963,12 @@ struct HipBackend {
         return copy2d(d, ldd, s, lds, w, h, hipMemcpyDeviceToHost);
     }
 
-    enum { TC_SCAN = 0, TC_SCREEN = 1, TC_TRACK = 2, TC_DECIDE = 3, TC_UPDATE = 4, TC_EMIT = 5, TC_RESOLVE = 6, TC_OTHER = 7 };
+    enum { TC_SCAN = 0, TC_SCREEN = 1, TC_TRACK = 2, TC_DECIDE = 3, TC_UPDATE = 4, TC_EMIT = 5, TC_RESOLVE = 6, TC_OTHER = 7, TC_GATHER = 8, TC_MERGE = 9 };
     void drain_timing() {
         for (size_t i = 0; i + 1 < ev_used && i / 2 < ev_kind.size(); i += 2) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]) == hipSuccess) {
-                const int c = ev_kind[i / 2] & 7;
+                const int c = ev_kind[i / 2] & 15;
                 class_ms[c] += ms;
                 class_n[c]++;
                 if (c == TC_SCREEN) scan_ms += ms;
@@ -2978,7 +3004,7 @@ struct HipBackend {
     }
     void reset_timing() {
         scan_ms = plain_ms = 0.0; scan_launches = plain_launches = 0; ev_used = 0; ev_kind.clear();
-        for (int c = 0; c < 8; c++) { class_ms[c] = 0.0; class_n[c] = 0; }
+        for (int c = 0; c < 16; c++) { class_ms[c] = 0.0; class_n[c] = 0; }
     }
 
     hipEvent_t next_event() {
@@ -3046,7 +3072,9 @@ struct HipBackend {
         int nt = (scan_tile_count(m_bound) + d.world - 1) / d.world;  // tiles of this rank
         return dim3((unsigned)(nt < scan_grid ? (nt > 0 ? nt : 1) : scan_grid));
     }
-    bool use_screen(const Dev& d, int32_t m_bound) const { return d.H != nullptr && m_bound >= screen_min_m; }
+    bool screen_off = false;  // set by the engine for a matrix that can open no window (negative entries): plain fp64 scans throughout
+    static constexpr bool kKeepGenericScreen = false;
+    bool use_screen(const Dev& d, int32_t m_bound) const { return d.H != nullptr && !screen_off && m_bound >= screen_min_m; }
     // the scan of one event; returns the number of per-workgroup records it leaves in d.recs.
     // With lookahead windows (d.la) k_track goes first: it either serves the event from the open
     // window (the scan kernels then return at once) or lets the scan run.  `sched`: the host's
@@ -3143,13 +3171,14 @@ struct HipBackend {
     }
     int32_t allgather_wx_on_stream(const Dev& d, size_t bytes) {
         if (!rccl_comm) { comm_err = "RCCL communicator not initialised"; return FNN_ERCCL; }
-        int rc = p_ncclAllGather(d.wsend, d.wrecv, bytes, /*ncclInt8*/ 0, rccl_comm, stream);
+        int rc = 0;
+        timed(TC_GATHER, timing == 2, [&] { rc = p_ncclAllGather(d.wsend, d.wrecv, bytes, /*ncclInt8*/ 0, rccl_comm, stream); });
         if (rc != 0) { comm_err = std::string("ncclAllGather: ") + (p_ncclGetErrorString ? p_ncclGetErrorString(rc) : "error"); return FNN_ERCCL; }
         return FNN_OK;
     }
     int32_t launch_wx_rest(const Dev& d, int32_t m_bound) {
         if (m_bound < 1) m_bound = 1;
-        hipLaunchKernelGGL(k_merge, dim3(1), dim3(1024), 0, stream, d);
+        timed(TC_MERGE, timing == 2, [&] { hipLaunchKernelGGL(k_merge, dim3(1), dim3(1024), 0, stream, d); });
         enqueue_rest(d, m_bound, (const Cand*)d.grecv, d.world * GATHER_RECS);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
@@ -3310,6 +3339,13 @@ int32_t fnn_get_kernel_times(fnn_handle* h, double* ms8, int64_t* launches8) {
     FNN_NEED(h);
     if (!ms8 || !launches8) return fnn::fail(FNN_EINVAL, "fnn_get_kernel_times: NULL output");
     for (int c = 0; c < 8; c++) { ms8[c] = h->eng.be.class_ms[c]; launches8[c] = h->eng.be.class_n[c]; }
+    return FNN_OK;
+}
+
+int32_t fnn_get_exchange_times(fnn_handle* h, double* ms2, int64_t* launches2) {
+    FNN_NEED(h);
+    if (!ms2 || !launches2) return fnn::fail(FNN_EINVAL, "fnn_get_exchange_times: NULL output");
+    for (int c = 0; c < 2; c++) { ms2[c] = h->eng.be.class_ms[8 + c]; launches2[c] = h->eng.be.class_n[8 + c]; }
     return FNN_OK;
 }
 

@@ -206,6 +206,8 @@ int32_t fnn_set_scan_timing(fnn_handle* h, int32_t enable);
 /* With timing on: milliseconds and launches of the last run by kernel class {0 k_scan, 1 k_screen, 2 k_track,
  * 3 k_decide, 4 k_update, 5 k_emit, 6 k_resolve, 7 k_finalize}. */
 int32_t fnn_get_kernel_times(fnn_handle* h, double* ms8, int64_t* launches8);
+/* Several ranks, timing 2: milliseconds and calls of {0 the all-gather of a sharded base scan on the stream, 1 k_merge}. */
+int32_t fnn_get_exchange_times(fnn_handle* h, double* ms2, int64_t* launches2);
 
 /* One-call convenience == create + set_rows + run + destroy
  * (FastNN.java:326 + :378). */

@@ -48,6 +48,9 @@ struct EmuBackend {
     static constexpr int64_t kColPad = 2048;
     int32_t screen_min_n() const { return 8; }   // tiny on purpose: the CPU tests exercise screening
     int32_t screen_min_m = 8;
+    bool screen_off = false;                          // (never set here, see kKeepGenericScreen)
+    static constexpr bool kKeepGenericScreen = true;  // the emulation keeps screening matrices with negative entries: it is the CPU suite's
+                                                      // coverage of the mixed-sign brackets, which the product no longer uses by default
     void set_problem_size(int32_t) {}
     void set_relaxed(int32_t) {}
     bool defer_chain = false; // (so does the deferred chain sum)
