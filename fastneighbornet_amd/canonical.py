@@ -97,8 +97,9 @@ def split_weights(D: np.ndarray, ordering: np.ndarray, device: int = 0):
     """Non-negative least-squares weights of the circular splits of `ordering` over
     `fnn_split_weights_f64` (the optimum the reference's live path computes, FastNN.java:401-454, in its
     index order :405-419).  Returns (weights[n(n-1)/2], stats dict); stats["method"]: "closed form"
-    (the unconstrained optimum is feasible), "from below" (Lawson-Hanson with a dense Cholesky factor of
-    the free set) or "reference" (CircularSplitWeights.java's active-set / conjugate-gradient method)."""
+    (the unconstrained optimum is feasible), "from below" (the block active-set method on an inverse Cholesky
+    factor of the free set) or "reference" (CircularSplitWeights.java's active-set /
+    conjugate-gradient method); stats["refactorizations"] = rebuilds of the factor, stats["solves"] = sub-problems."""
     from . import api
     a = api()
     D = np.ascontiguousarray(D, dtype=np.float64)
@@ -111,4 +112,5 @@ def split_weights(D: np.ndarray, ordering: np.ndarray, device: int = 0):
     out = {k: getattr(st, k) for k, _ in st._fields_ if k != "reserved"}
     out["method"] = "from below" if st.reserved[0] == 1 else ("reference" if st.cg_calls > 0 else "closed form")
     out["refactorizations"] = int(st.reserved[1])
+    out["solves"] = int(st.reserved[2])
     return w, out

@@ -1772,7 +1772,8 @@ __device__ __forceinline__ void rl_rowmin_block(const Dev& d, RlLds& L) {
 // it sc1, by the wave whose poll matched.)  Every wait is bounded: a worker that never sees its command leaves, the
 // control wave then reports error 23 instead of hanging.
 constexpr uint32_t RL_EXIT = 0xFFFFFu;
-constexpr long RL_SPINS = 400000;   // (x ~1 us per poll)
+constexpr long long RL_WAIT_TICKS = 200000000LL;  // deadline of every wait, in ticks of the 100 MHz wall clock (2 s): a count of polls would
+                                                  // turn a late-scheduled workgroup on a shared or profiled GPU into a spurious error 23
 __device__ __forceinline__ uint64_t rl_cmd_word(uint32_t stamp, uint32_t seq, uint32_t ps) {
     return ((uint64_t)(stamp & 0xFFFFFFu) << 40) | ((uint64_t)(seq & 0xFFFFFu) << 20) | (uint64_t)(ps & 0xFFFFFu);
 }
@@ -1788,7 +1789,8 @@ __device__ __forceinline__ uint32_t rl_h16(uint64_t x) {
     return (uint32_t)(x >> 48);
 }
 __device__ __forceinline__ uint64_t rl_head(int32_t cnt, uint32_t seq, uint64_t vbits, uint64_t txor) {
-    return ((uint64_t)(uint32_t)(cnt & 0xFF) << 56) | ((uint64_t)(seq & 0xFFFFFFu) << 32) | ((uint64_t)rl_h16(txor + 1ULL) << 16) |
+    // (both digests mix the command's sequence number in: a stale value or tie list identical to the previous command's does not pass)
+    return ((uint64_t)(uint32_t)(cnt & 0xFF) << 56) | ((uint64_t)(seq & 0xFFFFFFu) << 32) | ((uint64_t)rl_h16((txor + 1ULL) ^ ((uint64_t)seq << 1)) << 16) |
            (uint64_t)rl_h16(vbits ^ ((uint64_t)seq << 1));
 }
 __device__ __forceinline__ void rl_publish_part(const Dev& d, RlLds& L, uint32_t seq) {
@@ -1882,9 +1884,9 @@ struct RlBlockEnv {
             int ok = 1;
             if (lane == 0) {
                 const uint32_t want = L.base + (uint32_t)(nwg - 1) * seq;
-                long spins = 0;
+                const long long t_wait = (long long)wall_clock64();
                 while ((uint32_t)ld_sc1(d.rl_mail + 16) != want) {
-                    if (++spins > RL_SPINS) { ok = 0; break; }
+                    if ((long long)wall_clock64() - t_wait > RL_WAIT_TICKS) { ok = 0; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
@@ -1926,7 +1928,7 @@ struct RlBlockEnv {
                 }
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) e ^= (uint64_t)__shfl_xor((unsigned long long)e, off, 64);
-                if (rl_h16(e + 1ULL) != (uint32_t)__builtin_amdgcn_readlane((int)th, w)) ok = 0;
+                if (rl_h16((e + 1ULL) ^ ((uint64_t)seq << 1)) != (uint32_t)__builtin_amdgcn_readlane((int)th, w)) ok = 0;
                 total += cw;
             }
             if (lane == 0) {
@@ -1984,12 +1986,12 @@ __global__ __launch_bounds__(RL_T) void k_relaxed(Dev d, int ticks) {
         // a worker workgroup: commands until the exit command
         for (uint32_t seq = 1;; seq++) {
             if (threadIdx.x == 0) {
-                long spins = 0;
+                const long long t_wait = (long long)wall_clock64();
                 uint64_t w;
                 for (;;) {
                     w = ld_sc1(d.rl_mail);
                     if ((uint32_t)(w >> 40) == (stamp & 0xFFFFFFu) && (uint32_t)((w >> 20) & 0xFFFFFu) == (seq & 0xFFFFFu)) break;
-                    if (++spins > 4 * RL_SPINS) { w = RL_EXIT; break; }  // (never seen: leave; the control wave reports it)
+                    if ((long long)wall_clock64() - t_wait > 4 * RL_WAIT_TICKS) { w = RL_EXIT; break; }  // (never seen: leave; the control wave reports it)
                     __builtin_amdgcn_s_sleep(1);
                 }
                 const uint32_t ps = (uint32_t)(w & 0xFFFFFu);

@@ -419,11 +419,20 @@ __global__ __launch_bounds__(T) void k_copy_lower(const double* a, int64_t lda, 
 constexpr int TRI_NB = 64;
 // inverse of the Cholesky factor of a symmetric positive definite m x m block (m <= 64; lower triangle of S read):
 // Li (lower triangular, zeros above) with Li^T Li = S^-1.  ONE wave; lane t owns ROW t of the matrix in registers (every index
-// below is a compile-time constant: the loops are unrolled), finished entries of L go to LDS and are read back as broadcasts
-// (all lanes the same address).  Left-looking Cholesky, then lane t computes COLUMN t of the inverse by forward substitution.
-// The first version walked an LDS copy with dependent reads (170 us per block, 45 % of a 4096-taxon solve); this one ~10 us.
+// below is a compile-time constant: the loops are unrolled, 256 VGPR, no scratch); the entry of another row that a step needs
+// is the same for all lanes and comes straight out of the owning lane's register (two v_readlane_b32 into a scalar pair
+// that feeds the FMA): no LDS round trip on the 4032 multiply-adds.  Left-looking Cholesky, then lane t computes COLUMN t of
+// the inverse by forward substitution.  Measured (profiles/r03/r03_splits_kernel_stats_n4096.csv): 64 us per block - a first
+// version that walked an LDS copy with dependent reads took 170 us (45 % of a 4096-taxon solve).  What bounds it now is the
+// fetch of its own ~100 KB of straight-line code, executed once per launch (the same 64 us with broadcast LDS reads in place of
+// the lane reads); a rolled loop would index the register rows at run time, at about the same cost per term.
 // Rows beyond m are padded with the identity.  A pivot that is not positive reports its (1-based, offset by `off`)
 // position through atomicMin on *info.  (Not on the bit-exact path: FMAs are welcome here.)
+__device__ __forceinline__ double lane_value(double v, int src) {  // the value lane `src` holds (src a compile-time constant)
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __global__ __launch_bounds__(TRI_NB) void k_invchol_small(const double* S, int64_t lds, double* Li, int64_t ldl, int m, long long off, long long* info) {
     __shared__ double Ls[TRI_NB][TRI_NB + 1];
     __shared__ double rd[TRI_NB];
@@ -435,25 +444,24 @@ __global__ __launch_bounds__(TRI_NB) void k_invchol_small(const double* S, int64
     for (int j = 0; j < TRI_NB; j++) {
         double sj = a[j];
 #pragma unroll
-        for (int l = 0; l < j; l++) sj = __builtin_fma(-a[l], Ls[j][l], sj);  // (row t) . (row j) over the finished columns
-        double piv = __shfl(sj, j, 64);
+        for (int l = 0; l < j; l++) sj = __builtin_fma(-a[l], lane_value(a[l], j), sj);  // (row t) . (row j) over the finished columns
+        double piv = lane_value(sj, j);
         if (!(piv > 0.0)) {
             if (t == j && j < m) atomicMin(info, off + j + 1);
             piv = 1.0;
         }
         const double dj = __builtin_sqrt(piv);
         a[j] = t == j ? dj : (t > j ? sj / dj : 0.0);
-        Ls[t][j] = a[j];
         if (t == j) rd[j] = 1.0 / dj;
-        __syncthreads();
     }
+    __syncthreads();
     // column t of L^-1: x_i = (delta_it - sum_{l < i} L_il x_l) / L_ii (x_l = 0 for l < t falls out of the recurrence)
     double x[TRI_NB];
 #pragma unroll
     for (int i = 0; i < TRI_NB; i++) {
         double acc = i == t ? 1.0 : 0.0;
 #pragma unroll
-        for (int l = 0; l < i; l++) acc = __builtin_fma(-Ls[i][l], x[l], acc);
+        for (int l = 0; l < i; l++) acc = __builtin_fma(-lane_value(a[l], i), x[l], acc);
         x[i] = acc * rd[i];
     }
     __syncthreads();
@@ -585,6 +593,11 @@ struct Solver {
         if (!SWOK(hipMalloc(&p_, sizeof(Tp) * (count ? count : 1)))) { ok = false; return nullptr; }
         allocs.push_back(p_);
         return (Tp*)p_;
+    }
+    void release(void* p_) {  // one allocation back to the device (after the work queued on it)
+        (void)hipStreamSynchronize(s);
+        for (size_t i = 0; i < allocs.size(); i++)
+            if (allocs[i] == p_) { (void)hipFree(p_); allocs.erase(allocs.begin() + (long)i); return; }
     }
     size_t block_mark = SIZE_MAX;  // allocs[block_mark ..) belong to the block active-set method
     void release_block_buffers() {
@@ -849,9 +862,28 @@ struct Solver {
         const int64_t N = (int64_t)n * (n - 1) / 2;
         Blk& b = bk;
         block_mark = allocs.size();
-        b.cap = up64(std::min<int64_t>(N, std::max<int64_t>({(int64_t)(envd("FNN_SW_CAP", 3.25) * n) + 1024, std::min<int64_t>(8 * (int64_t)n + 64, 20000), 512})));
-        b.kmax = std::min<int64_t>(b.cap, std::max<int64_t>(64, up64(b.cap / 12)));
-        b.rcap = std::min<int64_t>(b.cap, up64(b.cap / 5) + 64);
+        // Capacity of the factor (splits that are in + the departed ones still inside + the entering block): random distances end
+        // with ~2.4 n positive splits, tree-like ones with more (tree + 5 % noise: 3.8 n) - as many as device memory allows, up
+        // to 6 n: the factor takes cap^2 doubles, the block buffers, the departed columns and their Gram matrices 0.61 cap^2 more.
+        auto sized = [&](double factor) {
+            b.cap = up64(std::min<int64_t>(N, std::max<int64_t>({(int64_t)(factor * n) + 1024, std::min<int64_t>(8 * (int64_t)n + 64, 20000), 512})));
+            b.kmax = std::min<int64_t>(b.cap, std::max<int64_t>(64, up64(b.cap / 12)));
+            b.rcap = std::min<int64_t>(b.cap, up64(b.cap / 5) + 64);
+            return 8.0 * ((double)b.cap * b.cap + 3.0 * (double)b.cap * b.kmax + (double)b.cap * b.rcap + 4.0 * (double)b.rcap * b.rcap + 3.0 * (double)b.kmax * b.kmax +
+                          0.5 * (double)std::max(b.rcap, b.kmax) * std::max(b.rcap, b.kmax)) + 64.0 * (double)b.cap + 48.0 * (double)std::max<int64_t>(1 << 16, N / 16 + 1024);
+        };
+        size_t free_b = 0, total_b = 0;
+        if (!SWOK(hipMemGetInfo(&free_b, &total_b))) free_b = 0;
+        const double budget = 0.92 * (double)free_b;
+        const double want = envd("FNN_SW_CAP", 0.0);
+        double chosen = 3.25;
+        for (double fct : {6.0, 5.0, 4.5, 4.0, 3.5, 3.25}) {
+            chosen = want > 0.0 ? want : fct;
+            if (want > 0.0 || sized(fct) <= budget) break;
+        }
+        (void)sized(chosen);
+        if (log) std::fprintf(stderr, "  [sw] capacity %lld splits (%.2f n), block <= %lld, departed <= %lld; device memory free %.1f GB\n", (long long)b.cap,
+                              (double)b.cap / n, (long long)b.kmax, (long long)b.rcap, (double)free_b * 1e-9);
         if (rocblas_create_handle(&b.bh) != rocblas_status_success) return false;
         struct HandleGuard { rocblas_handle h; ~HandleGuard() { rocblas_destroy_handle(h); } } guard{b.bh};
         rocblas_set_stream(b.bh, s);
@@ -1348,6 +1380,8 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, S.s);
     hipLaunchKernelGGL(k_reorder, dim3((unsigned)((n + T - 1) / T), (unsigned)n), dim3(T), 0, S.s, S.Dm, (int64_t)n, S.ord, S.d, n, S.ld);
+    S.release(S.Dm);  // (the raw copy has served: its n^2 doubles go back to the pool before the factor is sized)
+    S.Dm = nullptr;
     // the closed form if it is feasible; else from below (Lawson-Hanson, exact sub-problems); the reference's own method
     // (from above, conjugate gradients) where the free set is too large for a dense factor
     bool from_below = false;

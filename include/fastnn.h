@@ -257,12 +257,12 @@ int32_t fnn_comm_init_host(fnn_handle* h, int32_t world, int32_t rank, fnn_allga
  * (i, j), 0 <= i < j <= n-1, row-major, split k = taxa ordering[i+1 .. j] against the rest.  The
  * reference keeps the splits with weight > 1e-6 (FastNN.java:455). */
 typedef struct fnn_sw_stats {
-    int64_t outer_iterations; /* from below: steps (a split enters the free set per step); reference method: passes of its active-set loop */
-    int64_t cg_calls;         /* conjugate-gradient solves */
+    int64_t outer_iterations; /* from below: steps (a BLOCK of splits enters the free set per step); reference method: passes of its active-set loop */
+    int64_t cg_calls;         /* conjugate-gradient solves (reference method only) */
     int64_t cg_iterations;    /* ... and their iterations (each applies A and A^T once) */
     int64_t nsplits;          /* weights above 1e-6 */
     double  t_solve_s;        /* device time from the re-ordered distances to the weights */
-    int64_t reserved[3];      /* [0] 1 = solved from below, [1] Cholesky factorisations from scratch, [2] - */
+    int64_t reserved[3];      /* [0] 1 = solved from below (block active-set method), [1] rebuilds of the factor, [2] sub-problems solved */
 } fnn_sw_stats;
 int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ld, const int32_t* ordering, int32_t device,
                               double* weights_out, fnn_sw_stats* stats);
