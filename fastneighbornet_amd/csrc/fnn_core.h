@@ -197,7 +197,7 @@ struct Dev {
                      // (consumed by the NEXT event's k_track while that event may already fill [1..4], the <= 4 ComputeRx sums of its own decision)
     int64_t cstride; // n rounded up to a whole super-chunk
     Cand* recs;      // per-block scan records
-    uint64_t* rchk;  // k_track's fan-in: a check word per record (2 x 1024), see rec_publish
+    uint64_t* rchk;  // k_track's fan-in: a check word per record (2 x 1024), see rec_publish; [2048 ..): results of the ComputeRx helper workgroups
     uint16_t* H;     // bf16 screening copy of D: H[r * ldh + c] == bf16(D[r][c]) (its own row stride, see fnn_create)
     int64_t ldh;
     float* srec;     // screening: per unit [tile][4] lower bounds, then [tile][4] upper bounds
@@ -1161,6 +1161,14 @@ FNN_HD void rx_fill_thread(const Dev& d, int32_t s, int32_t m, int32_t twoP, con
         double v = d.D[(int64_t)z[k] * d.ld + s];
         d.chain[(int64_t)(k + 1) * d.cstride + chain_addr(pos)] = full ? v : v / 2.0;
     }
+}
+
+// the same for ONE of the four nodes (buffer k + 1): a helper workgroup of k_track gathers its own row
+FNN_HD void rx_fill_one(const Dev& d, int32_t s, int32_t m, int32_t twoP, const int32_t z[4], int k, int32_t zk) {
+    if (s >= m || zk < 0) return;
+    const bool full = (s == z[0] || s == z[1] || s == z[2] || s == z[3] || s >= twoP);
+    const double v = d.D[(int64_t)zk * d.ld + s];
+    d.chain[(int64_t)(k + 1) * d.cstride + chain_addr(d.spos[s])] = full ? v : v / 2.0;
 }
 
 // Rx = 0.0; for i in position order: Rx += term  (sequential, :551-560)

@@ -97,7 +97,7 @@ class Engine {
             !(dev.pslot = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
             !(dev.chain = (double*)be.alloc(sizeof(double) * 5 * (size_t)dev.cstride)) ||
             !(dev.recs = (Cand*)be.alloc(sizeof(Cand) * be.max_records(n))) ||
-            !(dev.rchk = (uint64_t*)be.alloc(sizeof(uint64_t) * 2048)) ||
+            !(dev.rchk = (uint64_t*)be.alloc(sizeof(uint64_t) * (2048 + 8))) ||
             !(dev.T = (double*)be.alloc(sizeof(double) * (nn + 8))) ||
             !(dev.srec = (float*)be.alloc(sizeof(float) * (2 * (size_t)screen_unit_count(n > 0 ? n : 1) + 16))) ||
             !(dev.stile = (float*)be.alloc(sizeof(float) * (2 * (size_t)screen_unit_count(n > 0 ? n : 1) / 4 + 16))) ||
@@ -455,6 +455,7 @@ class Engine {
             if (rc != FNN_OK) return rc;
             m_bound = hst.m;
             resync_schedule();
+            be.note_rx_exact(hst.n_rx_exact);
             if (hst.done) ended = true;
         }
         stats.t_agglom_s = now_s() - t0;

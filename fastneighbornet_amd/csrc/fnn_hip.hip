@@ -1493,7 +1493,59 @@ __device__ __forceinline__ Cand best_bcast(Cand b) {  // lane 0's candidate to t
 
 // All threads of a 1024-thread workgroup call this; S.lst holds the control block (visible to the whole
 // workgroup); `best` is valid in thread 0.  d.st is NOT used: dl.st points at the LDS copy.
-__device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds<CH_EPT>& L, Cand best) {
+// Helper workgroups for the exact ComputeRx sums (k_track only; nhelp = 0 elsewhere).  On tie-rich inputs (additive trees,
+// integer-valued distances) the 4-candidate choice can rarely be certified, and the <= 4 exact sequential sums - one after the
+// other in the deciding workgroup, ~30 us each - made an event 157 us long (profiles/r03/r03_input_classes.md: 4.8 s instead of
+// 1.4 s at 32768 taxa).  k_track is launched with four more workgroups that wait for a JOB word: the deciding workgroup posts
+// {launch tag | which sums | job flag} once per launch - "no job" as soon as the choice is certified (or the window cannot
+// serve the event, or the launch returns early), so the helpers leave long before the kernel ends - or "job" behind its six
+// parameter words (the four nodes' slots, m, 2P: write-through, drained): helper b gathers the ComputeRx terms of node b into its
+// own buffer, computes their exact sequential sum with the fast form, stores the result write-through and counts its arrival;
+// the deciding workgroup then reads the results past its L1.  Every wait has a deadline (error 14, never a hang).  The helpers are launched only while
+// the run needs them (HipBackend::note_rx_exact): a run on distances without ties never sees them.
+constexpr int TRK_JOB = 32 * 68, TRK_JOBDONE = 32 * 69, TRK_JOBM = 32 * 70;  // words of d.ticket (32 * 72 words; 65, 67: TRK_FLAG, TRK_BAD); JOBM: 6 parameter words
+constexpr int TRK_NHELP = 4;
+constexpr int RX_RES = 2048;  // d.rchk[RX_RES + b]: bit pattern of helper b's sum (behind the 2 x 1024 record check words)
+constexpr long long TRK_WAIT_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock
+__device__ __forceinline__ void job_post(const Dev& d, unsigned tag, unsigned low5) {
+    __hip_atomic_store(d.ticket + TRK_JOB, (tag << 5) | (low5 & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void rx_helper_workgroup(const Dev& d, ChainLds<CH_EPT>& L, int b, unsigned tag, unsigned* hword) {
+    if (threadIdx.x == 0) {
+        const long long t0 = (long long)wall_clock64();
+        unsigned w = 0;
+        for (;;) {
+            w = __hip_atomic_load(d.ticket + TRK_JOB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((w >> 5) == tag) break;
+            if ((long long)wall_clock64() - t0 > TRK_WAIT_TICKS) { w = 0; break; }  // (the deciding workgroup reports it)
+            __builtin_amdgcn_s_sleep(2);
+        }
+        *hword = w;
+    }
+    __syncthreads();
+    const unsigned w = *hword;
+    if (!(w & 1u) || !((w >> (1 + b)) & 1u)) return;
+    // the job's parameters (write-through stores of the deciding workgroup, drained before the JOB word went out)
+    int32_t z[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) z[k] = (int32_t)__hip_atomic_load(d.ticket + TRK_JOBM + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int32_t m_old = (int32_t)__hip_atomic_load(d.ticket + TRK_JOBM + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int32_t twoP_old = (int32_t)__hip_atomic_load(d.ticket + TRK_JOBM + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // this helper's row: the ComputeRx terms of node z[b] in reference position order (rx_fill_thread, one buffer), then their
+    // exact sequential sum.  The matrix and the slot tables do not change during this launch (k_update writes them).
+    const int32_t only[4] = {b == 0 ? z[0] : -1, b == 1 ? z[1] : -1, b == 2 ? z[2] : -1, b == 3 ? z[3] : -1};
+    for (int32_t sl = threadIdx.x; sl < m_old; sl += blockDim.x) rx_fill_one(d, sl, m_old, twoP_old, z, b, only[b]);
+    __threadfence_block();
+    __syncthreads();
+    const double r = block_chain_sum2<CH_EPT>(d.chain + (size_t)(b + 1) * d.cstride, m_old, CH_GUARD_BITS, L, nullptr);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(d.rchk + RX_RES + b, __builtin_bit_cast(uint64_t, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        atomicAdd(d.ticket + TRK_JOBDONE, 1u);
+    }
+}
+
+__device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds<CH_EPT>& L, Cand best, int nhelp = 0, unsigned jobtag = 0) {
     State& lst = S.lst;
     Dev dl = d;
     dl.st = &lst;
@@ -1599,6 +1651,8 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
     }
     __syncthreads();
     DEC_TICK(2);
+    const bool want_exact = lst.ev_active && !lst.ev_finish && !S.cert;
+    if (nhelp > 0 && !want_exact && tid == 0) job_post(d, jobtag, 0u);  // the helpers may leave
     if (!lst.ev_active) return;  // the loop has ended
     if (lst.ev_finish) {         // the special finish: planned inside pick; only the symbolic replay is left
         if (tid < 64) build_targets_wave(lst);
@@ -1609,6 +1663,29 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
         // rare: the <= 4 sums exactly, one after the other in this workgroup; their addends go to the chain buffers first
         const int32_t z[4] = {lst.sa, lst.sap, lst.sb, lst.sbp};
         const int32_t m_old = lst.m_old, twoP_old = 2 * lst.P_old;
+        if (nhelp > 0) {
+            // the four sums by the four helper workgroups, side by side: each gathers its own row and sums it
+            const unsigned mask = (z[0] >= 0 ? 1u : 0u) | (z[1] >= 0 ? 2u : 0u) | (z[2] >= 0 ? 4u : 0u) | (z[3] >= 0 ? 8u : 0u);
+            if (tid == 0) {
+                const int32_t par[6] = {z[0], z[1], z[2], z[3], m_old, twoP_old};
+#pragma unroll
+                for (int k = 0; k < 6; k++) __hip_atomic_store(d.ticket + TRK_JOBM + k, (unsigned)par[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the parameters are on their way out before the JOB word)
+                job_post(d, jobtag, 1u | (mask << 1));
+            }
+            if (tid == 0) {
+                const unsigned want = (unsigned)__builtin_popcount(mask);
+                const long long t0 = (long long)wall_clock64();
+                while (__hip_atomic_load(d.ticket + TRK_JOBDONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+                    if ((long long)wall_clock64() - t0 > TRK_WAIT_TICKS) { lst.error = 14; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __hip_atomic_store(d.ticket + TRK_JOBDONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int b = 0; b < 4; b++)
+                    S.rx[b] = ((mask >> b) & 1u) ? __builtin_bit_cast(double, __hip_atomic_load(d.rchk + RX_RES + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+            }
+            __syncthreads();
+        } else {
         for (int32_t sl = tid; sl < m_old; sl += blockDim.x) rx_fill_thread(d, sl, m_old, twoP_old, z);
         __threadfence_block();
         __syncthreads();
@@ -1618,6 +1695,7 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
             if (z[b] >= 0) r = block_chain_sum_rare<CH_EPT>(d.chain + (size_t)(b + 1) * d.cstride, m_old, CH_GUARD_BITS, &L, nullptr);  // (buffer 0 belongs to the pending row sum)
             if (tid == 0) S.rx[b] = r;
             __syncthreads();
+        }
         }
     }
     if (wv == 0) {
@@ -2104,18 +2182,23 @@ __device__ __forceinline__ void sweep_exact_item(const Dev& d, int64_t r, const 
 
 constexpr int TRK_REC_U = 1024;  // offset of the swept-pair records in d.recs
 
-__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed, int has_scan, int tgroup, int ticks) {
+__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed, int has_scan, int tgroup, int ticks, int nhelp, unsigned jobtag) {
     __shared__ ChainLds<CH_EPT> L;
     __shared__ DecideLds S;
     __shared__ Cand sh[TRK_THREADS / 64], shu[TRK_THREADS / 64];
     __shared__ int lastflag;
     __shared__ double shs[2];
+    __shared__ unsigned hword;
     State* st = d.st;
     if (blockIdx.x == 0) {  // the chain workgroup
         chain_workgroup(d, L);
         return;
     }
-    const int wg = (int)blockIdx.x - 1, G = (int)gridDim.x - 1;
+    const int wg = (int)blockIdx.x - 1, G = (int)gridDim.x - 1 - nhelp;
+    if (wg >= G) {  // a helper workgroup of the exact ComputeRx sums (see decide_step)
+        rx_helper_workgroup(d, L, wg - G, jobtag, &hword);
+        return;
+    }
     // phase split of the last-arriving workgroup (diagnostic, FNN_TICKS=1): thread 0 stamps the 100 MHz clock
     const bool prof = ticks != 0 && threadIdx.x == 0;
 #define TRK_TICK(slot) do { if (prof) S.tk[(slot) + 1] = (long long)wall_clock64(); } while (0)
@@ -2128,18 +2211,25 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     rec0.e[0] = rec0.e[1] = rec0.e[2] = rec0.e[3] = 0.0;
     if (start < LA_PCAP) rec0 = track_pair_load(d, start);
     if (st->done) {
-        if (wg == 0 && threadIdx.x == 0) st->ev_active = 0;  // (a launch sequence without a decide kernel must not replay the last event)
+        if (wg == 0 && threadIdx.x == 0) {
+            st->ev_active = 0;  // (a launch sequence without a decide kernel must not replay the last event)
+            if (nhelp > 0) job_post(d, jobtag, 0u);
+        }
         return;
     }
     // every tracking workgroup fetches the control block now (nothing writes to it while they track): the one that
     // arrives last continues on this LDS copy and writes it back at the end
     state_in(S.lst, st);
     if (!has_scan && st->stall) {  // (the launch sequence has no scan kernels and the window is gone: nothing to do)
-        if (wg == 0 && threadIdx.x == 0) st->n_stalled++;
+        if (wg == 0 && threadIdx.x == 0) {
+            st->n_stalled++;
+            if (nhelp > 0) job_post(d, jobtag, 0u);
+        }
         return;
     }
     if (force_base || !la_active(*st)) {
         if (wg == 0 && threadIdx.x == 0) {
+            if (nhelp > 0) job_post(d, jobtag, 0u);
             st->ev_timed = timed;
             if (st->la_valid) st->la_prev_end = 0;  // the window ends on schedule
             la_prepare_base(*st, d.lacnt);
@@ -2330,7 +2420,8 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     TRK_TICK(6);
     // the window has certified the minimum: Cx / Cy, the 4-candidate choice and the merge plan follow at once
     // (the launch sequence of a window event has no decide kernel); otherwise the event scans (or stalls)
-    if (lst.la_hit) decide_step(d, S, L, best);
+    if (lst.la_hit) decide_step(d, S, L, best, nhelp, jobtag);
+    else if (nhelp > 0 && threadIdx.x == 0) job_post(d, jobtag, 0u);  // (the event scans or stalls: nothing for the helpers)
     TRK_TICK(7);
     if (prof) {
         for (int q = 0; q < 8; q++) d.ticks[q] += S.tk[q + 1] - S.tk[q];
@@ -2842,6 +2933,14 @@ struct HipBackend {
     int unsched_grid = 2048; // workgroups of the screening launches that only run when a lookahead window fails (FNN_UNSCHED_GRID)
     int emit_grid = 256;    // workgroups of k_emit (FNN_EMIT_GRID)
     int track_grid = 64;    // track workgroups of k_track (FNN_TRACK_GRID); one more computes the pending chain
+    int rx_helpers_cfg = TRK_NHELP;  // helper workgroups of k_track for the exact ComputeRx sums (FNN_RX_HELPERS=0: the deciding workgroup does all four)
+    int rx_helpers = 0;              // ... launched only while the run needs them: on after a batch of events with exact sums, off after one without
+    int64_t rx_exact_seen = 0;
+    void note_rx_exact(int64_t n_rx_exact) {  // (the host's look at the state after every batch)
+        rx_helpers = n_rx_exact > rx_exact_seen ? rx_helpers_cfg : 0;
+        rx_exact_seen = n_rx_exact;
+    }
+    unsigned track_tag = 0;      // tag of a k_track launch in the helpers' JOB word
     bool skip_unsched_scans = true; // FNN_UNSCHED_SCANS=1: keep the (mostly idle) scan kernels in unscheduled events
     int track_group = TRK_GROUP;  // k_track: workgroups per first-level arrival counter (FNN_TRACK_GROUP)
     bool defer_chain = false; // set by the engine: k_update closes the event, the exact u.Sx sum runs inside the next k_track
@@ -2902,6 +3001,7 @@ struct HipBackend {
         if (const char* e = std::getenv("FNN_UNSCHED_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) unsched_grid = v; }
         if (const char* e = std::getenv("FNN_UNSCHED_SCANS")) skip_unsched_scans = std::atoi(e) == 0;
         if (const char* e = std::getenv("FNN_EMIT_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) emit_grid = v; }
+        if (const char* e = std::getenv("FNN_RX_HELPERS")) rx_helpers_cfg = std::atoi(e) != 0 ? TRK_NHELP : 0;
         if (const char* e = std::getenv("FNN_TRACK_GROUP")) { int v = std::atoi(e); if (v >= 2 && v <= 1024) track_group = v; }
         if (const char* e = std::getenv("FNN_TRACK_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 1024) track_grid = v; }
         // the first-level arrival counters sit at d.ticket + 32 (g + 1), g < ceil(grid / group); word 32 * 65 is TRK_FLAG, 32 * 67
@@ -3066,6 +3166,7 @@ struct HipBackend {
     }
     int32_t launch_init(const Dev& d) {
         reset_timing();
+        rx_exact_seen = 0; rx_helpers = 0;  // (a new run: the device's counter starts again)
         hipLaunchKernelGGL(k_init, grid1(d.n), dim3(256), 0, stream, d);
         return HIPOK(hipGetLastError()) ? FNN_OK : FNN_EHIP;
     }
@@ -3090,7 +3191,9 @@ struct HipBackend {
         //  looks at the state every batch, launches an event with a scan)
         const bool has_scan = sched || !screen || !skip_unsched_scans;
         if (d.la) timed(TC_TRACK, tall, [&]() {
-            hipLaunchKernelGGL(k_track, dim3(track_grid + 1), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0, has_scan ? 1 : 0, track_group, ticks ? 1 : 0);
+            track_tag = (track_tag % 0x7FFFFFEu) + 1u;  // (never 0: the JOB word starts out as 0)
+            hipLaunchKernelGGL(k_track, dim3(track_grid + 1 + rx_helpers), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0, has_scan ? 1 : 0,
+                               track_group, ticks ? 1 : 0, rx_helpers, track_tag);
         });
         int nrecs;
         if (screen && !has_scan) nrecs = 0;  // (a window event: the tail of k_track decides; no decide kernel follows)

@@ -49,6 +49,7 @@ struct EmuBackend {
     int32_t screen_min_n() const { return 8; }   // tiny on purpose: the CPU tests exercise screening
     int32_t screen_min_m = 8;
     bool screen_off = false;                          // (never set here, see kKeepGenericScreen)
+    void note_rx_exact(int64_t) {}                    // (the helper workgroups of the exact ComputeRx sums exist on the GPU only)
     static constexpr bool kKeepGenericScreen = true;  // the emulation keeps screening matrices with negative entries: it is the CPU suite's
                                                       // coverage of the mixed-sign brackets, which the product no longer uses by default
     void set_problem_size(int32_t) {}
