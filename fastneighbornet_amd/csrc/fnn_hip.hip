@@ -2107,17 +2107,25 @@ __global__ __launch_bounds__(RL_T) void k_relaxed(Dev d, int ticks) {
 
 // ------------------------------------------------------------------ k_decide
 // the decide step of an event that scanned: the scan's (or all ranks') candidate records are reduced first
-__global__ __launch_bounds__(CH_T) void k_decide(Dev d, const Cand* src, int nrecs) {
+__global__ __launch_bounds__(CH_T) void k_decide(Dev d, const Cand* src, int nrecs, int nhelp, unsigned jobtag) {
     __shared__ ChainLds<CH_EPT> L;
     __shared__ DecideLds S;
     __shared__ Cand shc[CH_T / 64];
+    __shared__ unsigned hword;
     State* st = d.st;
-    if (st->stall || st->la_hit) return;  // (nothing to decide / the tail of k_track has decided this event already)
+    if (blockIdx.x > 0) {  // a helper workgroup of the exact ComputeRx sums (see decide_step)
+        rx_helper_workgroup(d, L, (int)blockIdx.x - 1, jobtag, &hword);
+        return;
+    }
+    if (st->stall || st->la_hit) {  // (nothing to decide / the tail of k_track has decided this event already)
+        if (nhelp > 0 && threadIdx.x == 0) job_post(d, jobtag, 0u);
+        return;
+    }
     state_in(S.lst, st);
     if (threadIdx.x == 0) S.tkon = 0;
     Cand best = reduce_records(d, src, st->rl_active ? 1 : nrecs, shc);  // (Relaxed mode: the search's one record)
     __syncthreads();
-    decide_step(d, S, L, best);
+    decide_step(d, S, L, best, nhelp, jobtag);
     __syncthreads();
     if (threadIdx.x == 0) S.lst.rl_active = 0;
     __syncthreads();
@@ -2387,9 +2395,9 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
             // a swept pair may be the minimum: wait for the chain workgroup, sweep again with the exact sum
             if (threadIdx.x == 0) {
                 const unsigned want = (unsigned)lst.n_events;
-                long spins = 0;
+                const long long t_wait = (long long)wall_clock64();
                 while (__hip_atomic_load(d.ticket + TRK_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-                    if (++spins > 20000000) { lst.error = 10; break; }
+                    if ((long long)wall_clock64() - t_wait > TRK_WAIT_TICKS) { lst.error = 10; break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 __threadfence();
@@ -3240,7 +3248,10 @@ struct HipBackend {
     void enqueue_rest(const Dev& d, int32_t m_bound, const Cand* src, int nrecs) {
         dim3 g1 = grid1(m_bound);
         const bool tall = timing == 2;
-        if (nrecs > 0) timed(TC_DECIDE, tall, [&]() { hipLaunchKernelGGL(k_decide, dim3(1), dim3(CH_T), 0, stream, d, src, nrecs); });
+        if (nrecs > 0) timed(TC_DECIDE, tall, [&]() {
+            track_tag = (track_tag % 0x7FFFFFEu) + 1u;
+            hipLaunchKernelGGL(k_decide, dim3(1 + rx_helpers), dim3(CH_T), 0, stream, d, src, nrecs, rx_helpers, track_tag);
+        });
         timed(TC_UPDATE, tall, [&]() { hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d, defer_chain ? 1 : 0, ticks ? 1 : 0); });
         if (!defer_chain) timed(TC_OTHER, tall, [&]() { hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d); });
     }

@@ -857,7 +857,8 @@ struct Solver {
         const bool log = std::getenv("FNN_SW_LOG") != nullptr;
         lap_on = log;
         auto envd = [](const char* k, double dflt) { const char* e = std::getenv(k); return e ? std::atof(e) : dflt; };
-        const double kfrac = envd("FNN_SW_KFRAC", 0.20), rfrac = envd("FNN_SW_RFRAC", 0.15);
+        const double kfrac = envd("FNN_SW_KFRAC", 0.20);
+        double rfrac = envd("FNN_SW_RFRAC", 0.15);
         const int rad = (int)envd("FNN_SW_NMS", 3);
         const int64_t N = (int64_t)n * (n - 1) / 2;
         Blk& b = bk;
@@ -865,10 +866,10 @@ struct Solver {
         // Capacity of the factor (splits that are in + the departed ones still inside + the entering block): random distances end
         // with ~2.4 n positive splits, tree-like ones with more (tree + 5 % noise: 3.8 n) - as many as device memory allows, up
         // to 6 n: the factor takes cap^2 doubles, the block buffers, the departed columns and their Gram matrices 0.61 cap^2 more.
-        auto sized = [&](double factor) {
+        auto sized = [&](double factor, int kdiv, int rdiv) {
             b.cap = up64(std::min<int64_t>(N, std::max<int64_t>({(int64_t)(factor * n) + 1024, std::min<int64_t>(8 * (int64_t)n + 64, 20000), 512})));
-            b.kmax = std::min<int64_t>(b.cap, std::max<int64_t>(64, up64(b.cap / 12)));
-            b.rcap = std::min<int64_t>(b.cap, up64(b.cap / 5) + 64);
+            b.kmax = std::min<int64_t>(b.cap, std::max<int64_t>(64, up64(b.cap / kdiv)));
+            b.rcap = std::min<int64_t>(b.cap, up64(b.cap / rdiv) + 64);
             return 8.0 * ((double)b.cap * b.cap + 3.0 * (double)b.cap * b.kmax + (double)b.cap * b.rcap + 4.0 * (double)b.rcap * b.rcap + 3.0 * (double)b.kmax * b.kmax +
                           0.5 * (double)std::max(b.rcap, b.kmax) * std::max(b.rcap, b.kmax)) + 64.0 * (double)b.cap + 48.0 * (double)std::max<int64_t>(1 << 16, N / 16 + 1024);
         };
@@ -876,12 +877,18 @@ struct Solver {
         if (!SWOK(hipMemGetInfo(&free_b, &total_b))) free_b = 0;
         const double budget = 0.92 * (double)free_b;
         const double want = envd("FNN_SW_CAP", 0.0);
-        double chosen = 3.25;
-        for (double fct : {6.0, 5.0, 4.5, 4.0, 3.5, 3.25}) {
-            chosen = want > 0.0 ? want : fct;
-            if (want > 0.0 || sized(fct) <= budget) break;
+        // {capacity / n, block = capacity / kdiv, departed columns = capacity / rdiv}: the roomy shapes first; where memory is
+        // short (32768 taxa) a shape with smaller side buffers buys capacity (4 n instead of 3.5 n)
+        struct Shape { double f; int kdiv, rdiv; };
+        const Shape shapes[] = {{6.0, 12, 5}, {5.0, 12, 5}, {4.5, 12, 5}, {4.0, 12, 5}, {4.0, 16, 8}, {3.5, 12, 5}, {3.25, 12, 5}};
+        Shape pick = shapes[6];
+        for (const Shape& sh : shapes) {
+            pick = sh;
+            if (want > 0.0) { pick.f = want; break; }
+            if (sized(sh.f, sh.kdiv, sh.rdiv) <= budget) break;
         }
-        (void)sized(chosen);
+        (void)sized(pick.f, pick.kdiv, pick.rdiv);
+        rfrac = std::min(rfrac, 0.75 * (double)b.rcap / (double)b.cap);  // (the departed columns' buffers bound how many may stay in the factor)
         if (log) std::fprintf(stderr, "  [sw] capacity %lld splits (%.2f n), block <= %lld, departed <= %lld; device memory free %.1f GB\n", (long long)b.cap,
                               (double)b.cap / n, (long long)b.kmax, (long long)b.rcap, (double)free_b * 1e-9);
         if (rocblas_create_handle(&b.bh) != rocblas_status_success) return false;
