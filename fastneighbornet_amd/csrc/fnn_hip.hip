@@ -1545,7 +1545,10 @@ __device__ __forceinline__ void rx_helper_workgroup(const Dev& d, ChainLds<CH_EP
     }
 }
 
-__device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds<CH_EPT>& L, Cand best, int nhelp = 0, unsigned jobtag = 0) {
+// HELP: the kernel was launched with the helper workgroups (its own instantiation: the variant without them carries none of
+// that code - inlined into k_track it cost the hot path ten spilled registers and 2 % of the run on inputs without ties)
+template <bool HELP>
+__device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds<CH_EPT>& L, Cand best, unsigned jobtag) {
     State& lst = S.lst;
     Dev dl = d;
     dl.st = &lst;
@@ -1652,7 +1655,7 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
     __syncthreads();
     DEC_TICK(2);
     const bool want_exact = lst.ev_active && !lst.ev_finish && !S.cert;
-    if (nhelp > 0 && !want_exact && tid == 0) job_post(d, jobtag, 0u);  // the helpers may leave
+    if (HELP && !want_exact && tid == 0) job_post(d, jobtag, 0u);  // the helpers may leave
     if (!lst.ev_active) return;  // the loop has ended
     if (lst.ev_finish) {         // the special finish: planned inside pick; only the symbolic replay is left
         if (tid < 64) build_targets_wave(lst);
@@ -1663,7 +1666,7 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
         // rare: the <= 4 sums exactly, one after the other in this workgroup; their addends go to the chain buffers first
         const int32_t z[4] = {lst.sa, lst.sap, lst.sb, lst.sbp};
         const int32_t m_old = lst.m_old, twoP_old = 2 * lst.P_old;
-        if (nhelp > 0) {
+        if (HELP) {
             // the four sums by the four helper workgroups, side by side: each gathers its own row and sums it
             const unsigned mask = (z[0] >= 0 ? 1u : 0u) | (z[1] >= 0 ? 2u : 0u) | (z[2] >= 0 ? 4u : 0u) | (z[3] >= 0 ? 8u : 0u);
             if (tid == 0) {
@@ -2107,25 +2110,26 @@ __global__ __launch_bounds__(RL_T) void k_relaxed(Dev d, int ticks) {
 
 // ------------------------------------------------------------------ k_decide
 // the decide step of an event that scanned: the scan's (or all ranks') candidate records are reduced first
-__global__ __launch_bounds__(CH_T) void k_decide(Dev d, const Cand* src, int nrecs, int nhelp, unsigned jobtag) {
+template <bool HELP>
+__global__ __launch_bounds__(CH_T) void k_decide(Dev d, const Cand* src, int nrecs, unsigned jobtag) {
     __shared__ ChainLds<CH_EPT> L;
     __shared__ DecideLds S;
     __shared__ Cand shc[CH_T / 64];
     __shared__ unsigned hword;
     State* st = d.st;
-    if (blockIdx.x > 0) {  // a helper workgroup of the exact ComputeRx sums (see decide_step)
+    if (HELP && blockIdx.x > 0) {  // a helper workgroup of the exact ComputeRx sums (see decide_step)
         rx_helper_workgroup(d, L, (int)blockIdx.x - 1, jobtag, &hword);
         return;
     }
     if (st->stall || st->la_hit) {  // (nothing to decide / the tail of k_track has decided this event already)
-        if (nhelp > 0 && threadIdx.x == 0) job_post(d, jobtag, 0u);
+        if (HELP && threadIdx.x == 0) job_post(d, jobtag, 0u);
         return;
     }
     state_in(S.lst, st);
     if (threadIdx.x == 0) S.tkon = 0;
     Cand best = reduce_records(d, src, st->rl_active ? 1 : nrecs, shc);  // (Relaxed mode: the search's one record)
     __syncthreads();
-    decide_step(d, S, L, best, nhelp, jobtag);
+    decide_step<HELP>(d, S, L, best, jobtag);
     __syncthreads();
     if (threadIdx.x == 0) S.lst.rl_active = 0;
     __syncthreads();
@@ -2190,7 +2194,8 @@ __device__ __forceinline__ void sweep_exact_item(const Dev& d, int64_t r, const 
 
 constexpr int TRK_REC_U = 1024;  // offset of the swept-pair records in d.recs
 
-__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed, int has_scan, int tgroup, int ticks, int nhelp, unsigned jobtag) {
+template <bool HELP>
+__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed, int has_scan, int tgroup, int ticks, unsigned jobtag) {
     __shared__ ChainLds<CH_EPT> L;
     __shared__ DecideLds S;
     __shared__ Cand sh[TRK_THREADS / 64], shu[TRK_THREADS / 64];
@@ -2202,8 +2207,8 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         chain_workgroup(d, L);
         return;
     }
-    const int wg = (int)blockIdx.x - 1, G = (int)gridDim.x - 1 - nhelp;
-    if (wg >= G) {  // a helper workgroup of the exact ComputeRx sums (see decide_step)
+    const int wg = (int)blockIdx.x - 1, G = (int)gridDim.x - 1 - (HELP ? TRK_NHELP : 0);
+    if (HELP && wg >= G) {  // a helper workgroup of the exact ComputeRx sums (see decide_step)
         rx_helper_workgroup(d, L, wg - G, jobtag, &hword);
         return;
     }
@@ -2221,7 +2226,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     if (st->done) {
         if (wg == 0 && threadIdx.x == 0) {
             st->ev_active = 0;  // (a launch sequence without a decide kernel must not replay the last event)
-            if (nhelp > 0) job_post(d, jobtag, 0u);
+            if (HELP) job_post(d, jobtag, 0u);
         }
         return;
     }
@@ -2231,13 +2236,13 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     if (!has_scan && st->stall) {  // (the launch sequence has no scan kernels and the window is gone: nothing to do)
         if (wg == 0 && threadIdx.x == 0) {
             st->n_stalled++;
-            if (nhelp > 0) job_post(d, jobtag, 0u);
+            if (HELP) job_post(d, jobtag, 0u);
         }
         return;
     }
     if (force_base || !la_active(*st)) {
         if (wg == 0 && threadIdx.x == 0) {
-            if (nhelp > 0) job_post(d, jobtag, 0u);
+            if (HELP) job_post(d, jobtag, 0u);
             st->ev_timed = timed;
             if (st->la_valid) st->la_prev_end = 0;  // the window ends on schedule
             la_prepare_base(*st, d.lacnt);
@@ -2428,8 +2433,8 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     TRK_TICK(6);
     // the window has certified the minimum: Cx / Cy, the 4-candidate choice and the merge plan follow at once
     // (the launch sequence of a window event has no decide kernel); otherwise the event scans (or stalls)
-    if (lst.la_hit) decide_step(d, S, L, best, nhelp, jobtag);
-    else if (nhelp > 0 && threadIdx.x == 0) job_post(d, jobtag, 0u);  // (the event scans or stalls: nothing for the helpers)
+    if (lst.la_hit) decide_step<HELP>(d, S, L, best, jobtag);
+    else if (HELP && threadIdx.x == 0) job_post(d, jobtag, 0u);  // (the event scans or stalls: nothing for the helpers)
     TRK_TICK(7);
     if (prof) {
         for (int q = 0; q < 8; q++) d.ticks[q] += S.tk[q + 1] - S.tk[q];
@@ -3200,8 +3205,12 @@ struct HipBackend {
         const bool has_scan = sched || !screen || !skip_unsched_scans;
         if (d.la) timed(TC_TRACK, tall, [&]() {
             track_tag = (track_tag % 0x7FFFFFEu) + 1u;  // (never 0: the JOB word starts out as 0)
-            hipLaunchKernelGGL(k_track, dim3(track_grid + 1 + rx_helpers), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0, has_scan ? 1 : 0,
-                               track_group, ticks ? 1 : 0, rx_helpers, track_tag);
+            if (rx_helpers > 0)
+                hipLaunchKernelGGL(k_track<true>, dim3(track_grid + 1 + TRK_NHELP), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0,
+                                   has_scan ? 1 : 0, track_group, ticks ? 1 : 0, track_tag);
+            else
+                hipLaunchKernelGGL(k_track<false>, dim3(track_grid + 1), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0,
+                                   has_scan ? 1 : 0, track_group, ticks ? 1 : 0, track_tag);
         });
         int nrecs;
         if (screen && !has_scan) nrecs = 0;  // (a window event: the tail of k_track decides; no decide kernel follows)
@@ -3250,7 +3259,8 @@ struct HipBackend {
         const bool tall = timing == 2;
         if (nrecs > 0) timed(TC_DECIDE, tall, [&]() {
             track_tag = (track_tag % 0x7FFFFFEu) + 1u;
-            hipLaunchKernelGGL(k_decide, dim3(1 + rx_helpers), dim3(CH_T), 0, stream, d, src, nrecs, rx_helpers, track_tag);
+            if (rx_helpers > 0) hipLaunchKernelGGL(k_decide<true>, dim3(1 + TRK_NHELP), dim3(CH_T), 0, stream, d, src, nrecs, track_tag);
+            else hipLaunchKernelGGL(k_decide<false>, dim3(1), dim3(CH_T), 0, stream, d, src, nrecs, track_tag);
         });
         timed(TC_UPDATE, tall, [&]() { hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d, defer_chain ? 1 : 0, ticks ? 1 : 0); });
         if (!defer_chain) timed(TC_OTHER, tall, [&]() { hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d); });

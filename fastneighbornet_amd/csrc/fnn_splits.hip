@@ -376,18 +376,46 @@ __global__ __launch_bounds__(T) void k_mask(const int2* F, int64_t f, uint8_t* m
     const int64_t p = (int64_t)blockIdx.x * T + threadIdx.x;
     if (p < f) mask[(int64_t)F[p].x * ld + F[p].y] = v;
 }
+// A lower-triangular inverse factor as COLUMN PANELS of width pw: panel q holds the rows [q pw, cap) of its pw columns,
+// column-major with leading dimension cap - q pw - the zero half above the diagonal blocks is not stored (half the memory
+// of a square - 9/16 with the eight panels used - which is what bounds the factor's capacity at 32768 taxa).  Every product with
+// the factor runs panel by panel.  pw >= cap: one panel = plain square storage (the Gram factor of the departed columns).
+struct TriStore {
+    double* base;
+    int64_t cap, pw;
+    __host__ __device__ int64_t off(int64_t q) const { return pw * (q * cap - pw * (q * (q - 1) / 2)); }
+    __host__ __device__ int64_t ld(int64_t q) const { return cap - q * pw; }
+    __host__ __device__ double* panel(int64_t q) const { return base + off(q); }
+    __host__ __device__ double* at(int64_t row, int64_t col) const {  // row >= the first row of the column's panel
+        const int64_t q = col / pw, q0 = q * pw;
+        return base + off(q) + (col - q0) * ld(q) + (row - q0);
+    }
+    static int64_t elems(int64_t cap, int64_t pw) {
+        int64_t tot = 0;
+        for (int64_t q0 = 0; q0 < cap; q0 += pw) tot += std::min(pw, cap - q0) * (cap - q0);
+        return tot;
+    }
+};
+// Y[:, q] = W[0:f, list[q]] for a panel-stored factor (rows above the column's panel are zeros)
+__global__ __launch_bounds__(T) void k_gather_cols_tri(TriStore W, int64_t f, const int32_t* list, int64_t cnt, double* Y, int64_t ldy) {
+    const int64_t r = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (r >= f) return;
+    for (int64_t q = blockIdx.y; q < cnt; q += gridDim.y) {
+        const int64_t c = list[q];
+        Y[q * ldy + r] = r >= (c / W.pw) * W.pw ? *W.at(r, c) : 0.0;
+    }
+}
+// Y[f0 + i, q] = W[f0 + i, list[q]], i < k (list[q] < f0: the rows lie inside the columns' panels)
+__global__ __launch_bounds__(T) void k_gather_rows_tri(TriStore W, int64_t f0, int64_t k, const int32_t* list, int64_t cnt, double* Y, int64_t ldy) {
+    const int64_t i = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (i >= k) return;
+    for (int64_t q = blockIdx.y; q < cnt; q += gridDim.y) Y[q * ldy + f0 + i] = *W.at(f0 + i, list[q]);
+}
 // Y[:, q] = W[0:f, list[q]] (columns of the splits that left)
 __global__ __launch_bounds__(T) void k_gather_cols(const double* W, int64_t ldw, int64_t f, const int32_t* list, int64_t cnt, double* Y, int64_t ldy) {
     const int64_t r = (int64_t)blockIdx.x * T + threadIdx.x;
     if (r >= f) return;
     for (int64_t q = blockIdx.y; q < cnt; q += gridDim.y) Y[q * ldy + r] = W[(int64_t)list[q] * ldw + r];
-}
-// Y[f0 + i, q] = W[f0 + i, list[q]], i < k (the appended rows of the columns that left)
-__global__ __launch_bounds__(T) void k_gather_rows(const double* W, int64_t ldw, int64_t f0, int64_t k, const int32_t* list, int64_t cnt, double* Y,
-                                                   int64_t ldy) {
-    const int64_t i = (int64_t)blockIdx.x * T + threadIdx.x;
-    if (i >= k) return;
-    for (int64_t q = blockIdx.y; q < cnt; q += gridDim.y) Y[q * ldy + f0 + i] = W[(int64_t)list[q] * ldw + f0 + i];
 }
 // out (m x m, ldo) = a[idx, idx] (a: lda), the sub-block of the kept rows / columns
 __global__ __launch_bounds__(T) void k_gather_sym(const double* a, int64_t lda, const int32_t* idx, int64_t m, double* out, int64_t ldo) {
@@ -523,7 +551,7 @@ __global__ __launch_bounds__(T) void k_sum_parts(const double* P, int64_t stride
 // workgroup per 256 rows and column chunk; partial sums per chunk, added up in chunk order by k_sum_parts.
 constexpr int SMALLK = 8;
 constexpr int SK_CHUNK = 2048;
-__global__ __launch_bounds__(T) void k_tri_times_small(const double* Wl, int64_t ldw, int64_t f, const double* Bm, int64_t ldb, int k, double* part) {
+__global__ __launch_bounds__(T) void k_tri_times_small(TriStore Wl, int64_t f, const double* Bm, int64_t ldb, int k, double* part) {
     const int64_t row = (int64_t)blockIdx.x * T + threadIdx.x;
     const int64_t c0 = (int64_t)blockIdx.y * SK_CHUNK;
     if ((int64_t)blockIdx.x * T + T - 1 < c0) return;  // the whole row block lies above the diagonal of this chunk: zeros (the buffer is cleared)
@@ -534,7 +562,7 @@ __global__ __launch_bounds__(T) void k_tri_times_small(const double* Wl, int64_t
         int64_t c1 = c0 + SK_CHUNK < f ? c0 + SK_CHUNK : f;
         if (row + 1 < c1) c1 = row + 1;
         for (int64_t c = c0; c < c1; c++) {
-            const double w = Wl[c * ldw + row];
+            const double w = *Wl.at(row, c);
 #pragma unroll
             for (int a = 0; a < SMALLK; a++)
                 if (a < k) acc[a] += w * Bm[(int64_t)a * ldb + c];
@@ -545,14 +573,15 @@ __global__ __launch_bounds__(T) void k_tri_times_small(const double* Wl, int64_t
     }
 }
 // out (k x f, ldo) = Tm^T (f x k) * Wl (lower triangular): one workgroup per column of Wl, Wl read once
-__global__ __launch_bounds__(T) void k_t_times_tri_small(const double* Tm, int64_t ldt, int k, const double* Wl, int64_t ldw, int64_t f, double* out, int64_t ldo) {
+__global__ __launch_bounds__(T) void k_t_times_tri_small(const double* Tm, int64_t ldt, int k, TriStore Wl, int64_t f, double* out, int64_t ldo) {
     __shared__ double sh[T / 64][SMALLK];
     const int64_t j = blockIdx.x;
     double acc[SMALLK];
 #pragma unroll
     for (int a = 0; a < SMALLK; a++) acc[a] = 0.0;
+    const double* colj = Wl.at(j, j) - 0;  // column j from its diagonal entry down (contiguous inside its panel)
     for (int64_t l = j + threadIdx.x; l < f; l += T) {
-        const double w = Wl[j * ldw + l];
+        const double w = colj[l - j];
 #pragma unroll
         for (int a = 0; a < SMALLK; a++)
             if (a < k) acc[a] += w * Tm[(int64_t)a * ldt + l];
@@ -731,7 +760,8 @@ struct Solver {
     double t_ops = 0, t_sel = 0, t_append = 0, t_solve = 0, t_dead = 0, t_refactor = 0;  // host wall clock per phase (FNN_SW_LOG)
     struct Blk {
         rocblas_handle bh = nullptr;
-        int64_t cap = 0, kmax = 0, rcap = 0, f = 0, r = 0;
+        int64_t cap = 0, kmax = 0, rcap = 0, f = 0, r = 0, pw = 0;
+        TriStore Ws{nullptr, 0, 0}, LCs{nullptr, 0, 0};  // the factor (column panels) and the Gram factor (one panel = square)
         double *W = nullptr, *B = nullptr, *Tb = nullptr, *X = nullptr, *S = nullptr, *S0 = nullptr, *Li = nullptr, *tmp2 = nullptr;
         double *Y = nullptr, *CR = nullptr, *LC = nullptr, *CRb = nullptr, *CRw = nullptr;
         double *z = nullptr, *v = nullptr, *xs = nullptr, *cK = nullptr, *lam = nullptr, *gF = nullptr;
@@ -758,32 +788,29 @@ struct Solver {
         if (rocblas_dgemv_64(bk.bh, ta, m, nn, &alpha, A, lda, xv, 1, &beta, yv, 1) != rocblas_status_success) blas_ok = false;
     }
     // panels that skip the zero half of a lower-triangular operand
-    static int64_t panel(int64_t f) { return std::max<int64_t>(1024, up64((f + 7) / 8)); }
-    // out (f x k, ldo) = Wl (f x f lower, ldw) * Bm (f x k, ldb)
-    void tri_times(const double* Wl, int64_t ldw, int64_t f, const double* Bm, int64_t ldb, int64_t k, double* out, int64_t ldo) {
+    // out (f x k, ldo) = Wl (f x f lower triangular, panel-stored) * Bm (f x k, ldb): panel by panel, each adding into the rows it reaches
+    void tri_times(const TriStore& Wl, int64_t f, const double* Bm, int64_t ldb, int64_t k, double* out, int64_t ldo) {
         const int64_t chunks = (f + SK_CHUNK - 1) / SK_CHUNK;
         if (k <= SMALLK && chunks * k * f <= bk.cap * bk.kmax) {  // a few columns: one pass over Wl (partial sums per column chunk in bk.X)
             (void)hipMemsetAsync(bk.X, 0, sizeof(double) * (size_t)(chunks * k * f), s);
-            hipLaunchKernelGGL(k_tri_times_small, dim3((unsigned)((f + T - 1) / T), (unsigned)chunks), dim3(T), 0, s, Wl, ldw, f, Bm, ldb, (int)k, bk.X);
+            hipLaunchKernelGGL(k_tri_times_small, dim3((unsigned)((f + T - 1) / T), (unsigned)chunks), dim3(T), 0, s, Wl, f, Bm, ldb, (int)k, bk.X);
             hipLaunchKernelGGL(k_sum_parts, g2(f, k), dim3(T), 0, s, bk.X, k * f, (int)chunks, f, k, 1.0, 0.0, out, ldo);
             return;
         }
-        const int64_t pb = panel(f);
-        for (int64_t p0 = 0; p0 < f; p0 += pb) {
-            const int64_t p1 = std::min(f, p0 + pb);
-            gemm(rocblas_operation_none, rocblas_operation_none, p1 - p0, k, p1, 1.0, Wl + p0, ldw, Bm, ldb, 0.0, out + p0, ldo);
+        for (int64_t q = 0, q0 = 0; q0 < f; q++, q0 += Wl.pw) {
+            const int64_t w = std::min(Wl.pw, f - q0);
+            gemm(rocblas_operation_none, rocblas_operation_none, f - q0, k, w, 1.0, Wl.panel(q), Wl.ld(q), Bm + q0, ldb, q == 0 ? 0.0 : 1.0, out + q0, ldo);
         }
     }
-    // out (k x f, ldo) = Tm^T (Tm: f x k, ldt) * Wl (f x f lower, ldw)
-    void t_times_tri(const double* Tm, int64_t ldt, int64_t k, const double* Wl, int64_t ldw, int64_t f, double* out, int64_t ldo) {
+    // out (k x f, ldo) = Tm^T (Tm: f x k, ldt) * Wl (f x f lower triangular, panel-stored)
+    void t_times_tri(const double* Tm, int64_t ldt, int64_t k, const TriStore& Wl, int64_t f, double* out, int64_t ldo) {
         if (k <= SMALLK) {
-            hipLaunchKernelGGL(k_t_times_tri_small, dim3((unsigned)f), dim3(T), 0, s, Tm, ldt, (int)k, Wl, ldw, f, out, ldo);
+            hipLaunchKernelGGL(k_t_times_tri_small, dim3((unsigned)f), dim3(T), 0, s, Tm, ldt, (int)k, Wl, f, out, ldo);
             return;
         }
-        const int64_t pb = panel(f);
-        for (int64_t p0 = 0; p0 < f; p0 += pb) {
-            const int64_t p1 = std::min(f, p0 + pb);
-            gemm(rocblas_operation_transpose, rocblas_operation_none, k, p1 - p0, f - p0, 1.0, Tm + p0, ldt, Wl + p0 + p0 * ldw, ldw, 0.0, out + p0 * ldo, ldo);
+        for (int64_t q = 0, q0 = 0; q0 < f; q++, q0 += Wl.pw) {
+            const int64_t w = std::min(Wl.pw, f - q0);
+            gemm(rocblas_operation_transpose, rocblas_operation_none, k, w, f - q0, 1.0, Tm + q0, ldt, Wl.panel(q), Wl.ld(q), 0.0, out + q0 * ldo, ldo);
         }
     }
     // C (m x nn) = beta C + alpha A^T B with a long inner dimension kk (A: kk x m, B: kk x nn): rocBLAS has no split-K form of
@@ -870,7 +897,9 @@ struct Solver {
             b.cap = up64(std::min<int64_t>(N, std::max<int64_t>({(int64_t)(factor * n) + 1024, std::min<int64_t>(8 * (int64_t)n + 64, 20000), 512})));
             b.kmax = std::min<int64_t>(b.cap, std::max<int64_t>(64, up64(b.cap / kdiv)));
             b.rcap = std::min<int64_t>(b.cap, up64(b.cap / rdiv) + 64);
-            return 8.0 * ((double)b.cap * b.cap + 3.0 * (double)b.cap * b.kmax + (double)b.cap * b.rcap + 4.0 * (double)b.rcap * b.rcap + 3.0 * (double)b.kmax * b.kmax +
+            b.pw = std::max<int64_t>(1024, up64(b.cap / 8));
+            if (const char* e = std::getenv("FNN_SW_PANEL")) { const int64_t v = std::atoll(e); if (v >= 64) b.pw = up64(v); }
+            return 8.0 * ((double)TriStore::elems(b.cap, b.pw) + 3.0 * (double)b.cap * b.kmax + (double)b.cap * b.rcap + 4.0 * (double)b.rcap * b.rcap + 3.0 * (double)b.kmax * b.kmax +
                           0.5 * (double)std::max(b.rcap, b.kmax) * std::max(b.rcap, b.kmax)) + 64.0 * (double)b.cap + 48.0 * (double)std::max<int64_t>(1 << 16, N / 16 + 1024);
         };
         size_t free_b = 0, total_b = 0;
@@ -895,12 +924,14 @@ struct Solver {
         struct HandleGuard { rocblas_handle h; ~HandleGuard() { rocblas_destroy_handle(h); } } guard{b.bh};
         rocblas_set_stream(b.bh, s);
         rocblas_set_pointer_mode(b.bh, rocblas_pointer_mode_host);
-        b.W = alloc<double>((size_t)b.cap * b.cap);
+        b.W = alloc<double>((size_t)TriStore::elems(b.cap, b.pw));
+        b.Ws = TriStore{b.W, b.cap, b.pw};
         b.B = alloc<double>((size_t)b.cap * b.kmax); b.Tb = alloc<double>((size_t)b.cap * b.kmax); b.X = alloc<double>((size_t)b.cap * b.kmax);
         b.S = alloc<double>((size_t)b.kmax * b.kmax); b.S0 = alloc<double>((size_t)b.kmax * b.kmax); b.Li = alloc<double>((size_t)b.kmax * b.kmax);
         b.tmp2 = alloc<double>((size_t)(std::max(b.rcap, b.kmax) * std::max(b.rcap, b.kmax) / 2 + 4096));
         b.Y = alloc<double>((size_t)b.cap * b.rcap);
-        b.CR = alloc<double>((size_t)b.rcap * b.rcap); b.LC = alloc<double>((size_t)b.rcap * b.rcap); b.CRb = alloc<double>((size_t)b.rcap * b.rcap); b.CRw = alloc<double>((size_t)b.rcap * b.rcap);
+        b.CR = alloc<double>((size_t)b.rcap * b.rcap); b.LC = alloc<double>((size_t)b.rcap * b.rcap);
+        b.LCs = TriStore{b.LC, b.rcap, b.rcap}; b.CRb = alloc<double>((size_t)b.rcap * b.rcap); b.CRw = alloc<double>((size_t)b.rcap * b.rcap);
         b.z = alloc<double>((size_t)b.cap); b.v = alloc<double>((size_t)b.cap); b.xs = alloc<double>((size_t)b.cap); b.cK = alloc<double>((size_t)b.cap);
         b.lam = alloc<double>((size_t)b.rcap); b.gF = alloc<double>((size_t)b.cap);
         b.dF = alloc<int2>((size_t)b.cap); b.dscr = alloc<int2>((size_t)b.cap); b.dlist = alloc<int32_t>((size_t)b.cap); b.dlist2 = alloc<int32_t>((size_t)b.cap);
@@ -947,19 +978,29 @@ struct Solver {
         // The core of an append, shared by the factor W (rows for splits that enter) and by LC (rows for columns that depart).
         // phase 1: T = Wi Bc, S = S - T^T T for a lower-triangular inverse factor Wi (f x f); phase 2: rows f .. f + k of Wi
         // from T, the Cholesky factor's inverse Li of S:  [-Li T^T Wi | Li], zeros above.
-        auto rows_phase1 = [&](const double* Wi, int64_t ldw, int64_t f, const double* Bc, int64_t ldb, int64_t k, double* Tm, int64_t ldt, double* Sm, int64_t lds) {
+        auto rows_phase1 = [&](const TriStore& Wi, int64_t f, const double* Bc, int64_t ldb, int64_t k, double* Tm, int64_t ldt, double* Sm, int64_t lds) {
             if (f == 0) return;
-            tri_times(Wi, ldw, f, Bc, ldb, k, Tm, ldt);
+            tri_times(Wi, f, Bc, ldb, k, Tm, ldt);
             tn_splitk(k, k, f, -1.0, Tm, ldt, Tm, ldt, 1.0, Sm, lds);
         };
-        auto rows_phase2 = [&](double* Wi, int64_t ldw, int64_t f, const double* Tm, int64_t ldt, const double* Lim, int64_t ldl, int64_t k) {
+        auto rows_phase2 = [&](const TriStore& Wi, int64_t f, const double* Tm, int64_t ldt, const double* Lim, int64_t ldl, int64_t k) {
             if (f > 0) {
-                t_times_tri(Tm, ldt, k, Wi, ldw, f, b.X, b.kmax);                                                              // X = T^T Wi
-                gemm(rocblas_operation_none, rocblas_operation_none, k, f, k, -1.0, Lim, ldl, b.X, b.kmax, 0.0, Wi + f, ldw);    // new rows -Li X
-                (void)hipMemset2DAsync(Wi + f * ldw, sizeof(double) * (size_t)ldw, 0, sizeof(double) * (size_t)f, (size_t)k);  // zeros above them
+                t_times_tri(Tm, ldt, k, Wi, f, b.X, b.kmax);  // X = T^T Wi
+                for (int64_t q = 0, q0 = 0; q0 < f; q++, q0 += Wi.pw) {  // new rows -Li X, panel by panel
+                    const int64_t w = std::min(Wi.pw, f - q0);
+                    gemm(rocblas_operation_none, rocblas_operation_none, k, w, k, -1.0, Lim, ldl, b.X + q0 * b.kmax, b.kmax, 0.0, Wi.panel(q) + (f - q0), Wi.ld(q));
+                }
             }
-            (void)hipMemcpy2DAsync(Wi + f + f * ldw, sizeof(double) * (size_t)ldw, Lim, sizeof(double) * (size_t)ldl, sizeof(double) * (size_t)k, (size_t)k,
-                                   hipMemcpyDeviceToDevice, s);
+            for (int64_t c0 = f; c0 < f + k;) {  // the new columns: zeros above (inside their panel), then Li
+                const int64_t q = c0 / Wi.pw, q0 = q * Wi.pw, c1 = std::min(f + k, q0 + Wi.pw);
+                if (f > q0)
+                    (void)hipMemset2DAsync(Wi.at(q0, c0), sizeof(double) * (size_t)Wi.ld(q), 0, sizeof(double) * (size_t)(f - q0), (size_t)(c1 - c0));
+                // rows [max(f, q0), f + k) of the columns c0 .. c1 (the rows of Li above a panel that starts inside the block are its zeros)
+                const int64_t r0 = std::max(f, q0);
+                (void)hipMemcpy2DAsync(Wi.at(r0, c0), sizeof(double) * (size_t)Wi.ld(q), Lim + (c0 - f) * ldl + (r0 - f), sizeof(double) * (size_t)ldl,
+                                       sizeof(double) * (size_t)(f + k - r0), (size_t)(c1 - c0), hipMemcpyDeviceToDevice, s);
+                c0 = c1;
+            }
         };
         // append the k splits at b.dF[f .. f + k) with multipliers wK (device, may be null: no screening).  Screening: the block's
         // weights in the joint sub-problem are S^-1 w_K with S the block's Schur complement - known before the rows are formed;
@@ -975,7 +1016,7 @@ struct Solver {
             hipLaunchKernelGGL(k_hblock, g2(k, k), dim3(T), 0, s, dK, k, dK, k, n, b.S, b.kmax, 0);
             if (f > 0) hipLaunchKernelGGL(k_hblock, g2(f, k), dim3(T), 0, s, b.dF, f, dK, k, n, b.B, b.cap, 0);
             lap("append.hblock");
-            rows_phase1(b.W, b.cap, f, b.B, b.cap, k, b.Tb, b.cap, b.S, b.kmax);  // T = L^-1 B = L21^T, S = H_KK - L21 L21^T
+            rows_phase1(b.Ws, f, b.B, b.cap, k, b.Tb, b.cap, b.S, b.kmax);  // T = L^-1 B = L21^T, S = H_KK - L21 L21^T
             lap("append.W*B+syrk");
             (void)hipMemcpy2DAsync(b.S0, sizeof(double) * (size_t)b.kmax, b.S, sizeof(double) * (size_t)b.kmax, sizeof(double) * (size_t)k, (size_t)k,
                                    hipMemcpyDeviceToDevice, s);
@@ -1024,12 +1065,12 @@ struct Solver {
                 (void)hipStreamSynchronize(s);
             }
             hipLaunchKernelGGL(k_gather, g1(k), dim3(T), 0, s, dK, k, atwd, ld, b.cK);
-            rows_phase2(b.W, b.cap, f, Tuse, b.cap, b.Li, b.kmax, k);
+            rows_phase2(b.Ws, f, Tuse, b.cap, b.Li, b.kmax, k);
             if (f > 0) gemv(rocblas_operation_transpose, f, k, -1.0, Tuse, b.cap, b.z, 1.0, b.cK);  // c_K - L21 z
             gemv(rocblas_operation_none, k, k, 1.0, b.Li, b.kmax, b.cK, 0.0, b.z + f);                // z_K = L22^-1 (c_K - L21 z)
             lap("append.rows");
             if (b.r > 0) {  // the departed columns grow by the new rows; so does their Gram matrix
-                hipLaunchKernelGGL(k_gather_rows, g2(k, b.r), dim3(T), 0, s, b.W, b.cap, f, k, b.dlist, b.r, b.Y, b.cap);
+                hipLaunchKernelGGL(k_gather_rows_tri, g2(k, b.r), dim3(T), 0, s, b.Ws, f, k, b.dlist, b.r, b.Y, b.cap);
                 const double one = 1.0;
                 if (rocblas_dsyrk_64(b.bh, rocblas_fill_lower, rocblas_operation_transpose, b.r, k, &one, b.Y + f, b.cap, &one, b.CR, b.rcap) != rocblas_status_success)
                     blas_ok = false;
@@ -1077,7 +1118,7 @@ struct Solver {
             const int64_t nn = (int64_t)idxs.size(), r = b.r, f = b.f;
             lap(nullptr);
             (void)hipMemcpyAsync(b.dlist + r, idxs.data(), sizeof(int32_t) * (size_t)nn, hipMemcpyHostToDevice, s);
-            hipLaunchKernelGGL(k_gather_cols, g2(f, nn), dim3(T), 0, s, b.W, b.cap, f, b.dlist + r, nn, b.Y + r * b.cap, b.cap);
+            hipLaunchKernelGGL(k_gather_cols_tri, g2(f, nn), dim3(T), 0, s, b.Ws, f, b.dlist + r, nn, b.Y + r * b.cap, b.cap);
             // CR[r : r + nn, 0 : r + nn] = YN^T [Y, YN]
             tn_splitk(nn, r + nn, f, 1.0, b.Y + r * b.cap, b.cap, b.Y, b.cap, 0.0, b.CR + r, b.rcap);
             (void)hipStreamSynchronize(s);  // (idxs may be a temporary)
@@ -1089,10 +1130,10 @@ struct Solver {
                 hipLaunchKernelGGL(k_transpose_small, g2(nn, r), dim3(T), 0, s, b.CR + r, b.rcap, nn, r, b.B, b.cap);  // (r x nn)
                 (void)hipMemcpy2DAsync(b.S, sizeof(double) * (size_t)b.kmax, b.CR + r + r * b.rcap, sizeof(double) * (size_t)b.rcap, sizeof(double) * (size_t)nn,
                                        (size_t)nn, hipMemcpyDeviceToDevice, s);
-                rows_phase1(b.LC, b.rcap, r, b.B, b.cap, nn, b.Tb, b.cap, b.S, b.kmax);
+                rows_phase1(b.LCs, r, b.B, b.cap, nn, b.Tb, b.cap, b.S, b.kmax);
                 if (invchol(b.S, b.kmax, b.Li, b.kmax, nn) != 0) { b.r = r + nn; fine = factor_gram(); }
                 else {
-                    rows_phase2(b.LC, b.rcap, r, b.Tb, b.cap, b.Li, b.kmax, nn);
+                    rows_phase2(b.LCs, r, b.Tb, b.cap, b.Li, b.kmax, nn);
                     b.r = r + nn;
                 }
             }
@@ -1116,10 +1157,9 @@ struct Solver {
                 gemv(rocblas_operation_none, f, r, -1.0, b.Y, b.cap, b.lam, 1.0, b.v);
                 vv = b.v;
             }
-            const int64_t pb = panel(f);
-            for (int64_t p0 = 0; p0 < f; p0 += pb) {
-                const int64_t p1 = std::min(f, p0 + pb);
-                gemv(rocblas_operation_transpose, f - p0, p1 - p0, 1.0, b.W + p0 + p0 * b.cap, b.cap, vv + p0, 0.0, b.xs + p0);
+            for (int64_t q = 0, q0 = 0; q0 < f; q++, q0 += b.Ws.pw) {
+                const int64_t w = std::min(b.Ws.pw, f - q0);
+                gemv(rocblas_operation_transpose, f - q0, w, 1.0, b.Ws.panel(q), b.Ws.ld(q), vv + q0, 0.0, b.xs + q0);
             }
             (void)hipMemcpyAsync(out.data(), b.xs, sizeof(double) * (size_t)f, hipMemcpyDeviceToHost, s);
             (void)hipStreamSynchronize(s);

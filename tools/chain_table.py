@@ -15,7 +15,7 @@ import numpy as np
 
 
 def short(name):
-    for k in ("k_track", "k_screen", "k_emit", "k_resolve", "k_scan", "k_rx_fill", "k_decide4", "k_update",
+    for k in ("k_track", "k_screen", "k_emit", "k_resolve", "k_scan", "k_rx_fill", "k_decide4", "k_decide", "k_update",
               "k_finalize", "k_chain_flush", "k_init", "k_prep_screen", "k_synth", "k_events"):
         if k in name:
             return k
