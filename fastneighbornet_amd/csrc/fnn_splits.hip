@@ -797,9 +797,12 @@ struct Solver {
             hipLaunchKernelGGL(k_sum_parts, g2(f, k), dim3(T), 0, s, bk.X, k * f, (int)chunks, f, k, 1.0, 0.0, out, ldo);
             return;
         }
-        for (int64_t q = 0, q0 = 0; q0 < f; q++, q0 += Wl.pw) {
-            const int64_t w = std::min(Wl.pw, f - q0);
-            gemm(rocblas_operation_none, rocblas_operation_none, f - q0, k, w, 1.0, Wl.panel(q), Wl.ld(q), Bm + q0, ldb, q == 0 ? 0.0 : 1.0, out + q0, ldo);
+        // column chunks of about f / 8 (never across a storage panel): the zero triangle above a chunk's diagonal is the only waste
+        const int64_t gw = std::min(Wl.pw, std::max<int64_t>(1024, up64((f + 7) / 8)));
+        for (int64_t c0 = 0; c0 < f;) {
+            const int64_t q = c0 / Wl.pw, c1 = std::min({c0 + gw, (q + 1) * Wl.pw, f});
+            gemm(rocblas_operation_none, rocblas_operation_none, f - c0, k, c1 - c0, 1.0, Wl.at(c0, c0), Wl.ld(q), Bm + c0, ldb, c0 == 0 ? 0.0 : 1.0, out + c0, ldo);
+            c0 = c1;
         }
     }
     // out (k x f, ldo) = Tm^T (Tm: f x k, ldt) * Wl (f x f lower triangular, panel-stored)
@@ -808,9 +811,11 @@ struct Solver {
             hipLaunchKernelGGL(k_t_times_tri_small, dim3((unsigned)f), dim3(T), 0, s, Tm, ldt, (int)k, Wl, f, out, ldo);
             return;
         }
-        for (int64_t q = 0, q0 = 0; q0 < f; q++, q0 += Wl.pw) {
-            const int64_t w = std::min(Wl.pw, f - q0);
-            gemm(rocblas_operation_transpose, rocblas_operation_none, k, w, f - q0, 1.0, Tm + q0, ldt, Wl.panel(q), Wl.ld(q), 0.0, out + q0 * ldo, ldo);
+        const int64_t gw = std::min(Wl.pw, std::max<int64_t>(1024, up64((f + 7) / 8)));
+        for (int64_t c0 = 0; c0 < f;) {
+            const int64_t q = c0 / Wl.pw, c1 = std::min({c0 + gw, (q + 1) * Wl.pw, f});
+            gemm(rocblas_operation_transpose, rocblas_operation_none, k, c1 - c0, f - c0, 1.0, Tm + c0, ldt, Wl.at(c0, c0), Wl.ld(q), 0.0, out + c0 * ldo, ldo);
+            c0 = c1;
         }
     }
     // C (m x nn) = beta C + alpha A^T B with a long inner dimension kk (A: kk x m, B: kk x nn): rocBLAS has no split-K form of
@@ -895,7 +900,7 @@ struct Solver {
         // to 6 n: the factor takes cap^2 doubles, the block buffers, the departed columns and their Gram matrices 0.61 cap^2 more.
         auto sized = [&](double factor, int kdiv, int rdiv) {
             b.cap = up64(std::min<int64_t>(N, std::max<int64_t>({(int64_t)(factor * n) + 1024, std::min<int64_t>(8 * (int64_t)n + 64, 20000), 512})));
-            b.kmax = std::min<int64_t>(b.cap, std::max<int64_t>(64, up64(b.cap / kdiv)));
+            b.kmax = std::min<int64_t>({b.cap, std::max<int64_t>(64, up64(b.cap / kdiv)), (int64_t)8192});  // (a block costs 4 k^2 f beside its 4 k f^2: keep k / f small)
             b.rcap = std::min<int64_t>(b.cap, up64(b.cap / rdiv) + 64);
             b.pw = std::max<int64_t>(1024, up64(b.cap / 8));
             if (const char* e = std::getenv("FNN_SW_PANEL")) { const int64_t v = std::atoll(e); if (v >= 64) b.pw = up64(v); }
@@ -924,6 +929,7 @@ struct Solver {
         struct HandleGuard { rocblas_handle h; ~HandleGuard() { rocblas_destroy_handle(h); } } guard{b.bh};
         rocblas_set_stream(b.bh, s);
         rocblas_set_pointer_mode(b.bh, rocblas_pointer_mode_host);
+        const double t_alloc0 = log ? wall() : 0.0;
         b.W = alloc<double>((size_t)TriStore::elems(b.cap, b.pw));
         b.Ws = TriStore{b.W, b.cap, b.pw};
         b.B = alloc<double>((size_t)b.cap * b.kmax); b.Tb = alloc<double>((size_t)b.cap * b.kmax); b.X = alloc<double>((size_t)b.cap * b.kmax);
@@ -944,6 +950,7 @@ struct Solver {
                                                          64, s) != hipSuccess) return false;
         b.sort_tmp = alloc<uint8_t>(b.sort_bytes + 16);
         if (!ok) return false;
+        if (log) std::fprintf(stderr, "  [sw] buffers allocated in %.2f s\n", wall() - t_alloc0);
 
         // host state: the factor's splits in factor order, their weights, who left
         std::vector<int2> F;
@@ -1105,7 +1112,7 @@ struct Solver {
             upload_F(0, (int64_t)q);
             std::vector<int32_t> kept;
             while (b.f < (int64_t)q) {
-                const int64_t k = std::min<int64_t>(b.kmax, (int64_t)q - b.f);
+                const int64_t k = std::min<int64_t>({b.kmax, (int64_t)4096, (int64_t)q - b.f});
                 if (append(k, nullptr, kept) != k) return false;
             }
             (void)hipStreamSynchronize(s);

@@ -27,7 +27,7 @@ TRAJ_FIELDS = ["m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind",
 BIG_CASES = [(4096, "uniform53", 1), (4096, "dec4", 1), (16384, "uniform53", 1), (32768, "uniform53", 1),
              (4096, "uniform53", 2), (4096, "uniform53", 3), (4096, "tree", 5), (4096, "treenoise", 6), (4096, "neg", 1),
              (8192, "tree", 7), (8192, "treenoise", 8), (8192, "neg", 2), (16384, "uniform53", 2), (16384, "uniform53", 3),
-             (16384, "tree", 9), (16384, "treenoise", 10)]
+             (16384, "tree", 9), (16384, "treenoise", 10), (16384, "neg", 3)]
 
 
 
