@@ -229,46 +229,91 @@ std::vector<SplitAndWeight> splitsFromWeights(const std::vector<int32_t>& orderi
     return splits;
 }
 
-void printNexusWithSplitsAndDistances(std::FILE* out, const std::vector<int32_t>& order, const DistancesAndNames& dan,
-                                      const std::vector<SplitAndWeight>& splits) {
-    const int ntax = dan.nTaxa;
+namespace {
+
+int hostThreads() { return (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())); }
+
+// runs fn(t) for t = 0 .. count-1 on threads of its own and joins them
+template <class F>
+void onThreads(int count, F fn) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < count; t++) th.emplace_back(fn, t);
+    if (count > 0) fn(0);
+    for (auto& x : th) x.join();
+}
+
+void printTaxa(std::FILE* out, const DistancesAndNames& dan) {  // OutputPrinter.java:21-32
     std::fprintf(out, "#nexus\n\n");
-    // PrintTaxa (OutputPrinter.java:21-32)
-    std::fprintf(out, "BEGIN Taxa;\nDIMENSIONS ntax=%d;\nTAXLABELS\n", ntax);
-    for (int i = 0; i < ntax; i++) std::fprintf(out, "[%d] '%s'\n", i + 1, dan.names[(size_t)i].c_str());
+    std::fprintf(out, "BEGIN Taxa;\nDIMENSIONS ntax=%d;\nTAXLABELS\n", dan.nTaxa);
+    for (int i = 0; i < dan.nTaxa; i++) std::fprintf(out, "[%d] '%s'\n", i + 1, dan.names[(size_t)i].c_str());
     std::fprintf(out, ";\nEND; [Taxa]\n\n");
-    // PrintDistances (:34-47)
+}
+
+// PrintDistances (:34-47): n^2 numbers, a billion at 32768 taxa.  Bands of rows are formatted by all host threads into
+// character buffers of their own and written in order.  A band is first gathered from the packed triangle into a dense
+// tile: its entries left of the diagonal are COLUMN accesses of the triangle (stride ~ n doubles), which the gather
+// walks column by column, so that the band's rows share the cache lines (88 -> 52 ns per number).
+void printDistances(std::FILE* out, const DistancesAndNames& dan) {
+    const int ntax = dan.nTaxa;
     std::fprintf(out, "BEGIN Distances;\nDIMENSIONS ntax=%d;\nFORMAT labels=no diagonal triangle=both;\nMATRIX\n", ntax);
-    {   // n^2 numbers (a billion at 32768 taxa): rows are formatted by all host threads into buffers, written in order
-        const int nth = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-        const int rows_per = ntax >= 4096 ? 16 : std::max(1, 4096 / std::max(ntax, 1));
-        std::vector<std::string> bufs((size_t)nth);
-        for (int base = 0; base < ntax; base += nth * rows_per) {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nth; t++) {
-                const int r0 = base + t * rows_per, r1 = std::min(ntax, r0 + rows_per);
-                bufs[(size_t)t].clear();
-                if (r0 >= r1) continue;
-                th.emplace_back([&, t, r0, r1]() {
-                    std::string& b = bufs[(size_t)t];
-                    b.reserve((size_t)(r1 - r0) * (size_t)ntax * 22);
-                    char tmp[40];
-                    for (int i = r0; i < r1; i++) {
-                        for (int j = 0; j < ntax; j++) { b.push_back(' '); b.append(tmp, (size_t)javaDoubleToChars(dan.get(i, j), tmp)); }
-                        b.push_back('\n');
-                    }
-                });
+    const int nth = hostThreads();
+    const int rows_per = ntax >= 2048 ? 32 : std::max(1, 4096 / std::max(ntax, 1));
+    std::vector<std::vector<char>> text((size_t)nth);
+    std::vector<std::vector<double>> tile((size_t)nth);
+    std::vector<size_t> len((size_t)nth);
+    for (int base = 0; base < ntax; base += nth * rows_per) {
+        onThreads(nth, [&](int t) {
+            const int r0 = std::min(ntax, base + t * rows_per), r1 = std::min(ntax, r0 + rows_per), R = r1 - r0;
+            len[(size_t)t] = 0;
+            if (R <= 0) return;
+            std::vector<double>& tl = tile[(size_t)t];
+            tl.resize((size_t)rows_per * (size_t)ntax);
+            for (int j = 0; j < r0; j++) {  // left of the band's diagonal block: entries (j, r0 .. r1-1) are adjacent
+                const double* src = dan.distances.data() + dan.upperIndex(j, r0);
+                for (int k = 0; k < R; k++) tl[(size_t)k * (size_t)ntax + (size_t)j] = src[k];
             }
-            for (auto& x : th) x.join();
-            for (int t = 0; t < nth; t++) std::fwrite(bufs[(size_t)t].data(), 1, bufs[(size_t)t].size(), out);
-        }
+            for (int i = r0; i < r1; i++) {
+                double* row = tl.data() + (size_t)(i - r0) * (size_t)ntax;
+                for (int j = r0; j < r1; j++) row[j] = dan.get(i, j);
+                if (r1 < ntax) std::memcpy(row + r1, dan.distances.data() + dan.upperIndex(i, r1), sizeof(double) * (size_t)(ntax - r1));
+            }
+            std::vector<char>& b = text[(size_t)t];
+            b.resize((size_t)rows_per * ((size_t)ntax * 27 + 1));  // " " + at most 26 characters per number
+            char* o = b.data();
+            for (int k = 0; k < R; k++) {
+                const double* row = tl.data() + (size_t)k * (size_t)ntax;
+                for (int j = 0; j < ntax; j++) { *o++ = ' '; o += javaDoubleToChars(row[j], o); }
+                *o++ = '\n';
+            }
+            len[(size_t)t] = (size_t)(o - b.data());
+        });
+        for (int t = 0; t < nth; t++) std::fwrite(text[(size_t)t].data(), 1, len[(size_t)t], out);
     }
     std::fprintf(out, ";\nEND; [Distances]\n\n");
-    // PrintSplits (:49-69), PrintSplit (:71-85)
-    std::fprintf(out, "BEGIN Splits;\nDIMENSIONS ntax=%d nsplits=%zu;\n", ntax, splits.size());
+}
+
+void printSplitsHead(std::FILE* out, int ntax, size_t nsplits, const std::vector<int32_t>& order) {  // :49-62
+    std::fprintf(out, "BEGIN Splits;\nDIMENSIONS ntax=%d nsplits=%zu;\n", ntax, nsplits);
     std::fprintf(out, "FORMAT labels=no weights=yes confidences=no intervals=no;\nPROPERTIES fit=-1.0 cyclic;\nCYCLE");
     for (size_t i = 1; i < order.size(); i++) std::fprintf(out, " %d", order[i]);
     std::fprintf(out, ";\nMATRIX\n");
+}
+
+void printAssumptions(std::FILE* out, int ntax) {  // :87-96
+    std::fprintf(out, ";\nEND; [Splits]\n\n");
+    std::fprintf(out, "BEGIN st_Assumptions;\nuptodate;\ndisttransform=NeighborNet;\nsplitstransform=EqualAngle;\n");
+    std::fprintf(out, "SplitsPostProcess filter=dimension value=%d;\n exclude  no missing;\nautolayoutnodelabels;\nEND; [st_Assumptions]\n\n", ntax);
+}
+
+}  // namespace
+
+void printNexusWithSplitsAndDistances(std::FILE* out, const std::vector<int32_t>& order, const DistancesAndNames& dan,
+                                      const std::vector<SplitAndWeight>& splits) {
+    const int ntax = dan.nTaxa;
+    printTaxa(out, dan);
+    printDistances(out, dan);
+    // PrintSplits (:49-69), PrintSplit (:71-85)
+    printSplitsHead(out, ntax, splits.size(), order);
     int counter = 1;
     for (const SplitAndWeight& saw : splits) {
         int size = (int)saw.split.size();
@@ -278,10 +323,101 @@ void printNexusWithSplitsAndDistances(std::FILE* out, const std::vector<int32_t>
         std::fprintf(out, ",\n");
         counter++;
     }
-    std::fprintf(out, ";\nEND; [Splits]\n\n");
-    // PrintAssumptions (:87-96)
-    std::fprintf(out, "BEGIN st_Assumptions;\nuptodate;\ndisttransform=NeighborNet;\nsplitstransform=EqualAngle;\n");
-    std::fprintf(out, "SplitsPostProcess filter=dimension value=%d;\n exclude  no missing;\nautolayoutnodelabels;\nEND; [st_Assumptions]\n\n", ntax);
+    printAssumptions(out, ntax);
+}
+
+// The same document straight from the weights in live index order, without the member lists (at 32768 taxa the 77 000
+// splits list 0.8 billion taxon ids: 3 GB as vectors, a minute of fprintf calls).  The positive splits are found and their
+// lines formatted by all host threads: split (i, j) is the ascending list of ordering[i+1 .. j], read off a bit set that a
+// thread extends from one split to the next of the same i; the ids' texts come out of a table.
+size_t printNexusFromWeights(std::FILE* out, const std::vector<int32_t>& order, const DistancesAndNames& dan, const double* weights) {
+    const int ntax = dan.nTaxa;
+    const double optionThreshold = 0.000001;  // FastNN.java:455
+    printTaxa(out, dan);
+    printDistances(out, dan);
+    const int nth = hostThreads();
+    struct Pos { int32_t i, j; double w; };
+    std::vector<Pos> pos;
+    {   // the positive splits in index order: thread t looks at the rows i = t, t + nth, ... (balanced: row i has n - 1 - i entries)
+        std::vector<std::vector<Pos>> part((size_t)nth);
+        onThreads(nth, [&](int t) {
+            for (int i = t; i < ntax; i += nth) {
+                const int64_t at = (int64_t)i * (ntax - 1) - (int64_t)i * (i - 1) / 2 - (i + 1);  // + j: the live index of (i, j)
+                for (int j = i + 1; j < ntax; j++)
+                    if (weights[at + j] > optionThreshold) part[(size_t)t].push_back(Pos{i, j, weights[at + j]});
+            }
+        });
+        std::vector<size_t> at((size_t)nth, 0);
+        size_t total = 0;
+        for (const auto& p : part) total += p.size();
+        pos.reserve(total);
+        for (int i = 0; i < ntax; i++) {  // rows back in order
+            const std::vector<Pos>& p = part[(size_t)(i % nth)];
+            size_t& a = at[(size_t)(i % nth)];
+            while (a < p.size() && p[a].i == i) pos.push_back(p[a++]);
+        }
+    }
+    printSplitsHead(out, ntax, pos.size(), order);
+    // " <id>" for the ids 0 .. ntax
+    std::vector<char> idtext;
+    std::vector<uint32_t> idoff((size_t)ntax + 2);
+    for (int t = 0; t <= ntax; t++) {
+        char tmp[16];
+        const int l = std::snprintf(tmp, sizeof(tmp), " %d", t);
+        idoff[(size_t)t] = (uint32_t)idtext.size();
+        idtext.insert(idtext.end(), tmp, tmp + l);
+    }
+    idoff[(size_t)ntax + 1] = (uint32_t)idtext.size();
+    const size_t idmax = (size_t)(idoff[(size_t)ntax + 1] - idoff[(size_t)ntax]);
+    const size_t words = ((size_t)ntax + 64) / 64;
+    const size_t budget = (size_t)24 << 20;  // characters per thread and round (more only for one very long line)
+    std::vector<std::vector<char>> text((size_t)nth);
+    std::vector<std::vector<uint64_t>> bits((size_t)nth, std::vector<uint64_t>(words));
+    std::vector<size_t> len((size_t)nth), from((size_t)nth + 1);
+    for (size_t next = 0; next < pos.size();) {
+        for (int t = 0; t < nth; t++) {  // deal the next splits out by their size
+            from[(size_t)t] = next;
+            size_t bound = 0;
+            while (next < pos.size()) {
+                const size_t line = 96 + (size_t)(pos[next].j - pos[next].i) * idmax;
+                if (bound > 0 && bound + line > budget) break;
+                bound += line;
+                next++;
+            }
+            len[(size_t)t] = bound;
+        }
+        from[(size_t)nth] = next;
+        onThreads(nth, [&](int t) {
+            const size_t s0 = from[(size_t)t], s1 = from[(size_t)t + 1];
+            std::vector<char>& b = text[(size_t)t];
+            if (b.size() < len[(size_t)t]) b.resize(len[(size_t)t]);
+            char* o = b.data();
+            std::vector<uint64_t>& bs = bits[(size_t)t];
+            int ci = -1, cj = -1;  // the bit set holds ordering[ci+1 .. cj]
+            for (size_t s = s0; s < s1; s++) {
+                const Pos& p = pos[s];
+                if (p.i != ci) { std::fill(bs.begin(), bs.end(), 0); ci = p.i; cj = p.i; }
+                for (; cj < p.j; cj++) { const int32_t id = order[(size_t)cj + 1]; bs[(size_t)id >> 6] |= (uint64_t)1 << (id & 63); }
+                int size = p.j - p.i;
+                if (ntax - size < size) size = ntax - size;
+                o += std::snprintf(o, 40, "[%zu, size=%d] \t ", s + 1, size);
+                o += javaDoubleToChars(p.w, o);
+                std::memcpy(o, " \t ", 3); o += 3;
+                for (size_t wd = 0; wd < words; wd++)
+                    for (uint64_t m = bs[wd]; m; m &= m - 1) {
+                        const size_t id = wd * 64 + (size_t)__builtin_ctzll(m);
+                        const uint32_t a = idoff[id], l = idoff[id + 1] - a;
+                        std::memcpy(o, idtext.data() + a, l);
+                        o += l;
+                    }
+                *o++ = ','; *o++ = '\n';
+            }
+            len[(size_t)t] = (size_t)(o - b.data());
+        });
+        for (int t = 0; t < nth; t++) std::fwrite(text[(size_t)t].data(), 1, len[(size_t)t], out);
+    }
+    printAssumptions(out, ntax);
+    return pos.size();
 }
 
 }  // namespace nnet
@@ -291,6 +427,26 @@ extern "C" {
 void fnnh_java_double(double d, char* buf) { std::snprintf(buf, 32, "%s", nnet::javaDoubleToString(d).c_str()); }
 // Nexus document for (names, D, order, live-order weights) into the file `path`; test hook. Returns the number of splits or -1.
 int32_t fnnh_write_nexus(const char* path, int32_t n, const double* D, const char* names256, const int32_t* order, const double* weights) {
+    try {
+        nnet::DistancesAndNames dan;
+        dan.nTaxa = n;
+        dan.distances.resize((size_t)n * (size_t)(n - 1) / 2);
+        for (int i = 0; i < n; i++) dan.names.emplace_back(names256 + (size_t)i * 256);
+        const int nth = nnet::hostThreads();
+        nnet::onThreads(nth, [&](int t) {
+            for (int i = t; i < n - 1; i += nth)
+                std::memcpy(dan.distances.data() + dan.upperIndex(i, i + 1), D + (size_t)i * (size_t)n + (size_t)i + 1, sizeof(double) * (size_t)(n - 1 - i));
+        });
+        std::vector<int32_t> ord(order, order + n + 1);
+        std::FILE* f = std::fopen(path, "w");
+        if (!f) return -1;
+        const size_t ns = nnet::printNexusFromWeights(f, ord, dan, weights);
+        std::fclose(f);
+        return (int32_t)ns;
+    } catch (...) { return -1; }
+}
+// the same through the member lists (splitsFromWeights + printNexusWithSplitsAndDistances); test hook
+int32_t fnnh_write_nexus_lists(const char* path, int32_t n, const double* D, const char* names256, const int32_t* order, const double* weights) {
     try {
         nnet::DistancesAndNames dan;
         dan.nTaxa = n;

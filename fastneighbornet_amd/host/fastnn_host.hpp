@@ -157,6 +157,9 @@ std::vector<SplitAndWeight> splitsFromWeights(const std::vector<int32_t>& orderi
 // OutputPrinter.NexusWithSplitsAndDistances (OutputPrinter.java:8-96), written to `out`
 void printNexusWithSplitsAndDistances(std::FILE* out, const std::vector<int32_t>& order, const DistancesAndNames& dan,
                                       const std::vector<SplitAndWeight>& splits);
+// the same document from the weights in live index order (splitsFromWeights' rule), formatted by all host threads without
+// materialising the splits' member lists; returns the number of splits
+size_t printNexusFromWeights(std::FILE* out, const std::vector<int32_t>& order, const DistancesAndNames& dan, const double* weights);
 
 }  // namespace nnet
 #endif

@@ -139,11 +139,10 @@ int main(int argc, char** argv) {
             if (rc != FNN_OK) throw std::runtime_error(std::string("fastnn: ") + fnn_last_error());
         }
         const nnet::DistancesAndNames dan(fileName, nTaxa);
-        std::vector<nnet::SplitAndWeight> splits = nnet::splitsFromWeights(ordering, weights.data(), nTaxa);
         t1 = std::chrono::steady_clock::now();
         if (timeMe) std::fprintf(stderr, "Got the splits and weights in (s): %.9g\n", std::chrono::duration<double>(t1 - t0).count());
         t0 = std::chrono::steady_clock::now();
-        nnet::printNexusWithSplitsAndDistances(stdout, ordering, dan, splits);
+        (void)nnet::printNexusFromWeights(stdout, ordering, dan, weights.data());  // (splitsFromWeights + printNexusWithSplitsAndDistances, in one parallel pass)
         t1 = std::chrono::steady_clock::now();
         if (timeMe) std::fprintf(stderr, "Wrote the output in (s): %.9g\n", std::chrono::duration<double>(t1 - t0).count());
         return 0;

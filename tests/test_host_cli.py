@@ -196,3 +196,32 @@ def test_java_double_formatting_and_nexus_document(hostlib, oracle, tmp_path):
         assert ks == list(range(ks[0], ks[0] + len(ks))) and int(order[n]) not in taxa
         assert taxa == sorted(taxa)
     assert txt[-3] == "END; [st_Assumptions]" and txt[-2] == "" and txt[-1] == ""
+
+
+@pytest.mark.parametrize("n", [2, 5, 33, 300, 2100])
+def test_nexus_document_parallel_writer_equals_the_list_route(hostlib, tmp_path, n):
+    """printNexusFromWeights (what the CLI and fnnh_write_nexus run: bands of rows and groups of splits formatted by all host
+    threads, member lists never materialised) writes byte for byte the document of splitsFromWeights +
+    printNexusWithSplitsAndDistances (OutputPrinter.java:8-96 line by line) - weights on both sides of the 1e-6
+    threshold, in plain and in E notation, a random cycle; n = 2100 spans several bands and the multi-row tile gather."""
+    sig = [C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    hostlib.fnnh_write_nexus.argtypes = sig
+    hostlib.fnnh_write_nexus_lists.argtypes = sig
+    rng = np.random.default_rng(n)
+    D = rng.random((n, n)) * 10.0 ** rng.integers(-5, 9, (n, n))
+    D = D + D.T
+    np.fill_diagonal(D, 0.0)
+    order = np.concatenate([[0], rng.permutation(n) + 1]).astype(np.int32)
+    N = n * (n - 1) // 2
+    w = np.zeros(N)
+    idx = rng.choice(N, min(N, int(2.4 * n)), replace=False)
+    w[idx] = rng.random(len(idx)) * 10.0 ** rng.integers(-8, 4, len(idx))
+    names = b"".join((f"taxon {i + 1}".encode()).ljust(256, b"\0") for i in range(n))
+    args = (n, D.ctypes.data_as(C.POINTER(C.c_double)), names, order.ctypes.data_as(C.POINTER(C.c_int32)),
+            w.ctypes.data_as(C.POINTER(C.c_double)))
+    pa, pb = str(tmp_path / "a.nex"), str(tmp_path / "b.nex")
+    na = hostlib.fnnh_write_nexus(pa.encode(), *args)
+    nb = hostlib.fnnh_write_nexus_lists(pb.encode(), *args)
+    assert na == nb == int((w > 1e-6).sum())
+    a, b = open(pa, "rb").read(), open(pb, "rb").read()
+    assert a == b, next((i, a[max(0, i - 40): i + 40], b[max(0, i - 40): i + 40]) for i in range(min(len(a), len(b))) if a[i] != b[i])
