@@ -965,7 +965,8 @@ struct Solver {
         (void)hipMemsetAsync(act, 0, (size_t)n * (size_t)ld, s);
         double cmax = 0.0;
         { const Best bb = reduce_best<RD_MAX_UNMASKED>(atwd, nullptr); cmax = bb.k == INT64_MAX ? 0.0 : -bb.v; }
-        const double tol = 1e-12 * (cmax > 0.0 ? cmax : 1.0);
+        double tol = 1e-12 * (cmax > 0.0 ? cmax : 1.0);  // multipliers above it are candidates (raised to the measured noise floor, below)
+        const double tol_cap = 1e-10 * (cmax > 0.0 ? cmax : 1.0);
 
         auto upload_F = [&](int64_t from, int64_t to) {
             if (to > from) (void)hipMemcpyAsync(b.dF + from, F.data() + from, sizeof(int2) * (size_t)(to - from), hipMemcpyHostToDevice, s);
@@ -1234,6 +1235,7 @@ struct Solver {
             int64_t k = (int64_t)std::min<double>((double)b.kmax, std::max<double>((double)kmin, kfrac * (double)std::max<int64_t>(nlive, 1)));
             k = std::max<int64_t>(1, std::min<int64_t>({k, ncand, k_limit}));
             const bool no_cand = ncand == 0;
+            if (!no_cand && b.r == 0 && b.f + k > b.cap && b.f < b.cap) k = b.cap - b.f;  // (nothing to rebuild away: fill the factor to the brim first)
             if ((no_cand && (wdead > tol || (drift > 1e-10 * cmax && !fresh))) || (!no_cand && (b.f + k > b.cap || (double)b.r > rfrac * (double)b.f))) {
                 // a split that left wants back in, the factor has drifted or is full of departed splits: rebuild it, solve, look again
                 if (!no_cand && b.r == 0) { good = false; break; }  // the free set outgrows the dense factor: the caller takes the reference's route
@@ -1269,6 +1271,7 @@ struct Solver {
             }
             for (int64_t q = 0; q < kin; q++) F[(size_t)(f0 + q)] = F[(size_t)(f0 + kept[(size_t)q])];
             F.resize((size_t)(f0 + kin));
+            const int2 entered = F[(size_t)f0];
             hipLaunchKernelGGL(k_mask, g1(kin), dim3(T), 0, s, b.dF + f0, kin, act, ld, (uint8_t)1);
             st_adds += kin;
             xw.resize((size_t)b.f, 0.0); dead.resize((size_t)b.f, 0); cF.resize((size_t)b.f);
@@ -1318,17 +1321,33 @@ struct Solver {
                 // the same block once more with Lawson & Hanson's step, which cannot ascend; if that made no progress either (rounding
                 // noise at this level): a quarter of the block, and a single split that does not move is set aside
                 if (ratio_mode) {
-                    if (kin == 1) { banned.push_back(first); set_mask({first}, 1); }
+                    if (kin == 1) {
+                        // One split, the step that cannot ascend, and still no descent: the objective no longer resolves what this
+                        // multiplier is worth.  If the block's largest multiplier is below 1e-10 max|A^T d| (a tenth of what the
+                        // Kuhn-Tucker certificate of the tests allows), that level IS the noise floor of this problem - tree-like
+                        // distances at 32768 taxa: objective 9e10, changes in its 14th digit, thousands of such candidates, each
+                        // worth a step - and becomes the candidates' threshold; a larger one is set aside until a step moves.
+                        double wtop = 0.0;
+                        (void)hipMemcpyAsync(&wtop, b.ckey2, sizeof(double), hipMemcpyDeviceToHost, s);
+                        (void)hipStreamSynchronize(s);
+                        if (wtop <= tol_cap) {
+                            if (log) std::fprintf(stderr, "  [sw] noise floor: candidates' threshold %.3g -> %.3g (%.3g max|A^T d|)\n", tol, wtop, wtop / (cmax > 0.0 ? cmax : 1.0));
+                            tol = std::max(tol, wtop);
+                        } else {
+                            banned.push_back(entered); set_mask({entered}, 1);
+                        }
+                    }
                     k_limit = std::max<int64_t>(1, kin / 4);
                 } else {
                     ratio_mode = true; k_limit = kin;
                 }
                 continue;
             }
+            const bool moved = phi - phi_new > 1e-13 * std::fabs(phi);  // (a descent in the last digits is not progress)
             phi = phi_new; xw = sbuf; fresh = false;
             k_limit = k_limit > b.kmax / 2 ? b.kmax : 2 * k_limit;
             ratio_mode = ratio_mode && ncand <= 2 * kmin;  // near the end (few candidates, each displacing one split) the guaranteed step stays on
-            if (!banned.empty()) { set_mask(banned, 0); banned.clear(); }  // progress: the splits set aside may be looked at again
+            if (moved && !banned.empty()) { set_mask(banned, 0); banned.clear(); }  // progress: the splits set aside may be looked at again
             if (log && (st_lh_steps % 10 == 0 || st_lh_steps < 5))
                 std::fprintf(stderr, "  [sw] step %lld: |F| = %lld (+%lld departed in the factor) candidates %lld block %lld solves %lld objective %.12g | ops %.2f sel %.2f "
                              "append %.2f solve %.2f depart %.2f refactor %.2f s\n", (long long)st_lh_steps, (long long)(b.f - b.r), (long long)b.r, (long long)ncand,
@@ -1443,6 +1462,8 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
     if (S.reduce_sum<RD_COUNT_NEG>(S.x, nullptr) != 0.0) {
         from_below = !std::getenv("FNN_SW_REFERENCE_METHOD") && S.block_active_set();
         if (!from_below) {
+            if (std::getenv("FNN_SW_NO_REFERENCE_ROUTE"))  // (development: at BASELINE sizes the reference's route runs for hours)
+                return fnn::fail(FNN_ENOMEM, "fnn_split_weights_f64: the free set outgrew the dense factor (FNN_SW_NO_REFERENCE_ROUTE is set)");
             S.release_block_buffers();
             S.w = S.alloc<double>(NN); S.p = S.alloc<double>(NN); S.old_x = S.alloc<double>(NN);
             if (!S.ok) return fnn::fail(FNN_ENOMEM, "fnn_split_weights_f64: device allocation failed");

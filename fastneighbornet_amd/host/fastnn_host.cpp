@@ -287,7 +287,8 @@ void printDistances(std::FILE* out, const DistancesAndNames& dan) {
             }
             len[(size_t)t] = (size_t)(o - b.data());
         });
-        for (int t = 0; t < nth; t++) std::fwrite(text[(size_t)t].data(), 1, len[(size_t)t], out);
+        for (int t = 0; t < nth; t++)
+            if (len[(size_t)t]) std::fwrite(text[(size_t)t].data(), 1, len[(size_t)t], out);
     }
     std::fprintf(out, ";\nEND; [Distances]\n\n");
 }
@@ -414,7 +415,8 @@ size_t printNexusFromWeights(std::FILE* out, const std::vector<int32_t>& order, 
             }
             len[(size_t)t] = (size_t)(o - b.data());
         });
-        for (int t = 0; t < nth; t++) std::fwrite(text[(size_t)t].data(), 1, len[(size_t)t], out);
+        for (int t = 0; t < nth; t++)
+            if (len[(size_t)t]) std::fwrite(text[(size_t)t].data(), 1, len[(size_t)t], out);
     }
     printAssumptions(out, ntax);
     return pos.size();

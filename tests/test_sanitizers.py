@@ -65,4 +65,4 @@ def test_emulation_under_asan_ubsan(san_libs):
 
 def test_host_side_under_asan_ubsan(san_libs):
     rt, _, host = san_libs
-    _run(rt, {"FNN_HOST_LIB": host}, ["tests/test_host_cli.py", "-m", "not gpu", "-k", "reader or formatting"])
+    _run(rt, {"FNN_HOST_LIB": host}, ["tests/test_host_cli.py", "-m", "not gpu", "-k", "reader or formatting or parallel_writer"])
