@@ -444,6 +444,20 @@ __global__ __launch_bounds__(T) void k_copy_lower(const double* a, int64_t lda, 
     if (r >= m) return;
     for (int64_t c = blockIdx.y; c < m; c += gridDim.y) b[c * ldb + r] = r >= c ? a[c * lda + r] : 0.0;
 }
+// rows x cols block (column-major: the rows of a column are adjacent) filled / copied by kernels: the runtime's 2-D fill
+// (hipMemset2DAsync -> fillBufferAligned2D) ran at 6 GB/s on the pitched blocks of the factor - 209 ms for the 1.2 GB of zeros
+// above a block's new columns, 6.8 s of a 32768-taxon solve (profiles/r03/r03_splits_kernel_stats_n32768.csv) - and the 2-D
+// device-to-device copies go through the copy engines.
+__global__ __launch_bounds__(T) void k_fill2d(double* dst, int64_t ldd, int64_t rows, int64_t cols, double v) {
+    const int64_t r = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (r >= rows) return;
+    for (int64_t c = blockIdx.y; c < cols; c += gridDim.y) dst[c * ldd + r] = v;
+}
+__global__ __launch_bounds__(T) void k_copy2d(const double* src, int64_t lds_, double* dst, int64_t ldd, int64_t rows, int64_t cols) {
+    const int64_t r = (int64_t)blockIdx.x * T + threadIdx.x;
+    if (r >= rows) return;
+    for (int64_t c = blockIdx.y; c < cols; c += gridDim.y) dst[c * ldd + r] = src[c * lds_ + r];
+}
 constexpr int TRI_NB = 64;
 // inverse of the Cholesky factor of a symmetric positive definite m x m block (m <= 64; lower triangle of S read):
 // Li (lower triangular, zeros above) with Li^T Li = S^-1.  ONE wave; lane t owns ROW t of the matrix in registers (every index
@@ -861,7 +875,7 @@ struct Solver {
         gemm(rocblas_operation_none, rocblas_operation_none, m2, m1, m1, 1.0, t1, m2, Li, ldl, 0.0, t2, m2);                    // L21 Li11
         invchol_rec(S22, lds, Li22, ldl, m2, off + m1);
         gemm(rocblas_operation_none, rocblas_operation_none, m2, m1, m2, -1.0, Li22, ldl, t2, m2, 0.0, Li21, ldl);              // Li21 = -Li22 L21 Li11
-        (void)hipMemset2DAsync(Li + m1 * ldl, sizeof(double) * (size_t)ldl, 0, sizeof(double) * (size_t)m1, (size_t)m2);
+        hipLaunchKernelGGL(k_fill2d, g2(m1, m2), dim3(T), 0, s, Li + m1 * ldl, ldl, m1, m2, 0.0);
     }
     int64_t invchol(double* S, int64_t lds, double* Li, int64_t ldl, int64_t m) {  // 0, or the 1-based position of the first pivot that is not positive
         if (m <= 0) return 0;
@@ -1002,11 +1016,10 @@ struct Solver {
             for (int64_t c0 = f; c0 < f + k;) {  // the new columns: zeros above (inside their panel), then Li
                 const int64_t q = c0 / Wi.pw, q0 = q * Wi.pw, c1 = std::min(f + k, q0 + Wi.pw);
                 if (f > q0)
-                    (void)hipMemset2DAsync(Wi.at(q0, c0), sizeof(double) * (size_t)Wi.ld(q), 0, sizeof(double) * (size_t)(f - q0), (size_t)(c1 - c0));
+                    hipLaunchKernelGGL(k_fill2d, g2(f - q0, c1 - c0), dim3(T), 0, s, Wi.at(q0, c0), Wi.ld(q), f - q0, c1 - c0, 0.0);
                 // rows [max(f, q0), f + k) of the columns c0 .. c1 (the rows of Li above a panel that starts inside the block are its zeros)
                 const int64_t r0 = std::max(f, q0);
-                (void)hipMemcpy2DAsync(Wi.at(r0, c0), sizeof(double) * (size_t)Wi.ld(q), Lim + (c0 - f) * ldl + (r0 - f), sizeof(double) * (size_t)ldl,
-                                       sizeof(double) * (size_t)(f + k - r0), (size_t)(c1 - c0), hipMemcpyDeviceToDevice, s);
+                hipLaunchKernelGGL(k_copy2d, g2(f + k - r0, c1 - c0), dim3(T), 0, s, Lim + (c0 - f) * ldl + (r0 - f), ldl, Wi.at(r0, c0), Wi.ld(q), f + k - r0, c1 - c0);
                 c0 = c1;
             }
         };
@@ -1026,8 +1039,7 @@ struct Solver {
             lap("append.hblock");
             rows_phase1(b.Ws, f, b.B, b.cap, k, b.Tb, b.cap, b.S, b.kmax);  // T = L^-1 B = L21^T, S = H_KK - L21 L21^T
             lap("append.W*B+syrk");
-            (void)hipMemcpy2DAsync(b.S0, sizeof(double) * (size_t)b.kmax, b.S, sizeof(double) * (size_t)b.kmax, sizeof(double) * (size_t)k, (size_t)k,
-                                   hipMemcpyDeviceToDevice, s);
+            hipLaunchKernelGGL(k_copy2d, g2(k, k), dim3(T), 0, s, b.S, b.kmax, b.S0, b.kmax, k, k);
             const double* wcur = wK;
             std::vector<double> sK;
             bool changed = false;
@@ -1136,8 +1148,7 @@ struct Solver {
             if (r == 0 || nn > b.kmax) { b.r = r + nn; fine = factor_gram(); }
             else {  // border the inverse factor: cross block CR[r:, 0:r]^T, diagonal block CR[r:, r:]
                 hipLaunchKernelGGL(k_transpose_small, g2(nn, r), dim3(T), 0, s, b.CR + r, b.rcap, nn, r, b.B, b.cap);  // (r x nn)
-                (void)hipMemcpy2DAsync(b.S, sizeof(double) * (size_t)b.kmax, b.CR + r + r * b.rcap, sizeof(double) * (size_t)b.rcap, sizeof(double) * (size_t)nn,
-                                       (size_t)nn, hipMemcpyDeviceToDevice, s);
+                hipLaunchKernelGGL(k_copy2d, g2(nn, nn), dim3(T), 0, s, b.CR + r + r * b.rcap, b.rcap, b.S, b.kmax, nn, nn);
                 rows_phase1(b.LCs, r, b.B, b.cap, nn, b.Tb, b.cap, b.S, b.kmax);
                 if (invchol(b.S, b.kmax, b.Li, b.kmax, nn) != 0) { b.r = r + nn; fine = factor_gram(); }
                 else {
@@ -1260,8 +1271,7 @@ struct Solver {
             const std::vector<uint8_t> dead0 = dead;
             const std::vector<double> x0 = xw;
             const std::vector<int32_t> deadlist0 = deadlist;
-            if (r0 > 0) (void)hipMemcpy2DAsync(b.CRb, sizeof(double) * (size_t)b.rcap, b.CR, sizeof(double) * (size_t)b.rcap, sizeof(double) * (size_t)r0, (size_t)r0,
-                                               hipMemcpyDeviceToDevice, s);
+            if (r0 > 0) hipLaunchKernelGGL(k_copy2d, g2(r0, r0), dim3(T), 0, s, b.CR, b.rcap, b.CRb, b.rcap, r0, r0);
             std::vector<int32_t> kept;
             const int64_t kin = append(k, b.ckey2, kept);
             if (kin < 0) { good = false; break; }
@@ -1316,8 +1326,7 @@ struct Solver {
                 b.f = f0; b.r = r0;
                 F.resize((size_t)f0); dead = dead0; xw = x0; deadlist = deadlist0; cF.resize((size_t)f0);
                 if (r0 > 0) {
-                    (void)hipMemcpy2DAsync(b.CR, sizeof(double) * (size_t)b.rcap, b.CRb, sizeof(double) * (size_t)b.rcap, sizeof(double) * (size_t)r0, (size_t)r0,
-                                           hipMemcpyDeviceToDevice, s);
+                    hipLaunchKernelGGL(k_copy2d, g2(r0, r0), dim3(T), 0, s, b.CRb, b.rcap, b.CR, b.rcap, r0, r0);
                     (void)hipMemcpyAsync(b.dlist, deadlist.data(), sizeof(int32_t) * (size_t)r0, hipMemcpyHostToDevice, s);
                     (void)hipStreamSynchronize(s);
                     if (!factor_gram()) { good = false; break; }
