@@ -13,7 +13,7 @@ import numpy as np
 
 FNN_OK = 0
 STATUS_NAMES = {0: "FNN_OK", -1: "FNN_EINVAL", -2: "FNN_ENOMEM", -3: "FNN_EHIP", -4: "FNN_ERCCL",
-                -5: "FNN_ESTATE"}
+                -5: "FNN_ESTATE", -6: "FNN_ECAPACITY", -7: "FNN_EINEXACT"}
 
 KIND_2WAY, KIND_3WAY, KIND_4WAY, KIND_FINISH = 2, 3, 4, 5
 
@@ -52,7 +52,12 @@ class FnnStats(C.Structure):
 
 class FnnSwStats(C.Structure):
     _fields_ = [("outer_iterations", C.c_int64), ("cg_calls", C.c_int64), ("cg_iterations", C.c_int64),
-                ("nsplits", C.c_int64), ("t_solve_s", C.c_double), ("reserved", C.c_int64 * 3)]
+                ("nsplits", C.c_int64), ("t_solve_s", C.c_double), ("reserved", C.c_int64 * 3),
+                # ABI version 2
+                ("route", C.c_int32), ("certified", C.c_int32), ("kkt_violation", C.c_double), ("final_threshold_rel", C.c_double),
+                ("n_set_aside", C.c_int64), ("capacity", C.c_int64), ("free_set_peak", C.c_int64), ("giveup_reason", C.c_int32),
+                ("pad_", C.c_int32), ("entered", C.c_int64), ("screened_out", C.c_int64), ("departed", C.c_int64),
+                ("t_alloc_s", C.c_double), ("reserved2", C.c_int64 * 4)]
 
 
 EVENT_DTYPE = np.dtype(

@@ -96,10 +96,27 @@ HEADERS = [os.path.join(HERE, "csrc", "fnn_core.h"), os.path.join(HERE, "csrc", 
            os.path.join(ROOT, "include", "fastnn.h")]
 
 
+def toolchain_stamp() -> str:
+    """What the kept objects were compiled WITH: flags + compiler identity.  A change of either recompiles everything
+    (and thereby re-runs check_isa on the new compiler's output); mtimes alone would reuse stale objects."""
+    import hashlib
+    try:
+        ver = subprocess.run([hipcc(), "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    except OSError as e:  # pragma: no cover
+        ver = repr(e)
+    return hashlib.sha256((" ".join(FLAGS) + "\n" + ver).encode()).hexdigest()
+
+
 def build(force: bool = False) -> str:
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ_DIR, exist_ok=True)
+    stamp_file, stamp = os.path.join(OBJ_DIR, "toolchain.stamp"), toolchain_stamp()
+    if not (os.path.exists(stamp_file) and open(stamp_file).read().strip() == stamp):
+        # Objects without a matching stamp: other flags, another hipcc / ROCm, or a tree from before the stamp existed.  On a
+        # box that received prebuilt objects together with their stamp (the GPU box: same image) nothing is recompiled.
+        force = force or any(os.path.exists(os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(x))[0] + ".o")) for x in (SRC, SRC_SPLITS)) and \
+            os.path.exists(stamp_file)
     todo, objs = [], []
     for src in (SRC, SRC_SPLITS):
         obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
@@ -117,6 +134,8 @@ def build(force: bool = False) -> str:
                 shutil.copyfile(compile_one(src, d), obj)
             with ThreadPoolExecutor(2) as ex:
                 list(ex.map(one, todo))
+    if todo or not os.path.exists(stamp_file):
+        open(stamp_file, "w").write(stamp + "\n")
     if todo or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
         # (rocBLAS: the plain fp64 GEMM / GEMV / SYRK calls of the split-weight solver)
         subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lrocblas"])

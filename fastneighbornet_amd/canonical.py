@@ -93,13 +93,16 @@ def canonical_order(D: np.ndarray, device: int = 0, validate: bool = True) -> np
     return order
 
 
-def split_weights(D: np.ndarray, ordering: np.ndarray, device: int = 0):
+def split_weights(D: np.ndarray, ordering: np.ndarray, device: int = 0, allow_inexact: bool = False):
     """Non-negative least-squares weights of the circular splits of `ordering` over
     `fnn_split_weights_f64` (the optimum the reference's live path computes, FastNN.java:401-454, in its
     index order :405-419).  Returns (weights[n(n-1)/2], stats dict); stats["method"]: "closed form"
     (the unconstrained optimum is feasible), "from below" (the block active-set method on an inverse Cholesky
     factor of the free set) or "reference" (CircularSplitWeights.java's active-set /
-    conjugate-gradient method); stats["refactorizations"] = rebuilds of the factor, stats["solves"] = sub-problems."""
+    conjugate-gradient method); stats["refactorizations"] = rebuilds of the factor, stats["solves"] = sub-problems;
+    stats["certified"] / stats["kkt_violation"]: the solver's own Kuhn-Tucker check of the returned weights.  Raises FnnError
+    with code -6 (FNN_ECAPACITY: the optimum has more positive splits than the block method's factor holds and the
+    reference's route is not affordable at this size) or -7 (FNN_EINEXACT, unless allow_inexact)."""
     from . import api
     a = api()
     D = np.ascontiguousarray(D, dtype=np.float64)
@@ -107,10 +110,17 @@ def split_weights(D: np.ndarray, ordering: np.ndarray, device: int = 0):
     o = np.ascontiguousarray(ordering, dtype=np.int32)
     w = np.zeros(n * (n - 1) // 2, dtype=np.float64)
     st = _capi.FnnSwStats()
-    a.check(a.split_weights_f64(D.ctypes.data_as(C.POINTER(C.c_double)), n, n, o.ctypes.data_as(C.POINTER(C.c_int32)),
-                                device, w.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st)))
-    out = {k: getattr(st, k) for k, _ in st._fields_ if k != "reserved"}
-    out["method"] = "from below" if st.reserved[0] == 1 else ("reference" if st.cg_calls > 0 else "closed form")
+    rc = a.split_weights_f64(D.ctypes.data_as(C.POINTER(C.c_double)), n, n, o.ctypes.data_as(C.POINTER(C.c_int32)),
+                             device, w.ctypes.data_as(C.POINTER(C.c_double)), C.byref(st))
+    if rc == -7 and allow_inexact:   # FNN_EINEXACT: the weights are there, their Kuhn-Tucker check is above 1e-9 (stats say by how much)
+        rc = 0
+    try:
+        a.check(rc)
+    except _capi.FnnError as e:       # FNN_ECAPACITY leaves the give-up reason, the capacity and the peak of the free set in the stats
+        e.stats = {k: getattr(st, k) for k, _ in st._fields_ if not k.startswith(("reserved", "pad_"))}
+        raise
+    out = {k: getattr(st, k) for k, _ in st._fields_ if not k.startswith(("reserved", "pad_"))}
+    out["method"] = ("closed form", "from below", "reference")[st.route]
     out["refactorizations"] = int(st.reserved[1])
     out["solves"] = int(st.reserved[2])
     return w, out

@@ -297,7 +297,7 @@ class Engine {
             // brackets admit so many candidate units that the screened scan costs more than the plain one (measured, round 3:
             // 3.9 ms per event at 32768 taxa against 0.4 ms): such a run takes the plain fp64 scan for every event.
             // (FNN_SCREEN_MIN_N / FNN_SCREEN_MIN_M - the tests' way to force the screening pass on - keep it.)
-            if (dev.H && (!hst.nonneg || !hst.screen_ok) && !B::kKeepGenericScreen && !std::getenv("FNN_SCREEN_MIN_N") && !std::getenv("FNN_SCREEN_MIN_M")) {
+            if (dev.H && (!hst.nonneg || !hst.screen_ok) && !be.keep_generic_screen() && !std::getenv("FNN_SCREEN_MIN_N") && !std::getenv("FNN_SCREEN_MIN_M")) {
                 hst.la_on = 0;
                 dev.la = 0; dev.wx = 0; dev.strict = 0;
                 be.screen_off = true;

@@ -3189,7 +3189,7 @@ struct HipBackend {
         return dim3((unsigned)(nt < scan_grid ? (nt > 0 ? nt : 1) : scan_grid));
     }
     bool screen_off = false;  // set by the engine for a matrix that can open no window (negative entries): plain fp64 scans throughout
-    static constexpr bool kKeepGenericScreen = false;
+    bool keep_generic_screen() const { return false; }  // (the CPU emulation of the tests keeps the mixed-sign screening pass alive)
     bool use_screen(const Dev& d, int32_t m_bound) const { return d.H != nullptr && !screen_off && m_bound >= screen_min_m; }
     // the scan of one event; returns the number of per-workgroup records it leaves in d.recs.
     // With lookahead windows (d.la) k_track goes first: it either serves the event from the open

@@ -328,6 +328,42 @@ __global__ __launch_bounds__(T) void k_to_live(const double* x, double* live, in
     live[k] = v;
 }
 
+// The solver's own Kuhn-Tucker check of the returned weights (g = A^T (A x - d) from the implicit operators): per workgroup
+// {max -x, max |g| over x > 0, max -g over x <= 0, max |c|} over the strict upper triangle
+__global__ __launch_bounds__(T) void k_kkt(const double* x, const double* g, const double* c, int n, int64_t ld, double* partial) {
+    __shared__ double sh[T / 64][4];
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    for (int i = blockIdx.y; i < n; i += gridDim.y)
+        for (int j = blockIdx.x * T + threadIdx.x; j < n; j += gridDim.x * T) {
+            if (i >= j) continue;
+            const int64_t k = (int64_t)i * ld + j;
+            const double xv = x[k], gv = g[k], cv = fabs(c[k]);
+            if (-xv > v0 || xv != xv) v0 = xv != xv ? INFINITY : -xv;
+            if (xv > 0.0) { if (fabs(gv) > v1 || gv != gv) v1 = gv != gv ? INFINITY : fabs(gv); }
+            else if (-gv > v2 || gv != gv) v2 = gv != gv ? INFINITY : -gv;
+            if (cv > v3) v3 = cv;
+        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        v0 = fmax(v0, __shfl_down(v0, off, 64)); v1 = fmax(v1, __shfl_down(v1, off, 64));
+        v2 = fmax(v2, __shfl_down(v2, off, 64)); v3 = fmax(v3, __shfl_down(v3, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { double* q = sh[threadIdx.x >> 6]; q[0] = v0; q[1] = v1; q[2] = v2; q[3] = v3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double m = sh[0][threadIdx.x];
+        for (int q = 1; q < T / 64; q++) m = fmax(m, sh[q][threadIdx.x]);
+        partial[4 * (blockIdx.y * gridDim.x + blockIdx.x) + threadIdx.x] = m;
+    }
+}
+// a = a - c over the strict upper triangle
+__global__ __launch_bounds__(T) void k_sub(double* a, const double* c, int n, int64_t ld) {
+    const int j = blockIdx.x * T + threadIdx.x, i = blockIdx.y;
+    if (j >= n || i >= j) return;
+    const int64_t k = (int64_t)i * ld + j;
+    a[k] -= c[k];
+}
+
 // ---------------------------------------------------------------- "from below": block active-set method on the normal equations
 // The reference's method starts from the unconstrained optimum (every split free) and contracts; on distances that are
 // far from circular (random matrices: only ~2.4 n of the n(n-1)/2 splits end up with a positive weight) almost all of its
@@ -788,6 +824,11 @@ struct Solver {
     } bk;
     bool blas_ok = true;
     double gemm_flops = 0.0;
+    int giveup = 0;              // FNN_SW_GIVEUP_* of the block method
+    const char* giveup_text = "";
+    double final_tol_rel = 0.0, t_alloc_s = 0.0;
+    int64_t n_set_aside = 0, f_peak = 0, capacity = 0;
+    bool have_atwd = false;
     static int64_t up64(int64_t v) { return (v + 63) / 64 * 64; }
     static dim3 g1(int64_t c) { return dim3((unsigned)((c + T - 1) / T)); }
     static dim3 g2(int64_t rows, int64_t cols) { return dim3((unsigned)((rows + T - 1) / T), (unsigned)std::max<int64_t>(1, std::min<int64_t>(cols, 16384))); }
@@ -939,11 +980,12 @@ struct Solver {
         rfrac = std::min(rfrac, 0.75 * (double)b.rcap / (double)b.cap);  // (the departed columns' buffers bound how many may stay in the factor)
         if (log) std::fprintf(stderr, "  [sw] capacity %lld splits (%.2f n), block <= %lld, departed <= %lld; device memory free %.1f GB\n", (long long)b.cap,
                               (double)b.cap / n, (long long)b.kmax, (long long)b.rcap, (double)free_b * 1e-9);
-        if (rocblas_create_handle(&b.bh) != rocblas_status_success) return false;
+        capacity = b.cap;
+        if (rocblas_create_handle(&b.bh) != rocblas_status_success) { giveup = FNN_SW_GIVEUP_SETUP; giveup_text = "rocblas_create_handle failed"; return false; }
         struct HandleGuard { rocblas_handle h; ~HandleGuard() { rocblas_destroy_handle(h); } } guard{b.bh};
         rocblas_set_stream(b.bh, s);
         rocblas_set_pointer_mode(b.bh, rocblas_pointer_mode_host);
-        const double t_alloc0 = log ? wall() : 0.0;
+        const double t_alloc0 = wall();
         b.W = alloc<double>((size_t)TriStore::elems(b.cap, b.pw));
         b.Ws = TriStore{b.W, b.cap, b.pw};
         b.B = alloc<double>((size_t)b.cap * b.kmax); b.Tb = alloc<double>((size_t)b.cap * b.kmax); b.X = alloc<double>((size_t)b.cap * b.kmax);
@@ -961,10 +1003,11 @@ struct Solver {
         b.cidx = alloc<int64_t>((size_t)b.ccap); b.cidx2 = alloc<int64_t>((size_t)b.ccap);
         b.ccount = alloc<unsigned long long>(1);
         if (hipcub::DeviceRadixSort::SortPairsDescending(nullptr, b.sort_bytes, b.ckey, b.ckey2, b.cidx, b.cidx2, (int)std::min<int64_t>(b.ccap, INT32_MAX), 0,
-                                                         64, s) != hipSuccess) return false;
+                                                         64, s) != hipSuccess) { giveup = FNN_SW_GIVEUP_SETUP; giveup_text = "hipcub size query failed"; return false; }
         b.sort_tmp = alloc<uint8_t>(b.sort_bytes + 16);
-        if (!ok) return false;
-        if (log) std::fprintf(stderr, "  [sw] buffers allocated in %.2f s\n", wall() - t_alloc0);
+        if (!ok) { giveup = FNN_SW_GIVEUP_SETUP; giveup_text = "device allocation of the factor's buffers failed"; return false; }
+        t_alloc_s = wall() - t_alloc0;
+        if (log) std::fprintf(stderr, "  [sw] buffers allocated in %.2f s\n", t_alloc_s);
 
         // host state: the factor's splits in factor order, their weights, who left
         std::vector<int2> F;
@@ -1193,13 +1236,15 @@ struct Solver {
         };
         std::vector<double> sbuf;
         // every weight that is not positive leaves, until the sub-problem's minimiser is feasible (false: out of room / failure)
+        bool over_rcap = false;  // settle_all failed for lack of room for the departed columns (not a numerical failure)
         auto settle_all = [&]() -> bool {
+            over_rcap = false;
             for (;;) {
                 if (!solve(sbuf)) return false;
                 std::vector<int32_t> out;
                 for (size_t p = 0; p < sbuf.size(); p++) if (!dead[p] && !(sbuf[p] > 0.0)) out.push_back((int32_t)p);
                 if (out.empty()) return true;
-                if (b.r + (int64_t)out.size() > b.rcap) return false;
+                if (b.r + (int64_t)out.size() > b.rcap) { over_rcap = true; return false; }
                 st_dels += (int64_t)out.size();
                 if (!depart(out)) return false;
             }
@@ -1207,7 +1252,8 @@ struct Solver {
 
         const int64_t kmin = std::max<int64_t>(8, n / 32);
         int64_t k_limit = b.kmax;
-        bool ratio_mode = false, done = false, good = ok, fresh = false;
+        bool ratio_mode = false, done = false, good = ok, fresh = false, banned_rechecked = false;
+        auto give = [&](int why, const char* text) { giveup = why; giveup_text = text; good = false; };
         int stall = 0;  // steps in a row whose descent is not measurable (below 1e-13 |objective|)
         const int64_t max_outer = 40 * (int64_t)n + 1000;
         while (good && !done && st_lh_steps < max_outer) {
@@ -1250,15 +1296,22 @@ struct Solver {
             if (!no_cand && b.r == 0 && b.f + k > b.cap && b.f < b.cap) k = b.cap - b.f;  // (nothing to rebuild away: fill the factor to the brim first)
             if ((no_cand && (wdead > tol || (drift > 1e-10 * cmax && !fresh))) || (!no_cand && (b.f + k > b.cap || (double)b.r > rfrac * (double)b.f))) {
                 // a split that left wants back in, the factor has drifted or is full of departed splits: rebuild it, solve, look again
-                if (!no_cand && b.r == 0) { good = false; break; }  // the free set outgrows the dense factor: the caller takes the reference's route
-                if (!refactor() || !settle_all()) { good = false; break; }
+                if (!no_cand && b.r == 0) { give(FNN_SW_GIVEUP_CAPACITY, "the free set outgrew the dense factor"); break; }  // the caller decides about the reference's route
+                if (!refactor()) { give(FNN_SW_GIVEUP_NUMERIC, "rebuild of the factor failed"); break; }
+                if (!settle_all()) { give(over_rcap ? FNN_SW_GIVEUP_DEPARTED : FNN_SW_GIVEUP_NUMERIC, over_rcap ? "departed splits outgrew their buffers after a rebuild" : "sub-problem solve failed"); break; }
                 xw = sbuf; phi = objective(xw); fresh = true;
                 continue;
             }
-            if (no_cand) { done = true; break; }
+            if (no_cand) {
+                // Splits that were set aside (numerically dependent on the factor at the time, or no measurable descent) are still
+                // masked: before the method may call this the optimum they get one more look against the current factor.
+                if (!banned.empty() && !banned_rechecked) { set_mask(banned, 0); banned.clear(); banned_rechecked = true; continue; }
+                n_set_aside = (int64_t)banned.size();
+                done = true; break;
+            }
             // ---- the block: the largest local maxima of the multiplier
             if (hipcub::DeviceRadixSort::SortPairsDescending(b.sort_tmp, b.sort_bytes, b.ckey, b.ckey2, b.cidx, b.cidx2, (int)ncand, 0, 64, s) != hipSuccess) {
-                good = false; break;
+                give(FNN_SW_GIVEUP_NUMERIC, "candidate sort failed"); break;
             }
             hipLaunchKernelGGL(k_idx_to_split, g1(k), dim3(T), 0, s, b.cidx2, k, ld, b.dF + b.f);
             F.resize((size_t)(b.f + k));
@@ -1274,7 +1327,7 @@ struct Solver {
             if (r0 > 0) hipLaunchKernelGGL(k_copy2d, g2(r0, r0), dim3(T), 0, s, b.CR, b.rcap, b.CRb, b.rcap, r0, r0);
             std::vector<int32_t> kept;
             const int64_t kin = append(k, b.ckey2, kept);
-            if (kin < 0) { good = false; break; }
+            if (kin < 0) { give(FNN_SW_GIVEUP_NUMERIC, "append failed (BLAS / Cholesky)"); break; }
             if (kin == 0) {  // the first split is numerically dependent on the factor: set it aside until progress is made
                 F.resize((size_t)f0);
                 banned.push_back(first); set_mask({first}, 1);
@@ -1313,7 +1366,8 @@ struct Solver {
                     if (!depart(out)) { feasible = false; break; }
                 }
             }
-            if (!blas_ok) { good = false; break; }
+            if (!blas_ok) { give(FNN_SW_GIVEUP_NUMERIC, "a BLAS call failed"); break; }
+            f_peak = std::max(f_peak, b.f);
             const double phi_new = feasible ? objective(sbuf) : INFINITY;
             // Lawson & Hanson's step moves along the segment to the minimiser of a convex quadratic: it cannot ascend, so an
             // "ascent" in the objective's last digits is rounding and the step is taken; the other step has to descend.
@@ -1329,7 +1383,7 @@ struct Solver {
                     hipLaunchKernelGGL(k_copy2d, g2(r0, r0), dim3(T), 0, s, b.CRb, b.rcap, b.CR, b.rcap, r0, r0);
                     (void)hipMemcpyAsync(b.dlist, deadlist.data(), sizeof(int32_t) * (size_t)r0, hipMemcpyHostToDevice, s);
                     (void)hipStreamSynchronize(s);
-                    if (!factor_gram()) { good = false; break; }
+                    if (!factor_gram()) { give(FNN_SW_GIVEUP_NUMERIC, "Gram factor of the departed columns failed"); break; }
                 }
                 // the same block once more with Lawson & Hanson's step, which cannot ascend; if that made no progress either (rounding
                 // noise at this level): a quarter of the block, and a single split that does not move is set aside
@@ -1377,13 +1431,16 @@ struct Solver {
             }
             k_limit = k_limit > b.kmax / 2 ? b.kmax : 2 * k_limit;
             ratio_mode = ratio_mode && ncand <= 2 * kmin;  // near the end (few candidates, each displacing one split) the guaranteed step stays on
+            if (moved) banned_rechecked = false;
             if (moved && !banned.empty()) { set_mask(banned, 0); banned.clear(); }  // progress: the splits set aside may be looked at again
             if (log && (st_lh_steps % 10 == 0 || st_lh_steps < 5))
                 std::fprintf(stderr, "  [sw] step %lld: |F| = %lld (+%lld departed in the factor) candidates %lld block %lld solves %lld objective %.12g | ops %.2f sel %.2f "
                              "append %.2f solve %.2f depart %.2f refactor %.2f s\n", (long long)st_lh_steps, (long long)(b.f - b.r), (long long)b.r, (long long)ncand,
                              (long long)kin, (long long)st_solves, phi, t_ops, t_sel, t_append, t_solve, t_dead, t_refactor);
         }
-        if (!done) good = false;
+        if (!done && good) give(FNN_SW_GIVEUP_STEPS, "step limit reached");
+        final_tol_rel = tol / (cmax > 0.0 ? cmax : 1.0);
+        have_atwd = true;
         if (good) {  // the optimum on the grid
             (void)hipMemsetAsync(this->x, 0, sizeof(double) * (size_t)n * (size_t)ld, s);
             if (b.f) {
@@ -1453,7 +1510,10 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
     int cnt = 0;
     if (!SWOK(hipGetDeviceCount(&cnt)) || cnt <= 0) return fnn::fail(FNN_EHIP, "no HIP device available");
     if (device < 0 || device >= cnt || !SWOK(hipSetDevice(device))) return fnn::fail(FNN_EINVAL, "device ordinal out of range");
-    hipEvent_t e0, e1;
+    struct Events {  // (destroyed on every exit path)
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
     Solver S;
     S.n = n;
     S.ld = ((int64_t)n + 31) / 32 * 32 + 32;
@@ -1469,7 +1529,7 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
     S.live = S.alloc<double>((size_t)n * (n - 1) / 2);
     S.grid2 = dim3((unsigned)((n + T - 1) / T), (unsigned)n);
     S.gred = dim3((unsigned)((n + T - 1) / T), (unsigned)(n < 256 ? n : 256));
-    S.partial = S.alloc<double>((size_t)S.gred.x * S.gred.y);
+    S.partial = S.alloc<double>(4 * (size_t)S.gred.x * S.gred.y);
     S.sc = S.alloc<double>(SC_WORDS);
     S.bpartial = S.alloc<Best>((size_t)S.gred.x * S.gred.y);
     if (!S.ok) return fnn::fail(FNN_ENOMEM, "fnn_split_weights_f64: device allocation failed");
@@ -1479,50 +1539,107 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
         !SWOK(hipMemcpyAsync(S.ord, ordering, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyHostToDevice, S.s)) ||
         !SWOK(hipStreamSynchronize(S.s)))
         return fnn::fail(FNN_EHIP, "fnn_split_weights_f64: upload failed");
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, S.s);
+    if (!SWOK(hipEventCreate(&ev.e0)) || !SWOK(hipEventCreate(&ev.e1))) return fnn::fail(FNN_EHIP, "fnn_split_weights_f64: hipEventCreate failed");
+    (void)hipEventRecord(ev.e0, S.s);
     hipLaunchKernelGGL(k_reorder, dim3((unsigned)((n + T - 1) / T), (unsigned)n), dim3(T), 0, S.s, S.Dm, (int64_t)n, S.ord, S.d, n, S.ld);
     S.release(S.Dm);  // (the raw copy has served: its n^2 doubles go back to the pool before the factor is sized)
     S.Dm = nullptr;
-    // the closed form if it is feasible; else from below (Lawson-Hanson, exact sub-problems); the reference's own method
-    // (from above, conjugate gradients) where the free set is too large for a dense factor
-    bool from_below = false;
+    // the closed form if it is feasible; else from below (block active-set method, exact sub-problems); the reference's own
+    // method (from above, conjugate gradients) where the free set is too large for a dense factor AND that route is affordable
+    int route = FNN_SW_ROUTE_CLOSED_FORM;
     hipLaunchKernelGGL(k_unconstrained, dim3((unsigned)((n + T - 1) / T), (unsigned)n), dim3(T), 0, S.s, S.d, S.x, n, S.ld);
     if (S.reduce_sum<RD_COUNT_NEG>(S.x, nullptr) != 0.0) {
-        from_below = !std::getenv("FNN_SW_REFERENCE_METHOD") && S.block_active_set();
+        const bool want_reference = std::getenv("FNN_SW_REFERENCE_METHOD") != nullptr;
+        const bool from_below = !want_reference && S.block_active_set();
+        route = from_below ? FNN_SW_ROUTE_FROM_BELOW : FNN_SW_ROUTE_REFERENCE;
         if (!from_below) {
-            if (std::getenv("FNN_SW_NO_REFERENCE_ROUTE"))  // (development: at BASELINE sizes the reference's route runs for hours)
-                return fnn::fail(FNN_ENOMEM, "fnn_split_weights_f64: the free set outgrew the dense factor (FNN_SW_NO_REFERENCE_ROUTE is set)");
+            if (!want_reference) {
+                // The block method gave up.  Say so, always: the route that follows is the reference's own - correct, but
+                // O(n^2) work per conjugate-gradient iteration and thousands of iterations on large problems.
+                int64_t max_n = 4096;
+                if (const char* e = std::getenv("FNN_SW_REFERENCE_MAX_N")) max_n = std::atoll(e);
+                const bool allow = std::getenv("FNN_SW_ALLOW_REFERENCE_ROUTE") != nullptr || n <= max_n;
+                std::fprintf(stderr, "fnn_split_weights_f64: the block active-set method gave up at n = %d (%s; capacity %lld splits, free set peaked at %lld): %s\n",
+                             n, S.giveup_text, (long long)S.capacity, (long long)S.f_peak,
+                             std::getenv("FNN_SW_NO_REFERENCE_ROUTE") ? "FNN_SW_NO_REFERENCE_ROUTE is set"
+                             : allow ? "taking the reference's active-set / conjugate-gradient route"
+                                     : "the reference's conjugate-gradient route is not taken automatically above FNN_SW_REFERENCE_MAX_N taxa");
+                if (stats) {
+                    std::memset(stats, 0, sizeof(*stats));
+                    stats->giveup_reason = S.giveup; stats->capacity = S.capacity; stats->free_set_peak = S.f_peak;
+                    stats->outer_iterations = S.st_lh_steps; stats->entered = S.st_adds; stats->screened_out = S.st_screened; stats->departed = S.st_dels;
+                }
+                if (std::getenv("FNN_SW_NO_REFERENCE_ROUTE") || !allow) {
+                    const bool cap = S.giveup == FNN_SW_GIVEUP_CAPACITY || S.giveup == FNN_SW_GIVEUP_DEPARTED || S.giveup == FNN_SW_GIVEUP_SETUP;
+                    return fnn::fail(cap ? FNN_ECAPACITY : FNN_EHIP,
+                                     std::string("fnn_split_weights_f64: the block active-set method gave up (") + S.giveup_text + "); the optimum of these distances has more "
+                                     "positive splits than the dense factor holds (" + std::to_string((long long)S.capacity) + "), and the reference's conjugate-gradient route "
+                                     "is not taken automatically at this size (FNN_SW_ALLOW_REFERENCE_ROUTE=1 takes it)");
+                }
+            }
             S.release_block_buffers();
             S.w = S.alloc<double>(NN); S.p = S.alloc<double>(NN); S.old_x = S.alloc<double>(NN);
             if (!S.ok) return fnn::fail(FNN_ENOMEM, "fnn_split_weights_f64: device allocation failed");
             for (double* v : {S.w, S.p, S.old_x}) (void)hipMemsetAsync(v, 0, sizeof(double) * NN, S.s);
             S.st_lh_steps = 0; S.st_solves = 0;
             S.active_conjugate();
+            S.have_atwd = true;
         }
     }
     hipLaunchKernelGGL(k_to_live, S.grid2, dim3(T), 0, S.s, S.x, S.live, n, S.ld);
-    (void)hipEventRecord(e1, S.s);
+    (void)hipEventRecord(ev.e1, S.s);
+    // The solver's own Kuhn-Tucker check of what it returns: g = A^T (A x - d) from the implicit operators, which share
+    // nothing with the factor the block method solved with (outside the timed span: ~0.15 s at 32768 taxa)
+    if (!S.have_atwd) S.Atx(S.d, S.atwd);
+    S.Ab(S.x, S.y);
+    hipLaunchKernelGGL(k_sub, S.grid2, dim3(T), 0, S.s, S.y, S.d, n, S.ld);
+    S.Atx(S.y, S.r);
+    hipLaunchKernelGGL(k_kkt, S.gred, dim3(T), 0, S.s, S.x, S.r, S.atwd, n, S.ld, S.partial);
+    std::vector<double> kp(4 * (size_t)S.gred.x * S.gred.y);
+    (void)hipMemcpyAsync(kp.data(), S.partial, sizeof(double) * kp.size(), hipMemcpyDeviceToHost, S.s);
     hipError_t e = hipStreamSynchronize(S.s);
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    (void)hipEventElapsedTime(&ms, ev.e0, ev.e1);
     if (e != hipSuccess || hipGetLastError() != hipSuccess) return fnn::fail(FNN_EHIP, std::string("fnn_split_weights_f64: ") + hipGetErrorString(e));
+    double kk[4] = {0.0, 0.0, 0.0, 0.0};
+    for (size_t q = 0; q < kp.size(); q += 4)
+        for (int a = 0; a < 4; a++) kk[a] = (kp[q + a] > kk[a] || kp[q + a] != kp[q + a]) ? kp[q + a] : kk[a];
+    const double scale = kk[3] > 0.0 ? kk[3] : 1.0;
+    const double viol = std::max({kk[0], kk[1] / scale, kk[2] / scale});
+    const bool certified = viol <= 1e-9;  // (NaN compares false)
     if (!SWOK(hipMemcpy(weights_out, S.live, sizeof(double) * (size_t)n * (n - 1) / 2, hipMemcpyDeviceToHost)))
         return fnn::fail(FNN_EHIP, "fnn_split_weights_f64: download failed");
     if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        const bool from_below = route == FNN_SW_ROUTE_FROM_BELOW;
         stats->outer_iterations = from_below ? S.st_lh_steps : S.st_outer;
         stats->cg_calls = S.st_cg;
         stats->cg_iterations = S.st_it;
-        stats->reserved[0] = from_below ? 1 : 0;        // method: 1 = from below (Lawson-Hanson, dense factor), 0 = the reference's (or the closed form)
+        stats->reserved[0] = from_below ? 1 : 0;        // method: 1 = from below (block active-set, dense factor), 0 = the reference's (or the closed form)
         stats->reserved[1] = S.st_lh_refactor;
         stats->reserved[2] = S.st_solves;               // sub-problems solved (from below)
         stats->t_solve_s = ms * 1e-3;
         int64_t pos = 0;
         for (int64_t k = 0; k < (int64_t)n * (n - 1) / 2; k++) pos += weights_out[k] > 0.000001 ? 1 : 0;  // FastNN.java:455 threshold
         stats->nsplits = pos;
+        stats->route = route;
+        stats->certified = certified ? 1 : 0;
+        stats->kkt_violation = viol;
+        stats->final_threshold_rel = from_below ? S.final_tol_rel : 0.0;
+        stats->n_set_aside = from_below ? S.n_set_aside : 0;
+        stats->capacity = S.capacity;
+        stats->free_set_peak = S.f_peak;
+        stats->giveup_reason = S.giveup;
+        stats->entered = S.st_adds; stats->screened_out = S.st_screened; stats->departed = S.st_dels;
+        stats->t_alloc_s = S.t_alloc_s;
+    }
+    if (route == FNN_SW_ROUTE_FROM_BELOW && !certified) {
+        char buf[320];
+        std::snprintf(buf, sizeof(buf), "fnn_split_weights_f64: the weights fail the Kuhn-Tucker check: violation %.3g of max|A^T d| (min x %.3g, gradient on positive weights %.3g, "
+                      "on zero weights %.3g; candidates' final threshold %.3g, %lld splits set aside): not the certified optimum",
+                      viol, -kk[0], kk[1] / scale, kk[2] / scale, S.final_tol_rel, (long long)S.n_set_aside);
+        std::fprintf(stderr, "%s\n", buf);
+        return fnn::fail(FNN_EINEXACT, buf);
     }
     return FNN_OK;
 }

@@ -46,15 +46,25 @@ def bootstrap_rccl(dist, device):
     from . import api
     a = api()
     rank, world = dist.get_rank(), dist.get_world_size()
-    path = os.environ.get("FNN_RCCL_PATH") or rccl_path()
+    # A path the USER names (FNN_RCCL_PATH) is binding: a caller that names a library must not silently get another one.
+    # The path this module discovers is only the first candidate: if that file exists but cannot be loaded, the default
+    # search (librccl.so.1 on the loader's path) still gets its turn.
+    user = os.environ.get("FNN_RCCL_PATH")
+    cands = [user] if user else [rccl_path(), None]
     buf = (C.c_uint8 * 128)()
-    ok_local, why = 1, ""
-    try:
-        a.check(a.comm_probe(path.encode() if path else None))
-        if rank == 0:
+    ok_local, why, path = 0, "", cands[0]
+    for cnd in dict.fromkeys(cands):
+        try:
+            a.check(a.comm_probe(cnd.encode() if cnd else None))
+            ok_local, path = 1, cnd
+            break
+        except Exception as e:  # noqa: BLE001 - reported through the all-gather below
+            why = (why + "; " if why else "") + f"{cnd or 'default search'}: {e}"
+    if ok_local and rank == 0:
+        try:
             a.check(a.comm_unique_id(buf, path.encode() if path else None))
-    except Exception as e:  # noqa: BLE001 - reported through the all-gather below
-        ok_local, why = 0, str(e)
+        except Exception as e:  # noqa: BLE001
+            ok_local, why = 0, str(e)
     reports = [None] * world
     dist.all_gather_object(reports, (ok_local, why))
     bad = [(r, w) for r, (o, w) in enumerate(reports) if not o]

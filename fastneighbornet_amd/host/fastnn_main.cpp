@@ -136,7 +136,9 @@ int main(int argc, char** argv) {
         std::vector<double> D = danOrg.toMatrix();
         if (nTaxa >= 2) {
             int32_t rc = fnn_split_weights_f64(D.data(), nTaxa, nTaxa, ordering.data(), device, weights.data(), &sw);
-            if (rc != FNN_OK) throw std::runtime_error(std::string("fastnn: ") + fnn_last_error());
+            if (rc == FNN_EINEXACT)  // the weights are there; say what they are worth and go on (the reference has no such check)
+                std::fprintf(stderr, "fastnn: warning: %s\n", fnn_last_error());
+            else if (rc != FNN_OK) throw std::runtime_error(std::string("fastnn: ") + fnn_last_error());
         }
         const nnet::DistancesAndNames dan(fileName, nTaxa);
         t1 = std::chrono::steady_clock::now();

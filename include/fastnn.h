@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FASTNN_ABI_VERSION 1
+#define FASTNN_ABI_VERSION 2  /* 2: fnn_sw_stats grew (route, certificate, give-up reason), FNN_ECAPACITY / FNN_EINEXACT */
 
 typedef enum fnn_status {
     FNN_OK      = 0,
@@ -39,7 +39,13 @@ typedef enum fnn_status {
     FNN_ENOMEM  = -2,  /* host or device allocation failed */
     FNN_EHIP    = -3,  /* HIP runtime error or no device */
     FNN_ERCCL   = -4,  /* collective error (several GPUs: RCCL or the host callback) */
-    FNN_ESTATE  = -5   /* call sequence error (e.g. run before the matrix is set) */
+    FNN_ESTATE  = -5,  /* call sequence error (e.g. run before the matrix is set) */
+    FNN_ECAPACITY = -6,/* split weights: the optimum has more positive splits than the dense factor of the block method
+                          holds (nearly circular distances: O(n^2) splits) and the fall-back - CircularSplitWeights.java's
+                          conjugate-gradient route - is not affordable at this size; nothing is returned
+                          (FNN_SW_ALLOW_REFERENCE_ROUTE=1 takes that route anyway) */
+    FNN_EINEXACT = -7  /* split weights: weights_out IS filled, but the solver's own Kuhn-Tucker check of them exceeds
+                          1e-9 of max|A^T d| (fnn_sw_stats.kkt_violation says by how much): not the certified optimum */
 } fnn_status;
 
 /* Kind of agglomeration event (NetMakerOriginal.java:462-488; special finish :343-360). */
@@ -249,10 +255,13 @@ int32_t fnn_comm_init_host(fnn_handle* h, int32_t world, int32_t rank, fnn_allga
  * computes with a dense design matrix (FastNN.java:401-454), here on the implicit operators A b, A^T y
  * of CircularSplitWeights.java (2-D prefix sums) with the re-ordering of the distances restored.
  * Three routes to the same optimum: the Chepoi-Fichet closed form when it is feasible; "from below"
- * (Lawson-Hanson: the free set grows one split at a time, its normal equations - closed-form entries -
- * solved exactly through a dense Cholesky factor; right for distances that are far from circular, where
- * only ~2 n splits end up positive); CircularSplitWeights.java's own active-set / conjugate-gradient
- * method (from above) where the free set is too large for a dense factor.  weights_out has n(n-1)/2
+ * (a BLOCK active-set method: whole blocks of splits - local maxima of the multiplier - enter the free set
+ * per step and every weight that is not positive leaves; the free set's normal equations, whose entries have
+ * a closed form, are held as an inverse Cholesky factor that is appended to, never updated; right for
+ * distances that are far from circular, where only ~2.4 n ... 3.8 n splits end up positive; 32768 taxa in
+ * about a minute); CircularSplitWeights.java's own active-set / conjugate-gradient
+ * method (from above) for inputs whose free set outgrows the dense factor (nearly circular metrics) - and
+ * only where that route is affordable: see fnn_sw_stats.status.  weights_out has n(n-1)/2
  * entries in the index order of the reference's live path (FastNN.java:405-419): k runs over
  * (i, j), 0 <= i < j <= n-1, row-major, split k = taxa ordering[i+1 .. j] against the rest.  The
  * reference keeps the splits with weight > 1e-6 (FastNN.java:455). */
@@ -263,7 +272,33 @@ typedef struct fnn_sw_stats {
     int64_t nsplits;          /* weights above 1e-6 */
     double  t_solve_s;        /* device time from the re-ordered distances to the weights */
     int64_t reserved[3];      /* [0] 1 = solved from below (block active-set method), [1] rebuilds of the factor, [2] sub-problems solved */
+    /* ---- ABI version 2 ---- */
+    int32_t route;            /* FNN_SW_ROUTE_*: which of the three routes produced weights_out */
+    int32_t certified;        /* 1 = the weights passed the solver's own Kuhn-Tucker check (kkt_violation <= 1e-9) */
+    double  kkt_violation;    /* max(-min x, max |g| over x > 0, max -g over x = 0) / max|A^T d| with g = A^T (A x - d), evaluated
+                                 on the device from the RETURNED weights with the implicit operators (independent of the factor) */
+    double  final_threshold_rel; /* from below: the candidates' final multiplier threshold / max|A^T d|: 1e-12 unless the
+                                 noise-floor rule raised it */
+    int64_t n_set_aside;      /* from below: splits still set aside at termination (numerically dependent on the factor, or no
+                                 measurable descent); their multipliers are covered by kkt_violation */
+    int64_t capacity;         /* from below: splits the dense factor holds on this device for this n */
+    int64_t free_set_peak;    /* from below: the largest number of splits the factor held */
+    int32_t giveup_reason;    /* from below gave up (FNN_SW_GIVEUP_*; 0 = it did not): the reference route ran, or FNN_ECAPACITY */
+    int32_t pad_;
+    int64_t entered, screened_out, departed; /* from below: splits appended / dropped by the Schur-complement screening / left */
+    double  t_alloc_s;        /* seconds in hipMalloc for the factor's buffers (0.1-2.7 s from box to box at 32768 taxa) */
+    int64_t reserved2[4];
 } fnn_sw_stats;
+enum { FNN_SW_ROUTE_CLOSED_FORM = 0, FNN_SW_ROUTE_FROM_BELOW = 1, FNN_SW_ROUTE_REFERENCE = 2 };
+enum { FNN_SW_GIVEUP_NONE = 0, FNN_SW_GIVEUP_CAPACITY = 1,   /* the free set outgrew the dense factor */
+       FNN_SW_GIVEUP_STEPS = 2,                              /* step limit (40 n + 1000) */
+       FNN_SW_GIVEUP_NUMERIC = 3,                            /* BLAS / Cholesky failure */
+       FNN_SW_GIVEUP_DEPARTED = 4,                           /* the departed splits outgrew their buffers */
+       FNN_SW_GIVEUP_SETUP = 5 };                            /* allocation / library set-up failed */
+/* Returns FNN_OK with the certified optimum; FNN_EINEXACT with weights that failed the check (from below only: the
+ * reference route stops by its own rule, CG_EPSILON = 1e-8, ~1e-5 short of the optimum, and reports certified = 0 with
+ * FNN_OK); FNN_ECAPACITY when the block method's factor cannot hold the free set and n is above the size up to which the
+ * reference route is taken automatically (FNN_SW_REFERENCE_MAX_N, default 4096: measured in DESIGN.md section 7). */
 int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ld, const int32_t* ordering, int32_t device,
                               double* weights_out, fnn_sw_stats* stats);
 

@@ -48,10 +48,12 @@ struct EmuBackend {
     static constexpr int64_t kColPad = 2048;
     int32_t screen_min_n() const { return 8; }   // tiny on purpose: the CPU tests exercise screening
     int32_t screen_min_m = 8;
-    bool screen_off = false;                          // (never set here, see kKeepGenericScreen)
+    bool screen_off = false;                          // set by the engine for a matrix with negative entries when FNN_EMU_PLAIN_NEG is set (the product's behaviour)
     void note_rx_exact(int64_t) {}                    // (the helper workgroups of the exact ComputeRx sums exist on the GPU only)
-    static constexpr bool kKeepGenericScreen = true;  // the emulation keeps screening matrices with negative entries: it is the CPU suite's
-                                                      // coverage of the mixed-sign brackets, which the product no longer uses by default
+    // the emulation keeps screening matrices with negative entries: it is the CPU suite's coverage of the mixed-sign brackets,
+    // which the product no longer uses by default; FNN_EMU_PLAIN_NEG=1 gives it the product's semantics (plain fp64 scan at
+    // every event, no windows; with several ranks every event's scan is sharded and exchanged)
+    bool keep_generic_screen() const { return std::getenv("FNN_EMU_PLAIN_NEG") == nullptr; }
     void set_problem_size(int32_t) {}
     void set_relaxed(int32_t) {}
     bool defer_chain = false; // (so does the deferred chain sum)
@@ -250,7 +252,7 @@ struct EmuBackend {
             if (st.la_valid) st.la_prev_end = 0;
             fnn::la_prepare_base(st, d.lacnt);
         }
-        if (d.H && st.m >= screen_min_m) return scan_screened(d);
+        if (d.H && !screen_off && st.m >= screen_min_m) return scan_screened(d);
         fnn::Cand best;
         best = fnn::cand_none();
         st.rl_active = 0;
@@ -283,7 +285,7 @@ struct EmuBackend {
     // sequences do nothing) until the host launches an event with a scan.
     int32_t launch_event(const fnn::Dev& d, int32_t m_bound, bool sched) {
         fnn::State& st = *d.st;
-        const bool screen = d.H && m_bound >= screen_min_m;
+        const bool screen = d.H && !screen_off && m_bound >= screen_min_m;
         const bool has_scan = sched || !screen;
         if (has_scan) {
             if (!st.done) st.stall = 0;
@@ -316,7 +318,7 @@ struct EmuBackend {
     }
     int32_t allgather_on_stream(const fnn::Dev&, int32_t) { return FNN_ERCCL; }  // no RCCL in the emulation
     int32_t allgather_wx_on_stream(const fnn::Dev&, size_t) { return FNN_ERCCL; }
-    bool use_screen(const fnn::Dev& d, int32_t m_bound) const { return d.H != nullptr && m_bound >= screen_min_m; }
+    bool use_screen(const fnn::Dev& d, int32_t m_bound) const { return d.H != nullptr && !screen_off && m_bound >= screen_min_m; }
     // several ranks with lookahead windows: the sharded part of a base scan ... (exchange) ... merge + the rest
     int32_t launch_wx_scan(const fnn::Dev& d, int32_t) {
         fnn::State& st = *d.st;

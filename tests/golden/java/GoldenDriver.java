@@ -7,7 +7,9 @@
 // on the synthetic matrices of SURVEY.md 8(d) and prints one JSON line per case: the order's sha256 (over the
 // n + 1 little-endian int32 values, as tests/golden/*.json hash it), the order itself for small n, and the
 // seconds of the runNeighborNet() span (what FastNN.java:377-382 times).
-// usage: java -Xmx<..>g nnet.GoldenDriver <threads> <n:dist:seed> [<n:dist:seed> ...]
+// With `hip` as the first argument the SAME matrices also go through jni/NeighborNetHIP.java -> jni/fastnn_jni.c ->
+// libfastnn_hip.so (the drop-in a maintainer would add), and the line carries both hashes and both timings.
+// usage: java -Xmx<..>g nnet.GoldenDriver [hip] <threads> <n:dist:seed> [<n:dist:seed> ...]
 package nnet;
 
 import java.nio.ByteBuffer;
@@ -39,7 +41,17 @@ public class GoldenDriver {
         return D;
     }
 
+    static String sha(int[] order) throws Exception {
+        ByteBuffer bb = ByteBuffer.allocate(4 * order.length).order(ByteOrder.LITTLE_ENDIAN);
+        for (int v : order) bb.putInt(v);
+        StringBuilder hex = new StringBuilder();
+        for (byte b : MessageDigest.getInstance("SHA-256").digest(bb.array())) hex.append(String.format("%02x", b));
+        return hex.toString();
+    }
+
     public static void main(String[] a) throws Exception {
+        boolean hip = a.length > 0 && a[0].equals("hip");
+        if (hip) a = java.util.Arrays.copyOfRange(a, 1, a.length);
         int threads = Integer.parseInt(a[0]);
         ExecutorService pool = threads > 1 ? Executors.newFixedThreadPool(threads) : null;
         for (int c = 1; c < a.length; c++) {
@@ -47,13 +59,16 @@ public class GoldenDriver {
             int n = Integer.parseInt(p[0]);
             long seed = Long.parseLong(p[2]);
             double[][] D = synth(n, seed, p[1]);
+            String hipPart = "";
+            if (hip) {  // first: the reference destroys D in place (NetMakerOriginal.java:653-656), the engine does not
+                long h0 = System.nanoTime();
+                int[] oh = new NeighborNetHIP(D, n, threads, pool).runNeighborNet();
+                hipPart = ",\"hip_order_sha256\":\"" + sha(oh) + "\",\"hip_seconds\":" + (System.nanoTime() - h0) * 1e-9;
+            }
             long t0 = System.nanoTime();
             int[] order = new NeighborNetCanonical(D, n, threads, pool).runNeighborNet();
             double sec = (System.nanoTime() - t0) * 1e-9;
-            ByteBuffer bb = ByteBuffer.allocate(4 * order.length).order(ByteOrder.LITTLE_ENDIAN);
-            for (int v : order) bb.putInt(v);
-            StringBuilder hex = new StringBuilder();
-            for (byte b : MessageDigest.getInstance("SHA-256").digest(bb.array())) hex.append(String.format("%02x", b));
+            String hex = sha(order);
             StringBuilder o = new StringBuilder("null");
             if (n <= 64) {
                 o = new StringBuilder("[");
@@ -61,7 +76,7 @@ public class GoldenDriver {
                 o.append("]");
             }
             System.out.println("{\"n\":" + n + ",\"dist\":\"" + p[1] + "\",\"seed\":" + seed + ",\"threads\":" + threads
-                    + ",\"order_sha256\":\"" + hex + "\",\"order\":" + o + ",\"seconds\":" + sec + "}");
+                    + ",\"order_sha256\":\"" + hex + "\",\"order\":" + o + ",\"seconds\":" + sec + hipPart + "}");
             System.out.flush();
         }
         System.exit(0);  // the reference never shuts its thread pool down (FastNN.java:536-538): leave explicitly

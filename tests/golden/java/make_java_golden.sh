@@ -16,7 +16,26 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 command -v javac >/dev/null 2>&1 && command -v java >/dev/null 2>&1 || { echo "Java baseline unavailable: no javac/java on PATH"; exit 3; }
 [ -n "${FASTNN_REF_DIR:-}" ] && [ -f "$FASTNN_REF_DIR/NeighborNetCanonical.java" ] || { echo "Java baseline unavailable: set FASTNN_REF_DIR to the reference checkout"; exit 3; }
 OUT="$(mktemp -d)"
-javac -nowarn -d "$OUT" "$FASTNN_REF_DIR/NetNode.java" "$FASTNN_REF_DIR/NetMakerOriginal.java" "$FASTNN_REF_DIR/NeighborNetCanonical.java" "$HERE/GoldenDriver.java"
+ROOT="$(cd "$HERE/../../.." && pwd)"
+# the Java side of the drop-in (jni/NeighborNetHIP.java extends the reference's NetMakerOriginal) compiles with the reference
+javac -nowarn -d "$OUT" "$FASTNN_REF_DIR/NetNode.java" "$FASTNN_REF_DIR/NetMakerOriginal.java" "$FASTNN_REF_DIR/NeighborNetCanonical.java" \
+      "$ROOT/jni/NeighborNetHIP.java" "$HERE/GoldenDriver.java"
+# ... and, where the engine's library, jni.h and a GPU exist, it RUNS: the JNI shim is built and every case also goes
+# through NeighborNetHIP -> fastnn_jni.c -> libfastnn_hip.so ("hip_order_sha256" beside the reference's "order_sha256")
+ENGINE=()
+JH="${JAVA_HOME:-$(dirname "$(dirname "$(readlink -f "$(command -v javac)")")")}"
+if [ -f "$ROOT/fastneighbornet_amd/libfastnn_hip.so" ] && [ -f "$JH/include/jni.h" ] && [ "${FASTNN_JNI:-1}" != "0" ]; then
+  gcc -shared -fPIC -O2 -I"$JH/include" -I"$JH/include/linux" -I"$ROOT/include" "$ROOT/jni/fastnn_jni.c" \
+      -L"$ROOT/fastneighbornet_amd" -lfastnn_hip -Wl,-rpath,"$ROOT/fastneighbornet_amd" -o "$OUT/libfastnn_jni.so"
+  if python3 -c "import sys; sys.path.insert(0, '$ROOT'); import fastneighbornet_amd as fa; sys.exit(0 if fa.api().device_count() > 0 else 1)" 2>/dev/null; then
+    ENGINE=(hip)
+    echo "JNI drop-in built; a HIP device is visible: every case also runs through nnet.NeighborNetHIP"
+  else
+    echo "JNI drop-in built ($OUT/libfastnn_jni.so) but no HIP device is visible: reference legs only"
+  fi
+else
+  echo "JNI drop-in not built (needs fastneighbornet_amd/libfastnn_hip.so and \$JAVA_HOME/include/jni.h): reference legs only"
+fi
 CASES=("$@")
 [ ${#CASES[@]} -gt 0 ] || CASES=(4:uniform53:1 5:uniform53:1 9:dec4:2 17:uniform53:2 64:uniform53:1 64:dec4:1 200:uniform53:1 200:dec4:2 1030:dec4:4
                                  2048:uniform53:7 4096:uniform53:1 4096:dec4:1 4096:uniform53:2 4096:uniform53:3
@@ -34,5 +53,5 @@ finish() {
 }
 trap finish EXIT
 for c in "${CASES[@]}"; do
-  java -Xmx14g -cp "$OUT" nnet.GoldenDriver 1 "$c" | tee -a "$LINES"
+  java -Xmx14g -Djava.library.path="$OUT" -cp "$OUT" nnet.GoldenDriver ${ENGINE[@]+"${ENGINE[@]}"} 1 "$c" | tee -a "$LINES"
 done

@@ -6,7 +6,8 @@ oracle's results for them in the build container) and the GPU tests that replay 
                     ties everywhere (NeighborNetCanonical.java:151-178 first-strict-minimum, NetMakerOriginal.java:428-452)
   treenoise         additive tree metric with real-valued branch lengths + 5 % uniform noise (what real data look like)
   neg               uniform53 shifted by -0.25: a third of the entries negative (the lookahead windows' monotonicity
-                    argument needs non-negative entries: the engine screens every event instead)
+                    argument needs non-negative entries: the engine takes the plain fp64 scan for every event - no screening
+                    pass, no windows; with several ranks the scan of every event is sharded -)
 
 Host-generated classes depend on numpy's default_rng stream (PCG64), which is stable across numpy versions.
 """

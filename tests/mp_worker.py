@@ -37,7 +37,8 @@ def main():
     else:
         import fastneighbornet_amd as fa
         api = fa.api()
-    D = O.synth(n, seed, dist_name)
+    import inputs
+    D = inputs.make(n, dist_name, seed, O)   # uniform53 / dec4 (SplitMix64) and the host-generated classes: tree, treenoise, neg
     with Handle(api, n, record_events=True) as h:
         fd.init_gloo(h, dist)
         h.set_matrix(D)
@@ -45,7 +46,8 @@ def main():
         ev = h.events()
     json.dump({"order": order.tolist(), "n_events": int(st.n_events), "sum_entries": int(st.sum_entries),
                "kinds": ev["kind"].tolist(), "x": ev["x_id"].tolist(), "y": ev["y_id"].tolist(),
-               "window_hits": int(st.n_window_hits), "base_scans": int(st.n_base_scans)},
+               "window_hits": int(st.n_window_hits), "base_scans": int(st.n_base_scans), "rx_exact": int(st.n_rx_exact),
+               "screen_events": int(st.n_screen_events)},
               open(os.path.join(out_dir, f"rank{rank}.json"), "w"))
     dist.barrier()
     dist.destroy_process_group()

@@ -28,7 +28,7 @@ def test_library_builds_loads_and_exports_all_symbols():
     for name in declared_functions():
         assert hasattr(lib, name), f"{name} declared in fastnn.h but not exported"
     lib.fnn_abi_version.restype = C.c_int32
-    assert lib.fnn_abi_version() == 1
+    assert lib.fnn_abi_version() == 2
 
 
 def test_fails_loudly_without_device():
@@ -52,6 +52,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_capi.FnnOpts) == 64
     assert C.sizeof(_capi.FnnStats) == 25 * 8  # 18 named 8-byte fields + reserved[7]
     assert _capi.EVENT_DTYPE.itemsize == 48
+    assert C.sizeof(_capi.FnnSwStats) == 8 * 8 + 2 * 4 + 2 * 8 + 3 * 8 + 2 * 4 + 3 * 8 + 8 + 4 * 8  # fnn_sw_stats, ABI version 2
 
 
 def test_oracle_is_test_infrastructure_only():

@@ -23,7 +23,8 @@ TRAJ_FIELDS = ["m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind",
 
 # BASELINE.md section 3's primary seeds 1-3, the 4-decimal generator, and (round 3) the input classes of tests/inputs.py:
 # additive tree metrics with exact ties of the Q criterion everywhere, tree + noise, matrices with negative entries (for
-# which the engine keeps screening every event: the windows' monotonicity argument needs non-negative entries)
+# which the engine takes the plain fp64 scan at every event - no screening pass, no windows: the windows' monotonicity
+# argument needs non-negative entries, fnn_engine.h: begin)
 BIG_CASES = [(4096, "uniform53", 1), (4096, "dec4", 1), (16384, "uniform53", 1), (32768, "uniform53", 1),
              (4096, "uniform53", 2), (4096, "uniform53", 3), (4096, "tree", 5), (4096, "treenoise", 6), (4096, "neg", 1),
              (8192, "tree", 7), (8192, "treenoise", 8), (8192, "neg", 2), (16384, "uniform53", 2), (16384, "uniform53", 3),

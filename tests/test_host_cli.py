@@ -225,3 +225,69 @@ def test_nexus_document_parallel_writer_equals_the_list_route(hostlib, tmp_path,
     assert na == nb == int((w > 1e-6).sum())
     a, b = open(pa, "rb").read(), open(pb, "rb").read()
     assert a == b, next((i, a[max(0, i - 40): i + 40], b[max(0, i - 40): i + 40]) for i in range(min(len(a), len(b))) if a[i] != b[i])
+
+
+# ---- a whole-document known answer (tests/golden/kat5.nex) -------------------------------------------------------------
+# The 5-taxon known-answer case of SURVEY.md App. B (tests/golden/kat5.json: small-integer distances, circular order
+# [0, 1, 2, 3, 4, 5] hand-traced from NetMakerOriginal.java) continued through the rest of FastNN.main: the live path's
+# non-negative least-squares problem (FastNN.java:401-454) has the feasible Chepoi-Fichet solution
+#   x(i, j) = (d(i, j) + d(i+1, j+1) - d(i, j+1) - d(i+1, j)) / 2   (positions modulo n)
+# whose entries are half-integers here: in the live index order (FastNN.java:405-419: (0,1), (0,2), ... (3,4), split k =
+# taxa ordering[i+1 .. j]) x = 1, 3.5, 1.5, 1, 1, 1, 0, 1, 1.5, 1.5 - nine splits above the 1e-6 threshold (:455).  Every
+# number of the document is therefore exact, Double.toString prints "1.0" / "3.5" / "10.0", and the document is derived by
+# hand from OutputPrinter.java:8-96 line by line: `[k, size=min(|S|, n - |S|)] \t w \t  members,` (:70-85), the distance
+# block as " " + value per entry (:34-47), CYCLE from ordering[1..n] (:56-61), the fixed st_Assumptions block (:87-96).
+KAT5_LIVE_WEIGHTS = [1.0, 3.5, 1.5, 1.0, 1.0, 1.0, 0.0, 1.0, 1.5, 1.5]
+
+
+def _kat5():
+    import json
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "kat5.json")))
+    n = k["n"]
+    D = np.zeros((n, n))
+    for i, row in enumerate(k["lower_triangle_rows"]):
+        for j, v in enumerate(row):
+            D[i, j] = D[j, i] = float(v)
+    return k, D, open(os.path.join(ROOT, "tests", "golden", "kat5.nex"), "rb").read()
+
+
+def test_kat5_weights_are_the_live_paths_optimum():
+    """the fixture's weights are the unique optimum of the reference's dense problem (solver-independent: A x = d exactly, x >= 0)"""
+    from oracle import csw_oracle as W
+    _, D, _ = _kat5()
+    A = W.live_design_matrix(5, np.arange(6, dtype=np.int32))
+    assert (A @ np.array(KAT5_LIVE_WEIGHTS) == W.packed_distances(D)).all()
+
+
+def test_kat5_nexus_document_byte_for_byte(hostlib, tmp_path):
+    """N2: the host writer reproduces the hand-derived document of the 5-taxon known-answer case byte for byte."""
+    k, D, want = _kat5()
+    n = 5
+    sig = [C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    hostlib.fnnh_write_nexus.argtypes = sig
+    hostlib.fnnh_write_nexus_lists.argtypes = sig
+    names = b"".join((f"t{i + 1}".encode()).ljust(256, b"\0") for i in range(n))
+    order = np.arange(n + 1, dtype=np.int32)
+    w = np.array(KAT5_LIVE_WEIGHTS)
+    for fn in (hostlib.fnnh_write_nexus, hostlib.fnnh_write_nexus_lists):
+        p = str(tmp_path / "kat5.nex")
+        ns = fn(p.encode(), n, D.ctypes.data_as(C.POINTER(C.c_double)), names, order.ctypes.data_as(C.POINTER(C.c_int32)),
+                w.ctypes.data_as(C.POINTER(C.c_double)))
+        assert ns == 9
+        got = open(p, "rb").read()
+        assert got == want, next((i, got[max(0, i - 30): i + 30], want[max(0, i - 30): i + 30]) for i in range(min(len(got), len(want))) if got[i] != want[i])
+
+
+@pytest.mark.gpu
+def test_cli_kat5_whole_document(tmp_path):
+    """The CLI end to end on the known-answer Phylip file: order, split weights on the GPU (closed form: exact here) and the
+    document - stdout equals tests/golden/kat5.nex byte for byte (FastNN.java:398-491, OutputPrinter.java:8-96)."""
+    k, D, want = _kat5()
+    p = tmp_path / "kat5.phy"
+    p.write_text(k["phylip"])
+    exe = os.path.join(PKG, "bin", "fastnn")
+    r = subprocess.run([exe, "-distFile", str(p), "-mode", "Canonical", "-order"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout == "[0, 1, 2, 3, 4, 5]\n", r.stderr
+    r = subprocess.run([exe, "-distFile", str(p), "-mode", "Canonical"], capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == want

@@ -24,6 +24,8 @@ def test_oracle_against_java_goldens(oracle):
     checked = 0
     for c in doc["cases"]:
         key = (c["n"], c["dist"], c["seed"])
+        if "hip_order_sha256" in c:  # the case also went through jni/NeighborNetHIP.java -> libfastnn_hip.so on the operator's GPU
+            assert c["hip_order_sha256"] == c["order_sha256"], ("the JNI drop-in disagrees with the reference", key)
         if c["n"] <= 2100:
             order, _, _ = oracle.run(oracle.synth(c["n"], c["seed"], c["dist"]), threads=1, want_events=False)
             assert hashlib.sha256(order.tobytes()).hexdigest() == c["order_sha256"], key

@@ -38,7 +38,8 @@ def run_ranks(backend, world, n, seed, dist_name, tmp_path, port, extra_env=None
 
 
 def check(res, oracle, n, seed, dist_name):
-    o_ref, ev_ref, se = oracle.run(oracle.synth(n, seed, dist_name))
+    import inputs
+    o_ref, ev_ref, se = oracle.run(inputs.make(n, dist_name, seed, oracle))
     for r in res:
         assert r["order"] == o_ref.tolist()
         assert r["n_events"] == len(ev_ref) and r["sum_entries"] == se
@@ -62,6 +63,31 @@ def test_emulation_over_gloo(emu_api, oracle, tmp_path, world, n, seed, dist_nam
 def test_emulation_over_gloo_modes(emu_api, oracle, tmp_path, world, n, seed, env):
     res = run_ranks("emu", world, n, seed, "uniform53", tmp_path, 29711 + world + n, env)
     check(res, oracle, n, seed, "uniform53")
+
+
+@pytest.mark.parametrize("world,n,seed,dist_name,env", [
+    (2, 220, 5, "tree", None),                              # exact ties of Q everywhere: the tie-breaks and the exact ComputeRx sums decide
+    (3, 150, 6, "tree", {"FNN_LA_K": "4"}),
+    (2, 200, 7, "treenoise", None),
+    (2, 180, 1, "neg", {"FNN_EMU_PLAIN_NEG": "1"}),         # the PRODUCT's path for negative entries: plain scan of every event, sharded + exchanged
+    (3, 130, 2, "neg", {"FNN_EMU_PLAIN_NEG": "1"}),
+    (2, 160, 3, "neg", None)])                               # (the emulation's own default: mixed-sign screening brackets, windows refused)
+def test_emulation_over_gloo_input_classes(emu_api, oracle, tmp_path, world, n, seed, dist_name, env):
+    """Several ranks on the input classes that leave the fast path (tests/inputs.py): a tie-rich tree metric, tree + noise,
+    and a matrix with negative entries - with FNN_EMU_PLAIN_NEG the emulation follows the product (fnn_engine.h: begin turns
+    screening and windows off for such a matrix; every event's scan is then sharded by tile index mod world and its candidate
+    records exchanged: the one mode in which sharding every event pays)."""
+    res = run_ranks("emu", world, n, seed, dist_name, tmp_path, 29311 + 7 * world + n, env)
+    check(res, oracle, n, seed, dist_name)
+    assert len({(r["window_hits"], r["base_scans"], r["rx_exact"]) for r in res}) == 1  # the ranks stay in step
+    if dist_name == "neg":
+        assert all(r["window_hits"] == 0 for r in res)
+        if env:
+            assert all(r["screen_events"] == 0 and r["base_scans"] == 0 for r in res), [(r["screen_events"], r["base_scans"], r["n_events"]) for r in res]
+        else:
+            assert all(r["screen_events"] > 0 for r in res)
+    if dist_name == "tree":
+        assert all(r["rx_exact"] > 0 for r in res)
 
 
 def test_a_give_up_on_one_rank_is_an_error_on_all_ranks(emu_api, tmp_path):
@@ -116,6 +142,20 @@ def test_hip_ranks_sharing_one_gpu(hip_api, oracle, tmp_path, world, n, seed, di
     extra = {"FNN_SCREEN_MIN_N": "8", "FNN_SCREEN_MIN_M": "64"} if screen else None
     res = run_ranks("hip", world, n, seed, dist_name, tmp_path, 29611 + world + (7 if screen else 0), extra)
     check(res, oracle, n, seed, dist_name)
+
+
+@pytest.mark.gpu
+def test_hip_ranks_negative_entries_shard_every_scan(hip_api, tmp_path):
+    """The product's several-rank path for a matrix with negative entries (4096 taxa, uniform53 - 0.25): no screening copy
+    in use, no windows; EVERY event's plain fp64 scan is sharded by tile index mod world and its candidate records are
+    exchanged.  Two ranks on the one GPU, against the oracle's golden (tests/golden/big_4096_neg_s1.npz)."""
+    import numpy as np
+    res = run_ranks("hip", 2, 4096, 1, "neg", tmp_path, 29655)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "big_4096_neg_s1.npz"))
+    for r in res:
+        assert r["order"] == z["order"].tolist()
+        assert r["kinds"] == z["traj"][:, 6].tolist() and r["x"] == z["traj"][:, 4].tolist() and r["y"] == z["traj"][:, 5].tolist()
+        assert r["window_hits"] == 0 and r["screen_events"] == 0
 
 
 @pytest.mark.gpu
