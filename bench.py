@@ -160,6 +160,44 @@ def amdahl(chain, sec, n_ranks):
     return out
 
 
+def config5(api, h, n, seed, order_ref):
+    """order -> split weights -> Nexus document for the bench's matrix on this GPU; seconds per stage."""
+    import ctypes as C
+    import numpy as np
+    import fastneighbornet_amd as fa
+    h.synth(seed, "uniform53")
+    t0 = time.perf_counter()
+    D = h.matrix()                                   # fnn_get_matrix: the device-generated distances for the later stages
+    t_get = time.perf_counter() - t0
+    order, st = h.run()
+    assert (order == order_ref).all()
+    h.close()                                        # (the engine's 10 GiB go back before the solver sizes its factor)
+    t0 = time.perf_counter()
+    w, sw = fa.split_weights(D, order)
+    t_w = time.perf_counter() - t0
+    host = C.CDLL(os.path.join(os.path.dirname(fa.__file__), "libfastnn_host.so"))
+    host.fnnh_write_nexus.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    host.fnnh_write_nexus.restype = C.c_int32
+    names = b"".join((f"t{i + 1}".encode()).ljust(256, b"\0") for i in range(n))
+    t0 = time.perf_counter()
+    ns = host.fnnh_write_nexus(b"/dev/null", n, D.ctypes.data_as(C.POINTER(C.c_double)), names,
+                               order.ctypes.data_as(C.POINTER(C.c_int32)), w.ctypes.data_as(C.POINTER(C.c_double)))
+    t_doc = time.perf_counter() - t0
+    assert ns == int((w > 1e-6).sum()) == sw["nsplits"]
+    return {"order": round(st.t_total_s, 3), "weights": round(t_w, 2), "weights_device": round(sw["t_solve_s"], 2), "nexus": round(t_doc, 2),
+            "total": round(st.t_total_s + t_w + t_doc, 2),
+            "kkt": sw["kkt_violation"], "kkt_certified": bool(sw["certified"]),
+            "kkt_note": "max(-min x, max |g| on x > 0, max -g on x = 0) / max|A^T d|, g = A^T (A x - d), evaluated on the device from the returned "
+                        "weights with the implicit operators (independent of the factor the solver used); tests/test_split_weights.py::"
+                        "test_config5_end_to_end_32768 repeats it on the host with the oracle's operators",
+            "nsplits": int(ns), "route": sw["method"], "steps": int(sw["outer_iterations"]), "rebuilds": int(sw["refactorizations"]),
+            "entered": int(sw["entered"]), "screened_out": int(sw["screened_out"]), "departed": int(sw["departed"]),
+            "factor_capacity": int(sw["capacity"]), "free_set_peak": int(sw["free_set_peak"]), "hipmalloc_s": round(sw["t_alloc_s"], 2),
+            "matrix_download_s": round(t_get, 2),
+            "note": "order = fnn_run with the matrix resident; weights = fnn_split_weights_f64 wall clock incl. the upload of the host matrix; "
+                    "nexus = printNexusFromWeights to /dev/null on the host cores"}
+
+
 def golden_check(n, seed, order):
     """The order against the oracle's golden for this (n, seed), generated in the build container."""
     try:
@@ -181,6 +219,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chain", action="store_true", help="skip the extra run that times every kernel of the event chain")
+    ap.add_argument("--no-config5", action="store_true", help="skip BASELINE config 5 (order + split weights + Nexus document, ~100 s, outside the timed region)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -295,6 +334,12 @@ def main():
             "exchange": ({"allgather_calls": int(xcnt[0]), "allgather_us_avg": round(xms[0] * 1e3 / xcnt[0], 2),
                           "merge_us_avg": round(xms[1] * 1e3 / max(xcnt[1], 1), 2)} if xcnt[0] > 0 else None),
         }
+    # ---- several ranks: every rank's order, not only rank 0's (the replicated event chain rests on identical decisions)
+    ranks_orders = None
+    if dist is not None and not replicas:
+        mine = hashlib.sha256(last[0].tobytes()).hexdigest() if (worker and last is not None) else None
+        ranks_orders = [None] * world
+        dist.all_gather_object(ranks_orders, mine)
     if dist is not None:
         dist.barrier()
 
@@ -305,6 +350,13 @@ def main():
         assert sorted(order[1:].tolist()) == list(range(1, n + 1)) and order[0] == 0 and order[1] == 1
         gold = golden_check(n, seed, order) if not replicas else None
         assert gold is not False, "the circular order differs from the oracle's golden (tests/golden/oracle_big.json)"
+        ranks_seen = None
+        if ranks_orders is not None:
+            seen = [s for s in ranks_orders if s is not None]
+            ranks_seen = len(seen)
+            assert len(set(seen)) == 1 and seen[0] == hashlib.sha256(order.tobytes()).hexdigest(), \
+                f"the ranks returned different circular orders: {ranks_orders}"
+            assert not sharded or ranks_seen == world, f"only {ranks_seen} of {world} ranks reported an order"
         share = args.gpus if sharded else 1  # this rank's launches cover 1/share of the entries
         # dominant streaming kernel: the bf16 screening pass.  With lookahead windows the timed launches
         # are the host-scheduled base scans (kernel name k_screen<true, true>)
@@ -345,6 +397,8 @@ def main():
                 "events": int(st.n_events),
                 "sum_entries": int(st.sum_entries),
                 "order_matches_oracle_golden": gold,
+                # several ranks: how many ranks computed an order; all of them are compared with rank 0's (and so with the golden)
+                "rccl_ranks_seen": ranks_seen, "all_ranks_same_order": (True if ranks_seen else None),
                 "fp64_every_event_bytes": int(fp64_equiv),
                 "bytes_read_by_all_scan_work": int(st.bytes_total),
                 "lookahead_windows": {"events_with_a_scan": int(st.n_base_scans), "events_served_by_a_window": int(st.n_window_hits),
@@ -407,6 +461,14 @@ def main():
                 out["roofline"]["measured_stream_read_gbps"] = round(g.value, 1)
         except Exception:
             pass
+        # ---- BASELINE.json configs[4], outside the timed region: the same 32768 taxa end to end - order, circular split
+        # weights (fnn_split_weights_f64: block active-set method, with the solver's own Kuhn-Tucker certificate), Nexus
+        # document (the routine the CLI runs, to /dev/null) - FastNN.java:369-491
+        if n == 32768 and args.gpus == 1 and not args.no_config5:
+            try:
+                out["config5_e2e_s"] = config5(api, h, n, seed, order)
+            except Exception as e:  # reported, never required for the headline
+                out["config5_e2e_s"] = {"error": f"{type(e).__name__}: {e}"}
         if h is not None:
             h.close()
             h = None

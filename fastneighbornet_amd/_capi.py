@@ -99,6 +99,7 @@ class Api:
         f("get_counts", C.c_int32, [C.c_void_p, _ip, _ip, _ip])
         f("get_nodes", C.c_int32, [C.c_void_p, _ip, _ip, _dp])
         f("get_live_matrix", C.c_int32, [C.c_void_p, _dp])
+        f("get_matrix", C.c_int32, [C.c_void_p, _dp, C.c_int64])
         f("comm_init_host", C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, ALLGATHER_FN, C.c_void_p])
 
     def _fn(self, name, restype, argtypes, optional=False):
@@ -240,6 +241,12 @@ class Handle:
         self.api.check(self.api.get_nodes(self._h, ids.ctypes.data_as(_ip), nbr.ctypes.data_as(_ip),
                                           sx.ctypes.data_as(_dp)))
         return ids[:m], nbr[:m], sx[:m]
+
+    def matrix(self) -> np.ndarray:
+        """The resident n x n matrix (after set_matrix / synth, before run consumes it) - fnn_get_matrix."""
+        out = np.empty((self.n, self.n), dtype=np.float64)
+        self.api.check(self.api.get_matrix(self._h, out.ctypes.data_as(_dp), self.n))
+        return out
 
     def live_matrix(self) -> np.ndarray:
         m, _, _ = self.counts()

@@ -154,7 +154,13 @@ struct State {
     int32_t tp_n, tp_U;
     // an event launched WITHOUT scan kernels found that its window cannot serve it: this and the
     // following such events do nothing until the host (which resyncs every batch) launches one with a scan
-    int32_t stall, pad_stall;
+    int32_t stall;
+    int32_t chain_buf;        // which chain buffer (0 or CHAIN_ALT) holds the addends of the pending row sum: the fused event kernel fills
+                              // the other one while the chain workgroup of the same launch still reads this one
+    // reference positions that this event's plan changed for slots that need NOT be involved slots: the node at the last position
+    // takes y's place (agg3_plan; NetMakerOriginal.java:641-643).  The fused event kernel hands them to its column threads, which run
+    // in the same launch as the plan and cannot rely on seeing its plain stores to d.spos
+    int32_t pov_n, pov_slot[2], pov_pos[2], pad_pov;
     int64_t n_stalled;        // events skipped that way
     int64_t n_sweep_waits;    // k_track: sweeps that had to wait for the exact row sum
     int64_t ev_ticks[8];      // (unused; the phase-split diagnostics live in Dev::ticks)
@@ -184,6 +190,28 @@ struct State {
     Tgt tgt[MAX_TGT];
 };
 
+// Fused event kernel (k_track with fuse): what the deciding workgroup tells the column workgroups of the SAME launch - the
+// part of the control block that plan_view reads (same field names) and the values those threads cannot read from memory
+// because this very launch produces them.  Travels as PLAN_WORDS words of (int | launch tag << 32): a reader that finds the
+// launch's tag in every word has the whole message, in ONE round trip.
+struct PlanMsg {
+    int32_t kind;             // 0: no update in this launch (the window could not serve the event, the run has ended ...), 1: update
+    int32_t last_wg;          // the deciding workgroup: its block of columns goes to the spare workgroup
+    int32_t pU, cU;           // previous event's cluster: T[pU], T[pU+1] are tfin; Sx[cU], Sx[cU+1] come from the chain workgroup
+    int32_t chain_wait;       // ... of this launch (wait for its flag == evtag)
+    int32_t evtag;
+    int32_t chain_dst;        // chain buffer that takes this event's row-sum addends
+    int32_t nbulk;            // blocks of 1024 columns
+    int32_t pov_n, pov_slot[2], pov_pos[2], pad0;
+    int32_t tfin[4];          // two doubles
+    int32_t m_old, P_old, ev_finish, xs, ys, pad1;
+    int32_t nS, S[MAX_S];
+    int32_t ntgt, tU, tV;
+    Tgt tgt[MAX_TGT];
+    int32_t fill[44];
+};
+static_assert(sizeof(PlanMsg) == 4 * 128, "PlanMsg is PLAN_WORDS ints");
+
 struct Dev {
     double* D;       // slot-ordered matrix, row stride ld
     int64_t ld;
@@ -193,8 +221,11 @@ struct Dev {
     int32_t* sid;    // per slot: NetNode.id
     int32_t* spos;   // per slot: NetNode.positionID
     int32_t* pslot;  // reference position -> slot (-1 if empty)
-    double* chain;   // 5 buffers of cstride doubles, addressed through chain_addr(position): [0] the addends of the new cluster's row sum
-                     // (consumed by the NEXT event's k_track while that event may already fill [1..4], the <= 4 ComputeRx sums of its own decision)
+    double* chain;   // 6 buffers of cstride doubles, addressed through chain_addr(position): [0] / [CHAIN_ALT] the addends of the new cluster's
+                     // row sum (State.chain_buf says which; consumed by the NEXT event's k_track while that event may already fill [1..4], the
+                     // <= 4 ComputeRx sums of its own decision, and - fused event kernel - the other row-sum buffer)
+    uint64_t* plan;  // fused event kernel (k_track with fuse): the plan message of the deciding workgroup to the column workgroups of the
+                     // same launch, PLAN_WORDS words of (payload | launch tag << 32)
     int64_t cstride; // n rounded up to a whole super-chunk
     Cand* recs;      // per-block scan records
     uint64_t* rchk;  // k_track's fan-in: a check word per record (2 x 1024), see rec_publish; [2048 ..): results of the ComputeRx helper workgroups
@@ -244,6 +275,9 @@ struct Dev {
 // CH_EPT consecutive addends [t*CH_EPT, (t+1)*CH_EPT) of a 32768-addend super-chunk; with the
 // j-th PAIR of every chunk stored contiguously over t, each of the thread's 16-byte loads is
 // perfectly coalesced across the wave.  The producers scatter by position anyway.
+constexpr int CHAIN_ALT = 5;             // the second row-sum buffer of Dev.chain (see State.chain_buf)
+constexpr int CHAIN_BUFS = 6;
+constexpr int PLAN_WORDS = 128;
 constexpr int CH_T = 1024;               // threads of the chain workgroup
 constexpr int CH_EPT = 32;               // addends per thread
 constexpr int CH_SC = CH_T * CH_EPT;     // addends per super-chunk
@@ -1028,6 +1062,8 @@ FNN_HD void agg3_plan(const Dev& d, Tab& T, int32_t X, int32_t Y, int32_t Z, int
         T.set_pslot(py, last);
         if (last == U) pu = py;
         if (last == V) pv = py;
+        if (st.pov_n < 2) { st.pov_slot[st.pov_n] = last; st.pov_pos[st.pov_n] = py; st.pov_n++; }
+        else st.error = 15;  // (an event has at most two agg3way calls)
     }
     T.set_pslot(mc - 1, -1);
     emit(st, OP_AGG3, X, Y, Z, U, V, pu < pv ? 1 : 0);
@@ -1121,6 +1157,7 @@ FNN_HD void pick(const Dev& d, Cand best, int32_t a, int32_t b, int32_t ida, int
     st.ev_active = 1;
     st.ev_finish = 0;
     st.nops = 0;
+    st.pov_n = 0;
     st.m_old = st.m; st.P_old = st.P; st.c_old = st.c;
     Event& cur = st.cur;
     cur.m_before = st.m; cur.c_before = st.c;
@@ -1743,8 +1780,8 @@ struct PlanView {
     int32_t ix, ixn, iy, iyn;  // x, x.nbr, y, y.nbr (the merging nodes; -1: no partner)
     int32_t tdst[MAX_TGT], tkind[MAX_TGT], ta[MAX_TGT], tb[MAX_TGT], tc[MAX_TGT], td[MAX_TGT];  // the recipes (Tgt), sources as indices
 };
-template <class Uni>
-FNN_HD PlanView plan_view(const State& st, Uni uni) {  // uni(x): x as a wave-uniform value
+template <class Src, class Uni>
+FNN_HD PlanView plan_view(const Src& st, Uni uni) {  // uni(x): x as a wave-uniform value; Src: State, or the plan message of the fused event kernel
     PlanView v;
     v.m_old = uni(st.m_old); v.P_old = uni(st.P_old); v.ev_finish = uni(st.ev_finish);
     v.nS = uni(st.nS); v.ntgt = uni(st.ntgt); v.tU = uni(st.tU); v.tV = uni(st.tV);

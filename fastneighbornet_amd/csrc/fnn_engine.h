@@ -95,7 +95,8 @@ class Engine {
             !(dev.sid = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
             !(dev.spos = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
             !(dev.pslot = (int32_t*)be.alloc(sizeof(int32_t) * (nn + 8))) ||
-            !(dev.chain = (double*)be.alloc(sizeof(double) * 5 * (size_t)dev.cstride)) ||
+            !(dev.chain = (double*)be.alloc(sizeof(double) * CHAIN_BUFS * (size_t)dev.cstride)) ||
+            !(dev.plan = (uint64_t*)be.alloc(sizeof(uint64_t) * PLAN_WORDS)) ||
             !(dev.recs = (Cand*)be.alloc(sizeof(Cand) * be.max_records(n))) ||
             !(dev.rchk = (uint64_t*)be.alloc(sizeof(uint64_t) * (2048 + 8))) ||
             !(dev.T = (double*)be.alloc(sizeof(double) * (nn + 8))) ||
@@ -139,7 +140,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.recs); be.free(dev.rchk); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.wsend); be.free(dev.wrecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.rperm); be.free(dev.rl_stamp); be.free(dev.rl_cnt); be.free(dev.rl_list); be.free(dev.rl_val); be.free(dev.rl_mail); be.free(dev.ticks); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.plan); be.free(dev.recs); be.free(dev.rchk); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.wsend); be.free(dev.wrecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.rperm); be.free(dev.rl_stamp); be.free(dev.rl_cnt); be.free(dev.rl_list); be.free(dev.rl_val); be.free(dev.rl_mail); be.free(dev.ticks); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }
@@ -184,6 +185,14 @@ class Engine {
             return fail(FNN_EHIP, "fnn_set_matrix_device: copy failed (" + be.err() + ")");
         have_matrix = true;
         begun = ended = false;
+        return FNN_OK;
+    }
+
+    int32_t get_matrix(double* out, int64_t ld_out) {
+        if (!out || ld_out < n) return fail(FNN_EINVAL, "fnn_get_matrix: bad arguments");
+        if (!have_matrix) return fail(FNN_ESTATE, "fnn_get_matrix: no matrix resident (upload or fnn_synth first; a run consumes it)");
+        if (n > 0 && (be.sync() != FNN_OK || be.d2h_2d(out, ld_out, dev.D, ld, n, n) != FNN_OK))
+            return fail(FNN_EHIP, "fnn_get_matrix: download failed (" + be.err() + ")");
         return FNN_OK;
     }
 
@@ -280,7 +289,7 @@ class Engine {
             return fail(FNN_EHIP, "fnn_begin: state upload failed (" + be.err() + ")");
         if (be.memset(dev.islot, 0xFF, sizeof(int32_t) * (3 * (size_t)(n > 0 ? n : 1) + 8)) != FNN_OK ||
             be.memset(dev.cstamp, 0, sizeof(int32_t) * (3 * (size_t)(n > 0 ? n : 1) + 8)) != FNN_OK ||
-            be.memset(dev.ticket, 0, sizeof(uint32_t) * 32 * 72) != FNN_OK || be.memset(dev.lacnt, 0, 256) != FNN_OK || be.memset(dev.ticks, 0, sizeof(int64_t) * 32) != FNN_OK)
+            be.memset(dev.ticket, 0, sizeof(uint32_t) * 32 * 72) != FNN_OK || be.memset(dev.plan, 0, sizeof(uint64_t) * PLAN_WORDS) != FNN_OK || be.memset(dev.lacnt, 0, 256) != FNN_OK || be.memset(dev.ticks, 0, sizeof(int64_t) * 32) != FNN_OK)
             return fail(FNN_EHIP, "fnn_begin: memset failed (" + be.err() + ")");
         if (n > 3) {
             // max |D| (error bounds of the screening pass and of the certified 4-candidate choice), the bf16 copy if wanted

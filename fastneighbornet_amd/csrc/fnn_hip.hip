@@ -1467,6 +1467,12 @@ struct DecideLds {
     double tfin[2];            // T of the previous event's new cluster, just summed
     double rx[4];
     Quad qd;
+    // fused event kernel (k_track with fuse): the plan message (sent by the deciding workgroup, received by the column workgroups),
+    // the slot of the previous event's cluster whose T the decide step has just summed (tfin; -2: none), and the deciding
+    // workgroup's copy of the involved slots' block
+    PlanMsg msg;
+    int32_t msg_pU, berr;
+    double blk[MAX_S * MAX_S], sxl[MAX_S], tl[MAX_S];
 };
 
 constexpr int ST_NW = (int)(sizeof(State) / 4);
@@ -1566,6 +1572,7 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
     const bool need = S.need != 0;
     const int32_t m = lst.m, P = lst.P;
     const int32_t tpU = lst.tp_n > 0 ? lst.tp_U : -2;
+    if (tid == 0) S.msg_pU = tpU;
     // ONE round trip: wave 0 fetches the table entries the plan can touch, the 4 x 4 block of the matrix over the two
     // clusters' nodes and their T; wave 1 sums the partial sums of T of the previous event's new cluster
     if (wv == 0) {
@@ -2154,21 +2161,24 @@ constexpr int TRK_THREADS = 1024;
 constexpr int TRK_GROUP = 16;   // arrival tickets in two levels: same-address device-scope atomics cost ~50 ns each
 constexpr int TRK_FLAG = 32 * 65;  // word of d.ticket that carries "chain of event # done"
 constexpr int TRK_BAD = 32 * 67;   // word of d.ticket: a sweep item did not find the cluster it expected
-
-__device__ __forceinline__ void chain_deliver(const Dev& d, double usx) {
-    State* st = d.st;
-    d.Sx[st->chain_U] = usx;      // u.Sx and u.nbr.Sx (NetMakerOriginal.java:532, 535)
-    d.Sx[st->chain_U + 1] = usx;
-}
+constexpr int TRK_ERR = 32 * 66;   // word of d.ticket: a wait inside the fused event kernel ran into its deadline (reported by the next launch)
 
 __device__ __forceinline__ void chain_workgroup(const Dev& d, ChainLds<CH_EPT>& L) {
     State* st = d.st;
     if (!st->chain_pending) return;
-    const double usx = block_chain_sum2<CH_EPT>(d.chain, st->chain_m, CH_GUARD_BITS, L, nullptr);
+    // (everything this workgroup needs from the control block is read NOW: in the fused event kernel the deciding workgroup
+    //  closes the event and writes the control block back while this sum may still be running)
+    const int32_t cU = st->chain_U, cm = st->chain_m, cb = st->chain_buf;
+    const unsigned evtag = (unsigned)st->n_events;
+    const double usx = block_chain_sum2<CH_EPT>(d.chain + (size_t)cb * d.cstride, cm, CH_GUARD_BITS, L, nullptr);
     if (threadIdx.x == 0) {
-        chain_deliver(d, usx);
+        // u.Sx and u.nbr.Sx (NetMakerOriginal.java:532, 535): write-through, drained, then the flag - column threads of the
+        // SAME launch may be waiting for them (fused event kernel); every later kernel sees them anyway
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(d.Sx + cU), __builtin_bit_cast(uint64_t, usx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(d.Sx + cU + 1), __builtin_bit_cast(uint64_t, usx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __threadfence();
-        __hip_atomic_store(d.ticket + TRK_FLAG, (unsigned)st->n_events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d.ticket + TRK_FLAG, evtag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -2194,268 +2204,8 @@ __device__ __forceinline__ void sweep_exact_item(const Dev& d, int64_t r, const 
 
 constexpr int TRK_REC_U = 1024;  // offset of the swept-pair records in d.recs
 
-template <bool HELP>
-__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed, int has_scan, int tgroup, int ticks, unsigned jobtag) {
-    __shared__ ChainLds<CH_EPT> L;
-    __shared__ DecideLds S;
-    __shared__ Cand sh[TRK_THREADS / 64], shu[TRK_THREADS / 64];
-    __shared__ int lastflag;
-    __shared__ double shs[2];
-    __shared__ unsigned hword;
-    State* st = d.st;
-    if (blockIdx.x == 0) {  // the chain workgroup
-        chain_workgroup(d, L);
-        return;
-    }
-    const int wg = (int)blockIdx.x - 1, G = (int)gridDim.x - 1 - (HELP ? TRK_NHELP : 0);
-    if (HELP && wg >= G) {  // a helper workgroup of the exact ComputeRx sums (see decide_step)
-        rx_helper_workgroup(d, L, wg - G, jobtag, &hword);
-        return;
-    }
-    // phase split of the last-arriving workgroup (diagnostic, FNN_TICKS=1): thread 0 stamps the 100 MHz clock
-    const bool prof = ticks != 0 && threadIdx.x == 0;
-#define TRK_TICK(slot) do { if (prof) S.tk[(slot) + 1] = (long long)wall_clock64(); } while (0)
-    if (threadIdx.x == 0) S.tkon = ticks;
-    if (prof) S.tk[0] = (long long)wall_clock64();
-    // (this thread's first tracked pair is fetched beside the control block: its address depends on nothing)
-    const int64_t start = (int64_t)wg * TRK_THREADS + threadIdx.x;
-    PairRec rec0;
-    rec0.wa = rec0.wb = 0; rec0.sa = rec0.sb = -1;
-    rec0.e[0] = rec0.e[1] = rec0.e[2] = rec0.e[3] = 0.0;
-    if (start < LA_PCAP) rec0 = track_pair_load(d, start);
-    if (st->done) {
-        if (wg == 0 && threadIdx.x == 0) {
-            st->ev_active = 0;  // (a launch sequence without a decide kernel must not replay the last event)
-            if (HELP) job_post(d, jobtag, 0u);
-        }
-        return;
-    }
-    // every tracking workgroup fetches the control block now (nothing writes to it while they track): the one that
-    // arrives last continues on this LDS copy and writes it back at the end
-    state_in(S.lst, st);
-    if (!has_scan && st->stall) {  // (the launch sequence has no scan kernels and the window is gone: nothing to do)
-        if (wg == 0 && threadIdx.x == 0) {
-            st->n_stalled++;
-            if (HELP) job_post(d, jobtag, 0u);
-        }
-        return;
-    }
-    if (force_base || !la_active(*st)) {
-        if (wg == 0 && threadIdx.x == 0) {
-            if (HELP) job_post(d, jobtag, 0u);
-            st->ev_timed = timed;
-            if (st->la_valid) st->la_prev_end = 0;  // the window ends on schedule
-            la_prepare_base(*st, d.lacnt);
-            st->stall = has_scan ? 0 : 1;
-            if (!has_scan) st->n_stalled++;
-        }
-        return;
-    }
-    TrackArgs ta = track_args(*st);
-    const int64_t items = track_item_count(ta);
-    // The swept cluster's exact row sum is being computed by workgroup 0: the sweep runs on the tree-ordered
-    // sum of k_update's partials, which are fetched now and summed after the tracked pairs (their loads
-    // overlap).  (More than one unswept cluster is not expected: the window ends.)
-    double eps_u = 0.0;
-    bool giveup = false;  // the window cannot serve this event: it ends here (as after a failed certification)
-    const bool pending = st->chain_pending != 0 && ta.nf > ta.nf0;
-    if (pending && ta.nf - ta.nf0 != 1) giveup = true;
-    const bool approx = pending && !giveup;
-    double2 up0 = make_double2(0.0, 0.0), up1 = up0, up2 = up0;
-    const int npart = approx ? st->upart_n : 0;
-    if (threadIdx.x < 64) {
-        const double2* up = reinterpret_cast<const double2*>(d.upart);  // [workgroup] {sum, sum of magnitudes | T partials}
-        if ((int)threadIdx.x < npart) up0 = up[2 * threadIdx.x];
-        if ((int)threadIdx.x + 64 < npart) up1 = up[2 * (threadIdx.x + 64)];
-        if ((int)threadIdx.x + 128 < npart) up2 = up[2 * (threadIdx.x + 128)];
-    }
-    Cand best, bestu;
-    best = cand_none();
-    bestu = best;
-    const int64_t stride = (int64_t)G * TRK_THREADS;
-    TRK_TICK(0);
-    if (start < ta.np) track_pair_rec(d, rec0, ta, best);
-    for (int64_t it = start + stride; it < ta.np; it += stride) track_pair_item(d, it, ta, best);
-    TRK_TICK(1);
-    if (approx) {
-        if (threadIdx.x < 64) {
-            double su = (up0.x + up1.x) + up2.x, sa = (up0.y + up1.y) + up2.y;
-            for (int b = threadIdx.x + 192; b < npart; b += 64) { su += d.upart[4 * b]; sa += d.upart[4 * b + 1]; }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) { su += __shfl_down(su, off, 64); sa += __shfl_down(sa, off, 64); }
-            if (threadIdx.x == 0) { shs[0] = su; shs[1] = sa; }
-        }
-        __syncthreads();
-        ta.approx = 1;
-        ta.usl = st->chain_U;
-        ta.sxu = shs[0];
-        // both the sequential and the tree order are within gamma_m sum|terms| of the exact sum
-        eps_u = 4.0 * ((double)ta.m + 8.0) * 1.1102230246251565e-16 * shs[1];
-    }
-    bool swept_ok = true;
-    // (the sweep items are dealt out from the far end of the grid: tracked pairs and sweep run side by side in
-    //  different workgroups as long as there are fewer items than threads)
-    if (!giveup)
-        for (int64_t r = stride - 1 - start; r < items - ta.np; r += stride) swept_ok = track_sweep_item(d, r, ta, best, bestu) && swept_ok;
-    if (!swept_ok) atomicOr(d.ticket + TRK_BAD, 1u);  // (not expected: the swept cluster is not the chain's)
-    TRK_TICK(2);
-    // both minima in one pass: wave reduction, one barrier, thread 0 folds the waves
-    {
-        best = wave_reduce(best);
-        if (ta.approx) bestu = wave_reduce(bestu);
-        const int lane_ = threadIdx.x & 63, w_ = threadIdx.x >> 6;
-        if (lane_ == 0) { sh[w_] = best; shu[w_] = bestu; }
-        __syncthreads();
-        if (w_ == 0) {  // the waves' minima: one more wave reduction (no serial walk through LDS)
-            Cand b2, bu2;
-            b2 = cand_none(); bu2 = b2;
-            if (lane_ < TRK_THREADS / 64) { b2 = sh[lane_]; bu2 = shu[lane_]; }
-            best = wave_reduce(b2);
-            if (ta.approx) bestu = wave_reduce(bu2);
-            if (lane_ == 0) {
-                rec_publish(&d.recs[wg], best, d.rchk + wg, (uint32_t)st->n_events);
-                if (ta.approx) rec_publish(&d.recs[TRK_REC_U + wg], bestu, d.rchk + TRK_REC_U + wg, (uint32_t)st->n_events);
-            }
-        }
-    }
-    TRK_TICK(3);
-    if (threadIdx.x == 0) {
-        // the record went out write-through (rec_publish) from this very thread: once its stores are acknowledged
-        // the arrival may be counted - no release fence (a cache write-back) on the event chain
-        __builtin_amdgcn_s_waitcnt(0);
-        // last of its group of TRK_GROUP workgroups -> last of the groups (counters 128 bytes apart)
-        const unsigned g = (unsigned)wg / (unsigned)tgroup, ngroups = ((unsigned)G + tgroup - 1) / (unsigned)tgroup;
-        const unsigned gsize = g + 1 < ngroups ? (unsigned)tgroup : (unsigned)G - g * tgroup;
-        int last = 0;
-        if (atomicAdd(d.ticket + 32 * (g + 1), 1u) == gsize - 1) {
-            d.ticket[32 * (g + 1)] = 0u;  // (read again by the next launch only)
-            last = atomicAdd(d.ticket, 1u) == ngroups - 1 ? 1 : 0;
-        }
-        lastflag = last;
-    }
-    __syncthreads();
-    if (!lastflag) return;
-    // (no acquire fence: the records are read past the caches, rec_fetch, after the barrier above)
-    TRK_TICK(4);
-    // from here on this workgroup works on its LDS copy of the control block (no other workgroup writes to it
-    // during this launch); the copy goes back at the end
-    State& lst = S.lst;
-    Dev dl = d;
-    dl.st = &lst;
-    // the records of all workgroups, both sets at once, by the first wave
-    if (threadIdx.x < 64) {
-        Cand b, bu;
-        b = cand_none();
-        bu = b;
-        const unsigned badword = __hip_atomic_load(d.ticket + TRK_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t tag = (uint32_t)st->n_events;
-        bool stale = false, reread = false;
-        for (int pass = 0; pass < 2; pass++) {
-            b = cand_none();
-            bu = b;
-            stale = false;
-            for (int i = threadIdx.x; i < G; i += 64) {
-                Cand c = rec_fetch(&d.recs[i]);
-                if (rec_check_word(c, tag) != __hip_atomic_load(d.rchk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) stale = true;
-                if (cand_better(c, b)) b = c;
-                if (ta.approx) {
-                    c = rec_fetch(&d.recs[TRK_REC_U + i]);
-                    if (rec_check_word(c, tag) != __hip_atomic_load(d.rchk + TRK_REC_U + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) stale = true;
-                    if (cand_better(c, bu)) bu = c;
-                }
-            }
-            stale = __ballot(stale) != 0ULL;
-            if (!stale) break;
-            reread = true;
-            __threadfence();  // (not expected: see rec_publish)
-        }
-        b = wave_reduce(b);
-        if (ta.approx) bu = wave_reduce(bu);
-        if (threadIdx.x == 0) {
-            sh[0] = b;
-            shu[0] = bu;
-            if (badword != 0u) {
-                d.ticket[TRK_BAD] = 0u;
-                lastflag = 2;
-            }
-            if (stale) lastflag = 2;  // (a record that could not be read back intact: the window gives this event up)
-            if (reread) S.lst.n_ev_persistent++;
-        }
-    }
-    __syncthreads();
-    best = sh[0];
-    bestu = shu[0];
-    if (lastflag == 2) {
-        giveup = true;
-        if (d.strict && threadIdx.x == 0) S.lst.error = 13;  // several ranks: a give-up the other ranks cannot see would desynchronise them
-    }
-    __syncthreads();
-    TRK_TICK(5);
-    if (ta.approx && !giveup) {
-        // |Q~ - Q| <= eps_u + the roundings of (c-2) D - Sp - Sq, each <= 2^-53 of a term <= (c + 2n) Dmax
-        const double dmax = __builtin_bit_cast(double, st->dmax_bits);
-        const double margin = 2.0 * eps_u + 192.0 * 1.1102230246251565e-16 * ((double)st->n + 4.0) * dmax + 1e-300;
-        const bool certain = (bestu.q - margin > best.q) || (bestu.q == inf_f64());
-        if (!certain) {
-            // a swept pair may be the minimum: wait for the chain workgroup, sweep again with the exact sum
-            if (threadIdx.x == 0) {
-                const unsigned want = (unsigned)lst.n_events;
-                const long long t_wait = (long long)wall_clock64();
-                while (__hip_atomic_load(d.ticket + TRK_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-                    if ((long long)wall_clock64() - t_wait > TRK_WAIT_TICKS) { lst.error = 10; break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                __threadfence();
-                lst.n_sweep_waits++;
-            }
-            __syncthreads();
-            Cand bx;
-            bx = cand_none();
-            for (int64_t r = threadIdx.x; r < items - ta.np; r += TRK_THREADS) sweep_exact_item(d, r, ta, bx);
-            bx = block_reduce<TRK_THREADS / 64>(bx, sh);
-            if (threadIdx.x == 0) sh[0] = bx;
-            __syncthreads();
-            bx = sh[0];
-            if (cand_better(bx, best)) best = bx;
-        }
-        // certain: every swept pair's exact Q lies strictly above best.q, so best wins as it stands
-    }
-    if (giveup) { best = cand_none(); }
-    if (threadIdx.x == 0) {
-        *d.ticket = 0u;
-        lst.ev_timed = timed;
-        if (giveup) lst.n_sweep_waits++;
-        la_track_done(dl, best, ta);
-        lst.stall = (!lst.la_hit && !has_scan) ? 1 : 0;
-        if (lst.stall) lst.n_stalled++;
-    }
-    __syncthreads();
-    TRK_TICK(6);
-    // the window has certified the minimum: Cx / Cy, the 4-candidate choice and the merge plan follow at once
-    // (the launch sequence of a window event has no decide kernel); otherwise the event scans (or stalls)
-    if (lst.la_hit) decide_step<HELP>(d, S, L, best, jobtag);
-    else if (HELP && threadIdx.x == 0) job_post(d, jobtag, 0u);  // (the event scans or stalls: nothing for the helpers)
-    TRK_TICK(7);
-    if (prof) {
-        for (int q = 0; q < 8; q++) d.ticks[q] += S.tk[q + 1] - S.tk[q];
-    }
-    __syncthreads();
-    state_out(st, lst);
-#undef TRK_TICK
-}
-
-// ------------------------------------------------------------------ k_update
-// subtract + every micro-op + add of one event in ONE launch (fnn_core.h: update_bulk /
-// update_special).  The last workgroup handles the <= 8 involved slots in phases.
-// The involved slots' phases (fnn_core.h: subtract_thread / op_thread / add_thread on the S x S block) by ONE wave:
-// lane i < nS owns involved slot S[i] and column i of the block in LDS.  The generic bodies address the block through
-// slot numbers (a search per access: ~1000 instructions per phase for a lone wave); here every operand of a phase is
-// resolved once - slots that are the same for all lanes by a ballot, a lane's own partner by eight readlanes up front -
-// so a phase is a few dozen instructions.  Same operations, same order, same roundings as the generic bodies (which
-// the CPU emulation runs against the oracle); the GPU parity tests compare Sx, T's consumers and the live matrix
-// after every event.  Returns this lane's addends {row-sum addend, T terms of u, v} of the add phase.
 struct SpecialOut { double val, tu, tv; };
-__device__ __forceinline__ SpecialOut special_wave(const Dev& d, const State& lst, double* blk, double* sxl, double* tl, int32_t* berr) {
+__device__ __forceinline__ SpecialOut special_wave(const Dev& d, const State& lst, double* blk, double* sxl, double* tl, int32_t* berr, double* chain_dst) {
     const int lane = threadIdx.x & 63;
     const int nS = __builtin_amdgcn_readfirstlane(lst.nS);
     const int32_t Sl = lane < nS ? lst.S[lane < MAX_S ? lane : 0] : -1;
@@ -2599,7 +2349,7 @@ __device__ __forceinline__ SpecialOut special_wave(const Dev& d, const State& ls
                 const double uv = B(iU, iV);
                 out.tu = 0.5 * uv; out.tv = 0.5 * uv;
             }
-            d.chain[chain_addr(myspos)] = val;
+            chain_dst[chain_addr(myspos)] = val;
             out.val = val;
         }
     }
@@ -2609,6 +2359,583 @@ __device__ __forceinline__ SpecialOut special_wave(const Dev& d, const State& ls
 
 struct UniLane { __device__ __forceinline__ int32_t operator()(int32_t x) const { return __builtin_amdgcn_readfirstlane(x); } };
 
+// ------------------------------------------------------------------ the column thread of the update
+// ONE thread per column (node) - the two columns of a paired cluster sit in adjacent lanes and exchange the two
+// or four values the cluster distances need by shuffles.  (fnn_core.h: update_bulk is the same computation with
+// one thread per cluster; the CPU emulation runs that one against the oracle.  A wave runs alone on its SIMD
+// here and issues one instruction every ~4 cycles, so the length of a thread's instruction stream IS the
+// duration: splitting the pair halves it.)  All 64 lanes of a wave must call it (shuffles).
+// FUSED (k_track with fuse): the column threads run in the SAME launch as the decide step and the chain workgroup; what
+// those produce for a column comes in through `fx` instead of plain loads.
+struct BulkFix {
+    int32_t cU = -2, chain_wait = 0; unsigned evtag = 0;   // Sx[cU], Sx[cU + 1]: delivered by the chain workgroup of this launch
+    int32_t pU = -2; double tfin0 = 0.0, tfin1 = 0.0;      // T[pU], T[pU + 1]: summed by this launch's decide step
+    int32_t pov_n = 0, pov_slot[2] = {-1, -1}, pov_pos[2] = {0, 0};  // reference positions the plan changed (State.pov_*)
+};
+template <bool FUSED>
+__device__ __forceinline__ void bulk_column(const Dev& d, const PlanView& pv, const int32_t k, double* __restrict__ chain_dst, const BulkFix& fx,
+                                            double& dsum, double& dabs, double& tu, double& tv) {
+    const bool paired = k < 2 * pv.P_old;
+    bool act = k < pv.m_old;
+#pragma unroll
+    for (int i = 0; i < MAX_S; i++) if (i < pv.nS && pv.S[i] == k) act = false;
+    // everything a column reads, in one batch: its entries in the rows of all involved slots, Sx, T, position
+    double e[MAX_S];
+    const double* colp = d.D + k;
+#pragma unroll
+    for (int i = 0; i < MAX_S; i++) e[i] = (act && i < pv.nS) ? colp[(int64_t)pv.S[i] * d.ld] : 0.0;
+    double sx = act ? d.Sx[k] : 0.0;
+    double t_old = act ? d.T[k] : 0.0;
+    int32_t pos = act ? d.spos[k] : 0;
+    if (FUSED && act) {
+        // what this launch itself produced cannot be read with plain loads (other compute units, other L2 slices):
+        if (k == fx.pU) t_old = fx.tfin0;          // T of the previous event's cluster: summed by this launch's decide step
+        if (k == fx.pU + 1) t_old = fx.tfin1;
+#pragma unroll
+        for (int q = 0; q < 2; q++) if (q < fx.pov_n && k == fx.pov_slot[q]) pos = fx.pov_pos[q];  // a position the plan changed
+        if (fx.chain_wait && (k == fx.cU || k == fx.cU + 1)) {  // its exact row sum: from the chain workgroup of this launch
+            const long long t0 = (long long)wall_clock64();
+            while (__hip_atomic_load(d.ticket + TRK_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != fx.evtag) {
+                if ((long long)wall_clock64() - t0 > TRK_WAIT_TICKS) { atomicOr(d.ticket + TRK_ERR, 1u); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            sx = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const uint64_t*>(d.Sx + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+    }
+    const bool odd = (k & 1) != 0;
+    double told = 0.0;
+    if (!pv.ev_finish) {
+        // subtractClusterDistance(p, x); subtractClusterDistance(p, y) (:455-461, 681-696)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int32_t it = q == 0 ? pv.ix : pv.iy, itn = q == 0 ? pv.ixn : pv.iyn;
+            const double me0 = it >= 0 ? e[it] : 0.0, mf0 = itn >= 0 ? e[itn] : 0.0;   // this column's entries towards t, t.nbr
+            const double oe = __shfl_xor(me0, 1, 64), of = __shfl_xor(mf0, 1, 64);     // ... and the partner column's
+            const double e0 = odd ? oe : me0, f0 = odd ? of : mf0, e1 = odd ? me0 : oe, f1 = odd ? mf0 : of;
+            double v;
+            if (!paired && itn < 0) { v = me0; told += me0; }
+            else if (paired && itn < 0) { v = (e0 + e1) / 2.0; told += me0; }
+            else if (!paired && itn >= 0) { v = (me0 + mf0) / 2.0; told += 0.5 * (me0 + mf0); }
+            else { v = (((e0 + f0) + e1) + f1) / 4.0; told += 0.5 * (me0 + mf0); }
+            sx -= v;
+        }
+    }
+    // the rows that change, at this column (all values first: a changed row may be the source of another)
+    double nv[MAX_TGT];
+    double um = 0.0, vm = 0.0;
+#pragma unroll
+    for (int t = 0; t < MAX_TGT; t++) {
+        nv[t] = 0.0;
+        if (t < pv.ntgt) {
+            nv[t] = tgt_eval(pv, t, [&](int32_t i) { return e[i]; });
+            if (t == pv.tU) um = nv[t];
+            if (t == pv.tV) vm = nv[t];
+        }
+    }
+    if (act) {
+        const int64_t rk = (int64_t)k * d.ld;
+#pragma unroll
+        for (int t = 0; t < MAX_TGT; t++) {
+            if (t < pv.ntgt) {
+                // the entry and its mirror; of the two only the one at or below the diagonal has a bf16 copy
+                const int32_t dst = pv.tdst[t];
+                const int64_t rb = (int64_t)dst * d.ld;
+                d.D[rb + k] = nv[t];
+                d.D[rk + dst] = nv[t];
+                if (d.H) d.H[k < dst ? (int64_t)dst * d.ldh + k : (int64_t)k * d.ldh + dst] = bf16_from_double(nv[t]);
+            }
+        }
+    }
+    if (!pv.ev_finish) {
+        // updateClusterDistances, per-node part (:520-531)
+        const double uo = __shfl_xor(um, 1, 64), vo = __shfl_xor(vm, 1, 64);
+        const double u0 = odd ? uo : um, v0 = odd ? vo : vm, u1 = odd ? um : uo, v1 = odd ? vm : vo;
+        const double dpu = paired ? (((u0 + v0) + u1) + v1) / 4.0 : (um + vm) / 2.0;
+        if (act) {
+            const bool rep = !paired || !odd;
+            d.Sx[k] = sx + dpu;
+            chain_dst[chain_addr(pos)] = rep ? dpu : 0.0;
+            d.T[k] = (t_old - told) + 0.5 * (um + vm);
+            dsum = rep ? dpu : 0.0;
+            dabs = dsum < 0.0 ? -dsum : dsum;
+            tu = paired ? 0.5 * um : um;
+            tv = paired ? 0.5 * vm : vm;
+        }
+    }
+}
+
+
+// ---- the plan message of the fused event kernel (fnn_core.h: PlanMsg) ----
+// post: wave 0 of the deciding workgroup, from its LDS copy; every word carries the launch's tag, so no flag and no drain
+__device__ __forceinline__ void plan_post(const Dev& d, const PlanMsg& m, unsigned tag) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&m);
+    __hip_atomic_store(d.plan + lane, ((uint64_t)tag << 32) | w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d.plan + 64 + lane, ((uint64_t)tag << 32) | w[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// "no update in this launch" (kind 0): the waiting workgroups leave.  One wave.
+__device__ __forceinline__ void plan_post_none(const Dev& d, unsigned tag) {
+    const int lane = threadIdx.x & 63;
+    __hip_atomic_store(d.plan + lane, (uint64_t)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(d.plan + 64 + lane, (uint64_t)tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wait (wave 0 polls, the whole workgroup joins at the barrier); a deadline instead of a hang
+__device__ __forceinline__ void plan_wait(const Dev& d, PlanMsg& m, unsigned tag) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        uint32_t* w = reinterpret_cast<uint32_t*>(&m);
+        const long long t0 = (long long)wall_clock64();
+        for (;;) {
+            const uint64_t a = __hip_atomic_load(d.plan + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t b = __hip_atomic_load(d.plan + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool ok = (uint32_t)(a >> 32) == tag && (uint32_t)(b >> 32) == tag;
+            if (__ballot(ok) == ~0ULL) { w[lane] = (uint32_t)a; w[64 + lane] = (uint32_t)b; break; }
+            if ((long long)wall_clock64() - t0 > TRK_WAIT_TICKS) {
+                w[lane] = 0u; w[64 + lane] = 0u;  // (kind = 0)
+                if (lane == 0) atomicOr(d.ticket + TRK_ERR, 2u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+
+// fuse != 0: a WINDOW event in ONE launch.  The launch sequence has no scan kernels (has_scan == 0) and no k_update: when
+// the window serves the event, the deciding workgroup (the tracking workgroup that arrives last) posts the plan as a message
+// (plan_post), runs the involved slots' phases itself and closes the event; tracking workgroup b < ceil(m / 1024) has waited for
+// the message and now updates the columns [1024 b, 1024 b + 1024) (bulk_column<true>); the SPARE workgroup (the launch's last)
+// takes the block of the deciding workgroup.  Saves a kernel boundary per event (~4.5 us: dispatch, the release at the end of
+// one kernel and the acquire at the start of the next) at the price of one message round trip (~1 us), and the chain
+// workgroup's exact row sum (14-23 us) now runs beside tracking AND update.  What the launch itself produces for a column
+// thread - T of the previous event's cluster (decide step), its exact row sum (chain workgroup), reference positions the plan
+// moved - travels in the message or is read write-through (BulkFix); the row-sum addends alternate between two chain buffers
+// (State.chain_buf) because the chain workgroup of this launch is still reading the other one.
+template <bool HELP>
+__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed, int has_scan, int tgroup, int ticks, unsigned jobtag, int fuse) {
+    __shared__ ChainLds<CH_EPT> L;
+    __shared__ DecideLds S;
+    __shared__ Cand sh[TRK_THREADS / 64], shu[TRK_THREADS / 64];
+    __shared__ int lastflag;
+    __shared__ double shs[2];
+    __shared__ unsigned hword;
+    __shared__ double shp[TRK_THREADS / 64][4];
+    State* st = d.st;
+    if (blockIdx.x == 0) {  // the chain workgroup
+        chain_workgroup(d, L);
+        return;
+    }
+    const bool spare = fuse != 0 && blockIdx.x == gridDim.x - 1;
+    const int wg = (int)blockIdx.x - 1, G = (int)gridDim.x - 1 - (HELP ? TRK_NHELP : 0) - (fuse ? 1 : 0);
+    if (HELP && !spare && wg >= G) {  // a helper workgroup of the exact ComputeRx sums (see decide_step)
+        rx_helper_workgroup(d, L, wg - G, jobtag, &hword);
+        return;
+    }
+    // phase split of the last-arriving workgroup (diagnostic, FNN_TICKS=1): thread 0 stamps the 100 MHz clock
+    const bool prof = ticks != 0 && threadIdx.x == 0;
+#define TRK_TICK(slot) do { if (prof) S.tk[(slot) + 1] = (long long)wall_clock64(); } while (0)
+    // The tracking part.  Returns the block of columns this workgroup updates once the plan message is there (-1: none, -2: it
+    // has to wait for the message to know).
+    auto track = [&]() -> int {
+    if (threadIdx.x == 0) S.tkon = ticks;
+    if (prof) S.tk[0] = (long long)wall_clock64();
+    // (this thread's first tracked pair is fetched beside the control block: its address depends on nothing)
+    const int64_t start = (int64_t)wg * TRK_THREADS + threadIdx.x;
+    PairRec rec0;
+    rec0.wa = rec0.wb = 0; rec0.sa = rec0.sb = -1;
+    rec0.e[0] = rec0.e[1] = rec0.e[2] = rec0.e[3] = 0.0;
+    if (start < LA_PCAP) rec0 = track_pair_load(d, start);
+    if (st->done) {
+        if (wg == 0) {
+            if (threadIdx.x == 0) {
+                st->ev_active = 0;  // (a launch sequence without a decide kernel must not replay the last event)
+                if (HELP) job_post(d, jobtag, 0u);
+            }
+            if (fuse && threadIdx.x < 64) plan_post_none(d, jobtag);
+        }
+        return -1;
+    }
+    // every tracking workgroup fetches the control block now (nothing writes to it while they track): the one that
+    // arrives last continues on this LDS copy and writes it back at the end
+    state_in(S.lst, st);
+    if (!has_scan && st->stall) {  // (the launch sequence has no scan kernels and the window is gone: nothing to do)
+        if (wg == 0) {
+            if (threadIdx.x == 0) {
+                st->n_stalled++;
+                if (HELP) job_post(d, jobtag, 0u);
+            }
+            if (fuse && threadIdx.x < 64) plan_post_none(d, jobtag);
+        }
+        return -1;
+    }
+    if (force_base || !la_active(*st)) {
+        if (wg == 0) {
+            if (threadIdx.x == 0) {
+                if (HELP) job_post(d, jobtag, 0u);
+                st->ev_timed = timed;
+                if (st->la_valid) st->la_prev_end = 0;  // the window ends on schedule
+                la_prepare_base(*st, d.lacnt);
+                st->stall = has_scan ? 0 : 1;
+                if (!has_scan) st->n_stalled++;
+            }
+            if (fuse && threadIdx.x < 64) plan_post_none(d, jobtag);
+        }
+        return -1;
+    }
+    // (fused event kernel) the pending row sum as the control block describes it at the START of the launch
+    const int32_t chain_pending0 = st->chain_pending, chain_buf0 = st->chain_buf, chain_U0 = st->chain_U, m0 = st->m;
+    const unsigned evtag0 = (unsigned)st->n_events;
+    const int nbulk = (m0 + TRK_THREADS - 1) / TRK_THREADS;
+    TrackArgs ta = track_args(*st);
+    const int64_t items = track_item_count(ta);
+    // The swept cluster's exact row sum is being computed by workgroup 0: the sweep runs on the tree-ordered
+    // sum of k_update's partials, which are fetched now and summed after the tracked pairs (their loads
+    // overlap).  (More than one unswept cluster is not expected: the window ends.)
+    double eps_u = 0.0;
+    bool giveup = false;  // the window cannot serve this event: it ends here (as after a failed certification)
+    const bool pending = chain_pending0 != 0 && ta.nf > ta.nf0;
+    if (pending && ta.nf - ta.nf0 != 1) giveup = true;
+    const bool approx = pending && !giveup;
+    double2 up0 = make_double2(0.0, 0.0), up1 = up0, up2 = up0;
+    const int npart = approx ? st->upart_n : 0;
+    if (threadIdx.x < 64) {
+        const double2* up = reinterpret_cast<const double2*>(d.upart);  // [workgroup] {sum, sum of magnitudes | T partials}
+        if ((int)threadIdx.x < npart) up0 = up[2 * threadIdx.x];
+        if ((int)threadIdx.x + 64 < npart) up1 = up[2 * (threadIdx.x + 64)];
+        if ((int)threadIdx.x + 128 < npart) up2 = up[2 * (threadIdx.x + 128)];
+    }
+    Cand best, bestu;
+    best = cand_none();
+    bestu = best;
+    const int64_t stride = (int64_t)G * TRK_THREADS;
+    TRK_TICK(0);
+    if (start < ta.np) track_pair_rec(d, rec0, ta, best);
+    for (int64_t it = start + stride; it < ta.np; it += stride) track_pair_item(d, it, ta, best);
+    TRK_TICK(1);
+    if (approx) {
+        if (threadIdx.x < 64) {
+            double su = (up0.x + up1.x) + up2.x, sa = (up0.y + up1.y) + up2.y;
+            for (int b = threadIdx.x + 192; b < npart; b += 64) { su += d.upart[4 * b]; sa += d.upart[4 * b + 1]; }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { su += __shfl_down(su, off, 64); sa += __shfl_down(sa, off, 64); }
+            if (threadIdx.x == 0) { shs[0] = su; shs[1] = sa; }
+        }
+        __syncthreads();
+        ta.approx = 1;
+        ta.usl = chain_U0;
+        ta.sxu = shs[0];
+        // both the sequential and the tree order are within gamma_m sum|terms| of the exact sum
+        eps_u = 4.0 * ((double)ta.m + 8.0) * 1.1102230246251565e-16 * shs[1];
+    }
+    bool swept_ok = true;
+    // (the sweep items are dealt out from the far end of the grid: tracked pairs and sweep run side by side in
+    //  different workgroups as long as there are fewer items than threads)
+    if (!giveup)
+        for (int64_t r = stride - 1 - start; r < items - ta.np; r += stride) swept_ok = track_sweep_item(d, r, ta, best, bestu) && swept_ok;
+    if (!swept_ok) atomicOr(d.ticket + TRK_BAD, 1u);  // (not expected: the swept cluster is not the chain's)
+    TRK_TICK(2);
+    // both minima in one pass: wave reduction, one barrier, thread 0 folds the waves
+    {
+        best = wave_reduce(best);
+        if (ta.approx) bestu = wave_reduce(bestu);
+        const int lane_ = threadIdx.x & 63, w_ = threadIdx.x >> 6;
+        if (lane_ == 0) { sh[w_] = best; shu[w_] = bestu; }
+        __syncthreads();
+        if (w_ == 0) {  // the waves' minima: one more wave reduction (no serial walk through LDS)
+            Cand b2, bu2;
+            b2 = cand_none(); bu2 = b2;
+            if (lane_ < TRK_THREADS / 64) { b2 = sh[lane_]; bu2 = shu[lane_]; }
+            best = wave_reduce(b2);
+            if (ta.approx) bestu = wave_reduce(bu2);
+            if (lane_ == 0) {
+                rec_publish(&d.recs[wg], best, d.rchk + wg, evtag0);
+                if (ta.approx) rec_publish(&d.recs[TRK_REC_U + wg], bestu, d.rchk + TRK_REC_U + wg, evtag0);
+            }
+        }
+    }
+    TRK_TICK(3);
+    if (threadIdx.x == 0) {
+        // the record went out write-through (rec_publish) from this very thread: once its stores are acknowledged
+        // the arrival may be counted - no release fence (a cache write-back) on the event chain
+        __builtin_amdgcn_s_waitcnt(0);
+        // last of its group of TRK_GROUP workgroups -> last of the groups (counters 128 bytes apart)
+        const unsigned g = (unsigned)wg / (unsigned)tgroup, ngroups = ((unsigned)G + tgroup - 1) / (unsigned)tgroup;
+        const unsigned gsize = g + 1 < ngroups ? (unsigned)tgroup : (unsigned)G - g * tgroup;
+        int last = 0;
+        if (atomicAdd(d.ticket + 32 * (g + 1), 1u) == gsize - 1) {
+            d.ticket[32 * (g + 1)] = 0u;  // (read again by the next launch only)
+            last = atomicAdd(d.ticket, 1u) == ngroups - 1 ? 1 : 0;
+        }
+        lastflag = last;
+    }
+    __syncthreads();
+    if (!lastflag) return (fuse && wg < nbulk) ? -2 : -1;  // (fused: its block of columns, once the plan is there)
+    // (no acquire fence: the records are read past the caches, rec_fetch, after the barrier above)
+    TRK_TICK(4);
+    // from here on this workgroup works on its LDS copy of the control block (no other workgroup writes to it
+    // during this launch); the copy goes back at the end
+    State& lst = S.lst;
+    Dev dl = d;
+    dl.st = &lst;
+    // the records of all workgroups, both sets at once, by the first wave
+    if (threadIdx.x < 64) {
+        Cand b, bu;
+        b = cand_none();
+        bu = b;
+        const unsigned badword = __hip_atomic_load(d.ticket + TRK_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned errword = fuse ? __hip_atomic_load(d.ticket + TRK_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t tag = evtag0;
+        bool stale = false, reread = false;
+        for (int pass = 0; pass < 2; pass++) {
+            b = cand_none();
+            bu = b;
+            stale = false;
+            for (int i = threadIdx.x; i < G; i += 64) {
+                Cand c = rec_fetch(&d.recs[i]);
+                if (rec_check_word(c, tag) != __hip_atomic_load(d.rchk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) stale = true;
+                if (cand_better(c, b)) b = c;
+                if (ta.approx) {
+                    c = rec_fetch(&d.recs[TRK_REC_U + i]);
+                    if (rec_check_word(c, tag) != __hip_atomic_load(d.rchk + TRK_REC_U + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) stale = true;
+                    if (cand_better(c, bu)) bu = c;
+                }
+            }
+            stale = __ballot(stale) != 0ULL;
+            if (!stale) break;
+            reread = true;
+            __threadfence();  // (not expected: see rec_publish)
+        }
+        b = wave_reduce(b);
+        if (ta.approx) bu = wave_reduce(bu);
+        if (threadIdx.x == 0) {
+            sh[0] = b;
+            shu[0] = bu;
+            if (badword != 0u) {
+                d.ticket[TRK_BAD] = 0u;
+                lastflag = 2;
+            }
+            if (errword != 0u) S.lst.error = 16;  // a wait of an earlier fused launch ran into its deadline
+            if (stale) lastflag = 2;  // (a record that could not be read back intact: the window gives this event up)
+            if (reread) S.lst.n_ev_persistent++;
+        }
+    }
+    __syncthreads();
+    best = sh[0];
+    bestu = shu[0];
+    if (lastflag == 2) {
+        giveup = true;
+        if (d.strict && threadIdx.x == 0) S.lst.error = 13;  // several ranks: a give-up the other ranks cannot see would desynchronise them
+    }
+    __syncthreads();
+    TRK_TICK(5);
+    if (ta.approx && !giveup) {
+        // |Q~ - Q| <= eps_u + the roundings of (c-2) D - Sp - Sq, each <= 2^-53 of a term <= (c + 2n) Dmax
+        const double dmax = __builtin_bit_cast(double, st->dmax_bits);
+        const double margin = 2.0 * eps_u + 192.0 * 1.1102230246251565e-16 * ((double)st->n + 4.0) * dmax + 1e-300;
+        const bool certain = (bestu.q - margin > best.q) || (bestu.q == inf_f64());
+        if (!certain) {
+            // a swept pair may be the minimum: wait for the chain workgroup, sweep again with the exact sum
+            if (threadIdx.x == 0) {
+                const unsigned want = evtag0;
+                const long long t_wait = (long long)wall_clock64();
+                while (__hip_atomic_load(d.ticket + TRK_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+                    if ((long long)wall_clock64() - t_wait > TRK_WAIT_TICKS) { lst.error = 10; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __threadfence();
+                lst.n_sweep_waits++;
+            }
+            __syncthreads();
+            Cand bx;
+            bx = cand_none();
+            for (int64_t r = threadIdx.x; r < items - ta.np; r += TRK_THREADS) sweep_exact_item(d, r, ta, bx);
+            bx = block_reduce<TRK_THREADS / 64>(bx, sh);
+            if (threadIdx.x == 0) sh[0] = bx;
+            __syncthreads();
+            bx = sh[0];
+            if (cand_better(bx, best)) best = bx;
+        }
+        // certain: every swept pair's exact Q lies strictly above best.q, so best wins as it stands
+    }
+    if (giveup) { best = cand_none(); }
+    if (threadIdx.x == 0) {
+        *d.ticket = 0u;
+        lst.ev_timed = timed;
+        if (giveup) lst.n_sweep_waits++;
+        la_track_done(dl, best, ta);
+        lst.stall = (!lst.la_hit && !has_scan) ? 1 : 0;
+        if (lst.stall) lst.n_stalled++;
+    }
+    __syncthreads();
+    TRK_TICK(6);
+    // the window has certified the minimum: Cx / Cy, the 4-candidate choice and the merge plan follow at once
+    // (the launch sequence of a window event has no decide kernel); otherwise the event scans (or stalls)
+    if (lst.la_hit) decide_step<HELP>(d, S, L, best, jobtag);
+    else if (HELP && threadIdx.x == 0) job_post(d, jobtag, 0u);  // (the event scans or stalls: nothing for the helpers)
+    TRK_TICK(7);
+    if (prof) {
+        for (int q = 0; q < 8; q++) d.ticks[q] += S.tk[q + 1] - S.tk[q];
+    }
+    __syncthreads();
+    if (fuse) {
+        long long tk0 = prof ? (long long)wall_clock64() : 0;
+#define FUS_TICK(slot) do { if (prof) { const long long now_ = (long long)wall_clock64(); d.ticks[8 + (slot)] += now_ - tk0; tk0 = now_; } } while (0)
+        const bool upd = lst.la_hit && lst.ev_active;
+        if (!upd) {
+            if (threadIdx.x < 64) plan_post_none(d, jobtag);
+        } else {
+            // ---- the plan message: the tail of the control block (nS .. tgt) word for word, the scalars by thread 0
+            PlanMsg& M = S.msg;
+            const int chain_wait = chain_pending0 ? 1 : 0;
+            const int chain_dst = (chain_pending0 && chain_buf0 == 0) ? CHAIN_ALT : 0;
+            static_assert(offsetof(PlanMsg, fill) - offsetof(PlanMsg, nS) == 60 * 4 && sizeof(State) - offsetof(State, nS) == 60 * 4, "plan tail layout");
+            if (threadIdx.x >= 64 && threadIdx.x < 64 + 60) (&M.nS)[threadIdx.x - 64] = (&lst.nS)[threadIdx.x - 64];
+            if (threadIdx.x >= 128 && threadIdx.x < 128 + 44) M.fill[threadIdx.x - 128] = 0;
+            if (threadIdx.x == 0) {
+                M.kind = 1; M.last_wg = wg; M.pU = S.msg_pU; M.cU = chain_pending0 ? chain_U0 : -2; M.chain_wait = chain_wait;
+                M.evtag = (int32_t)evtag0; M.chain_dst = chain_dst; M.nbulk = nbulk;
+                M.pov_n = lst.pov_n; M.pov_slot[0] = lst.pov_slot[0]; M.pov_slot[1] = lst.pov_slot[1];
+                M.pov_pos[0] = lst.pov_pos[0]; M.pov_pos[1] = lst.pov_pos[1]; M.pad0 = 0;
+                const uint64_t t0b = __builtin_bit_cast(uint64_t, S.tfin[0]), t1b = __builtin_bit_cast(uint64_t, S.tfin[1]);
+                M.tfin[0] = (int32_t)(uint32_t)t0b; M.tfin[1] = (int32_t)(uint32_t)(t0b >> 32);
+                M.tfin[2] = (int32_t)(uint32_t)t1b; M.tfin[3] = (int32_t)(uint32_t)(t1b >> 32);
+                M.m_old = lst.m_old; M.P_old = lst.P_old; M.ev_finish = lst.ev_finish; M.xs = lst.xs; M.ys = lst.ys; M.pad1 = 0;
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) plan_post(d, M, jobtag);
+            FUS_TICK(0);
+            // ---- the involved slots' phases on this LDS copy (k_update's special workgroup, here without fetching the control block)
+            double* blk = S.blk; double* sxl = S.sxl; double* tl = S.tl;
+            if (threadIdx.x == 0) {
+                S.berr = 0;
+                bool needs = false;
+                for (int i = 0; i < lst.nS; i++) needs = needs || (chain_wait && (lst.S[i] == chain_U0 || lst.S[i] == chain_U0 + 1));
+                if (needs) {  // an involved slot's exact row sum is still on its way from the chain workgroup of this launch
+                    const long long t_wait = (long long)wall_clock64();
+                    while (__hip_atomic_load(d.ticket + TRK_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != evtag0) {
+                        if ((long long)wall_clock64() - t_wait > TRK_WAIT_TICKS) { lst.error = 10; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < MAX_S * MAX_S) {
+                const int32_t e = (int32_t)threadIdx.x, i = e / MAX_S, j = e % MAX_S;
+                special_block_load(dl, blk, sxl, tl, e);
+                if (i < lst.nS && j == 0 && chain_wait && (lst.S[i] == chain_U0 || lst.S[i] == chain_U0 + 1))
+                    sxl[i] = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const uint64_t*>(d.Sx + lst.S[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (i < lst.nS && j == 1 && S.msg_pU >= 0 && (lst.S[i] == S.msg_pU || lst.S[i] == S.msg_pU + 1)) tl[i] = S.tfin[lst.S[i] - S.msg_pU];
+            }
+            __syncthreads();
+            FUS_TICK(1);
+            double dsum = 0.0, dabs = 0.0, tu = 0.0, tv = 0.0;
+            if (threadIdx.x < 64) {  // (the other waves only keep the barriers company)
+                const SpecialOut o = special_wave(d, lst, blk, sxl, tl, &S.berr, d.chain + (size_t)chain_dst * d.cstride);
+                dsum = o.val;
+                dabs = o.val < 0.0 ? -o.val : o.val;
+                tu = o.tu;
+                tv = o.tv;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    dsum += __shfl_down(dsum, off, 64); dabs += __shfl_down(dabs, off, 64);
+                    tu += __shfl_down(tu, off, 64); tv += __shfl_down(tv, off, 64);
+                }
+                if (threadIdx.x == 0) {  // this workgroup's partial sums: record nbulk (behind the column blocks')
+                    double* r = d.upart + 4 * (size_t)nbulk;
+                    r[0] = dsum; r[1] = dabs; r[2] = tu; r[3] = tv;
+                }
+            } else {
+                const int nb = 2 + lst.nops;
+                for (int q = 0; q < nb; q++) __syncthreads();
+            }
+            FUS_TICK(2);
+            if (threadIdx.x < MAX_S * MAX_S) special_block_store(dl, blk, sxl, tl, (int32_t)threadIdx.x);
+            // the close of the event (nothing in the update reads what it writes)
+            if (threadIdx.x == 64) {
+                lst.tp_n = lst.ev_finish ? 0 : nbulk + 1;  // partial sums of T of the new cluster's nodes: the next decide step adds them up
+                lst.tp_U = lst.U;
+                if (S.berr) lst.error = S.berr;
+                lst.upart_n = nbulk + 1;
+                lst.chain_m = lst.m;
+                lst.chain_U = lst.U;
+                lst.chain_buf = chain_dst;
+                lst.chain_pending = lst.ev_finish ? 0 : 1;
+                close_event(dl);
+                if (lst.ev_finish) {  // special finish: u, v keep the default Sx (NetNode.java:15); nothing to sum
+                    d.Sx[lst.U] = 0.0;
+                    d.Sx[lst.U + 1] = 0.0;
+                }
+            }
+            __syncthreads();
+            FUS_TICK(3);
+        }
+#undef FUS_TICK
+    }
+    state_out(st, lst);
+    return -1;
+    };  // track
+    int block = -1;
+    {
+        const int r = spare ? -2 : track();
+        if (r == -2) {  // wait for the plan of this launch
+            const bool prof2 = ticks != 0 && threadIdx.x == 0 && !spare && wg == 0;
+            long long tk0 = prof2 ? (long long)wall_clock64() : 0;
+            plan_wait(d, S.msg, jobtag);
+            if (prof2) d.ticks[12] += (long long)wall_clock64() - tk0;
+            const PlanMsg& M = S.msg;
+            if (M.kind == 1) block = spare ? (M.last_wg < M.nbulk ? M.last_wg : -1) : wg;
+        } else block = r;
+    }
+    if (block < 0) return;
+    // ---- this workgroup's block of 1024 columns
+    {
+        const bool prof2 = ticks != 0 && threadIdx.x == 0 && !spare && wg == 0;
+        long long tk0 = prof2 ? (long long)wall_clock64() : 0;
+        const PlanMsg& M = S.msg;
+        const PlanView pv = plan_view(M, UniLane{});
+        BulkFix fx;
+        fx.cU = __builtin_amdgcn_readfirstlane(M.cU); fx.chain_wait = __builtin_amdgcn_readfirstlane(M.chain_wait);
+        fx.evtag = (unsigned)__builtin_amdgcn_readfirstlane(M.evtag);
+        fx.pU = __builtin_amdgcn_readfirstlane(M.pU);
+        fx.tfin0 = __builtin_bit_cast(double, ((uint64_t)(uint32_t)M.tfin[1] << 32) | (uint32_t)M.tfin[0]);
+        fx.tfin1 = __builtin_bit_cast(double, ((uint64_t)(uint32_t)M.tfin[3] << 32) | (uint32_t)M.tfin[2]);
+        fx.pov_n = __builtin_amdgcn_readfirstlane(M.pov_n);
+        fx.pov_slot[0] = __builtin_amdgcn_readfirstlane(M.pov_slot[0]); fx.pov_slot[1] = __builtin_amdgcn_readfirstlane(M.pov_slot[1]);
+        fx.pov_pos[0] = __builtin_amdgcn_readfirstlane(M.pov_pos[0]); fx.pov_pos[1] = __builtin_amdgcn_readfirstlane(M.pov_pos[1]);
+        const int chain_dst = __builtin_amdgcn_readfirstlane(M.chain_dst);
+        if (prof2) { const long long now_ = (long long)wall_clock64(); d.ticks[13] += now_ - tk0; tk0 = now_; }
+        double dsum = 0.0, dabs = 0.0, tu = 0.0, tv = 0.0;
+        bulk_column<true>(d, pv, (int32_t)(block * TRK_THREADS + (int)threadIdx.x), d.chain + (size_t)chain_dst * d.cstride, fx, dsum, dabs, tu, tv);
+        if (prof2) { const long long now_ = (long long)wall_clock64(); d.ticks[14] += now_ - tk0; tk0 = now_; }
+        // per-workgroup partial sums (tree order), as k_update's
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            dsum += __shfl_down(dsum, off, 64); dabs += __shfl_down(dabs, off, 64);
+            tu += __shfl_down(tu, off, 64); tv += __shfl_down(tv, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { double* r = shp[threadIdx.x >> 6]; r[0] = dsum; r[1] = dabs; r[2] = tu; r[3] = tv; }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const int k = threadIdx.x;
+            double acc = 0.0;
+            for (int w = 0; w < TRK_THREADS / 64; w++) acc += shp[w][k];
+            d.upart[4 * (size_t)block + k] = acc;
+        }
+        if (prof2) d.ticks[15] += (long long)wall_clock64() - tk0;
+    }
+#undef TRK_TICK
+}
+
+// ------------------------------------------------------------------ k_update
+// subtract + every micro-op + add of one event in ONE launch (fnn_core.h: update_bulk /
+// update_special).  The last workgroup handles the <= 8 involved slots in phases.
+// The involved slots' phases (fnn_core.h: subtract_thread / op_thread / add_thread on the S x S block) by ONE wave:
+// lane i < nS owns involved slot S[i] and column i of the block in LDS.  The generic bodies address the block through
+// slot numbers (a search per access: ~1000 instructions per phase for a lone wave); here every operand of a phase is
+// resolved once - slots that are the same for all lanes by a ballot, a lane's own partner by eight readlanes up front -
+// so a phase is a few dozen instructions.  Same operations, same order, same roundings as the generic bodies (which
+// the CPU emulation runs against the oracle); the GPU parity tests compare Sx, T's consumers and the live matrix
+// after every event.  Returns this lane's addends {row-sum addend, T terms of u, v} of the add phase.
 __global__ __launch_bounds__(256) void k_update(Dev d, int defer, int ticks) {
     __shared__ double shp[4][4];
     __shared__ State lst;  // every workgroup fetches the control block ONCE, with one coalesced load
@@ -2640,7 +2967,7 @@ __global__ __launch_bounds__(256) void k_update(Dev d, int defer, int ticks) {
         __syncthreads();
         UPD_TICK(1);
         if (threadIdx.x < 64) {  // (the other waves only keep the barriers company)
-            const SpecialOut o = special_wave(d, lst, blk, sxl, tl, &berr);
+            const SpecialOut o = special_wave(d, lst, blk, sxl, tl, &berr, d.chain);
             dsum = o.val;
             dabs = o.val < 0.0 ? -o.val : o.val;
             tu = o.tu;
@@ -2660,6 +2987,7 @@ __global__ __launch_bounds__(256) void k_update(Dev d, int defer, int ticks) {
                 lst.upart_n = (int)gridDim.x;
                 lst.chain_m = lst.m;
                 lst.chain_U = lst.U;
+                lst.chain_buf = 0;
                 lst.chain_pending = lst.ev_finish ? 0 : 1;
                 close_event(dl);
                 if (lst.ev_finish) {  // special finish: u, v keep the default Sx (NetNode.java:15); nothing to sum
@@ -2671,86 +2999,11 @@ __global__ __launch_bounds__(256) void k_update(Dev d, int defer, int ticks) {
         __syncthreads();
         state_out(st, lst);
     } else {
-        // ONE thread per column (node) - the two columns of a paired cluster sit in adjacent lanes and exchange the two
-        // or four values the cluster distances need by shuffles.  (fnn_core.h: update_bulk is the same computation with
-        // one thread per cluster; the CPU emulation runs that one against the oracle.  A wave runs alone on its SIMD
-        // here and issues one instruction every ~4 cycles, so the length of a thread's instruction stream IS the
-        // kernel's duration: splitting the pair halves it.)
+        // ONE thread per column (node): bulk_column, shared with the fused event kernel (k_track with fuse)
         const PlanView pv = plan_view(lst, UniLane{});
         UPD_TICK(1);
-        const int32_t k = (int32_t)(blockIdx.x * 256 + threadIdx.x);
-        const bool paired = k < 2 * pv.P_old;
-        bool act = k < pv.m_old;
-#pragma unroll
-        for (int i = 0; i < MAX_S; i++) if (i < pv.nS && pv.S[i] == k) act = false;
-        // everything a column reads, in one batch: its entries in the rows of all involved slots, Sx, T, position
-        double e[MAX_S];
-        const double* colp = d.D + k;
-#pragma unroll
-        for (int i = 0; i < MAX_S; i++) e[i] = (act && i < pv.nS) ? colp[(int64_t)pv.S[i] * d.ld] : 0.0;
-        double sx = act ? d.Sx[k] : 0.0;
-        const double t_old = act ? d.T[k] : 0.0;
-        const int32_t pos = act ? d.spos[k] : 0;
-        const bool odd = (k & 1) != 0;
-        double told = 0.0;
-        if (!pv.ev_finish) {
-            // subtractClusterDistance(p, x); subtractClusterDistance(p, y) (:455-461, 681-696)
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int32_t it = q == 0 ? pv.ix : pv.iy, itn = q == 0 ? pv.ixn : pv.iyn;
-                const double me0 = it >= 0 ? e[it] : 0.0, mf0 = itn >= 0 ? e[itn] : 0.0;   // this column's entries towards t, t.nbr
-                const double oe = __shfl_xor(me0, 1, 64), of = __shfl_xor(mf0, 1, 64);     // ... and the partner column's
-                const double e0 = odd ? oe : me0, f0 = odd ? of : mf0, e1 = odd ? me0 : oe, f1 = odd ? mf0 : of;
-                double v;
-                if (!paired && itn < 0) { v = me0; told += me0; }
-                else if (paired && itn < 0) { v = (e0 + e1) / 2.0; told += me0; }
-                else if (!paired && itn >= 0) { v = (me0 + mf0) / 2.0; told += 0.5 * (me0 + mf0); }
-                else { v = (((e0 + f0) + e1) + f1) / 4.0; told += 0.5 * (me0 + mf0); }
-                sx -= v;
-            }
-        }
-        // the rows that change, at this column (all values first: a changed row may be the source of another)
-        double nv[MAX_TGT];
-        double um = 0.0, vm = 0.0;
-#pragma unroll
-        for (int t = 0; t < MAX_TGT; t++) {
-            nv[t] = 0.0;
-            if (t < pv.ntgt) {
-                nv[t] = tgt_eval(pv, t, [&](int32_t i) { return e[i]; });
-                if (t == pv.tU) um = nv[t];
-                if (t == pv.tV) vm = nv[t];
-            }
-        }
-        if (act) {
-            const int64_t rk = (int64_t)k * d.ld;
-#pragma unroll
-            for (int t = 0; t < MAX_TGT; t++) {
-                if (t < pv.ntgt) {
-                    // the entry and its mirror; of the two only the one at or below the diagonal has a bf16 copy
-                    const int32_t dst = pv.tdst[t];
-                    const int64_t rb = (int64_t)dst * d.ld;
-                    d.D[rb + k] = nv[t];
-                    d.D[rk + dst] = nv[t];
-                    if (d.H) d.H[k < dst ? (int64_t)dst * d.ldh + k : (int64_t)k * d.ldh + dst] = bf16_from_double(nv[t]);
-                }
-            }
-        }
-        if (!pv.ev_finish) {
-            // updateClusterDistances, per-node part (:520-531)
-            const double uo = __shfl_xor(um, 1, 64), vo = __shfl_xor(vm, 1, 64);
-            const double u0 = odd ? uo : um, v0 = odd ? vo : vm, u1 = odd ? um : uo, v1 = odd ? vm : vo;
-            const double dpu = paired ? (((u0 + v0) + u1) + v1) / 4.0 : (um + vm) / 2.0;
-            if (act) {
-                const bool rep = !paired || !odd;
-                d.Sx[k] = sx + dpu;
-                d.chain[chain_addr(pos)] = rep ? dpu : 0.0;
-                d.T[k] = (t_old - told) + 0.5 * (um + vm);
-                dsum = rep ? dpu : 0.0;
-                dabs = dsum < 0.0 ? -dsum : dsum;
-                tu = paired ? 0.5 * um : um;
-                tv = paired ? 0.5 * vm : vm;
-            }
-        }
+        const BulkFix nofix{};
+        bulk_column<false>(d, pv, (int32_t)(blockIdx.x * 256 + threadIdx.x), d.chain, nofix, dsum, dabs, tu, tv);
         UPD_TICK(2);
     }
     // per-workgroup partial sums (tree order): of the new cluster's row-sum addends and their magnitudes (for
@@ -2957,6 +3210,8 @@ struct HipBackend {
     bool skip_unsched_scans = true; // FNN_UNSCHED_SCANS=1: keep the (mostly idle) scan kernels in unscheduled events
     int track_group = TRK_GROUP;  // k_track: workgroups per first-level arrival counter (FNN_TRACK_GROUP)
     bool defer_chain = false; // set by the engine: k_update closes the event, the exact u.Sx sum runs inside the next k_track
+    bool fuse_events = true;  // window events as ONE launch (k_track with fuse; FNN_FUSE=0: k_track + k_update as before)
+    bool fused_last = false;  // the launch sequence being enqueued is such a fused one
     bool scan_nt = true;    // non-temporal matrix loads in the scan (FNN_SCAN_NT)
     bool ticks = false;     // FNN_TICKS=1: k_track records the phase split of its last workgroup (fnn_debug_event_ticks)
 
@@ -3016,6 +3271,7 @@ struct HipBackend {
         if (const char* e = std::getenv("FNN_EMIT_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 65535) emit_grid = v; }
         if (const char* e = std::getenv("FNN_RX_HELPERS")) rx_helpers_cfg = std::atoi(e) != 0 ? TRK_NHELP : 0;
         if (const char* e = std::getenv("FNN_TRACK_GROUP")) { int v = std::atoi(e); if (v >= 2 && v <= 1024) track_group = v; }
+        if (const char* e = std::getenv("FNN_FUSE")) fuse_events = std::atoi(e) != 0;
         if (const char* e = std::getenv("FNN_TRACK_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 1024) track_grid = v; }
         // the first-level arrival counters sit at d.ticket + 32 (g + 1), g < ceil(grid / group); word 32 * 65 is TRK_FLAG, 32 * 67
         // TRK_BAD and the array holds 32 * 72 words: at most 64 groups (the two switches are development aids, but an
@@ -3203,14 +3459,18 @@ struct HipBackend {
         //  device stalls - this and the following such events do nothing - until the host, which
         //  looks at the state every batch, launches an event with a scan)
         const bool has_scan = sched || !screen || !skip_unsched_scans;
+        // a WINDOW event in one launch (k_track with fuse: tracking, decide step and the update; no k_update follows): only launch
+        // sequences without scan kernels, with the row sum deferred, and while every block of 1024 columns finds a tracking workgroup
+        fused_last = fuse_events && d.la && screen && !has_scan && defer_chain && (m_bound + TRK_THREADS - 1) / TRK_THREADS <= track_grid;
+        const int fz = fused_last ? 1 : 0;
         if (d.la) timed(TC_TRACK, tall, [&]() {
-            track_tag = (track_tag % 0x7FFFFFEu) + 1u;  // (never 0: the JOB word starts out as 0)
+            track_tag = (track_tag % 0x7FFFFFEu) + 1u;  // (never 0: the JOB word and the plan message start out as 0)
             if (rx_helpers > 0)
-                hipLaunchKernelGGL(k_track<true>, dim3(track_grid + 1 + TRK_NHELP), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0,
-                                   has_scan ? 1 : 0, track_group, ticks ? 1 : 0, track_tag);
+                hipLaunchKernelGGL(k_track<true>, dim3(track_grid + 1 + TRK_NHELP + fz), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0,
+                                   has_scan ? 1 : 0, track_group, ticks ? 1 : 0, track_tag, fz);
             else
-                hipLaunchKernelGGL(k_track<false>, dim3(track_grid + 1), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0,
-                                   has_scan ? 1 : 0, track_group, ticks ? 1 : 0, track_tag);
+                hipLaunchKernelGGL(k_track<false>, dim3(track_grid + 1 + fz), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0,
+                                   has_scan ? 1 : 0, track_group, ticks ? 1 : 0, track_tag, fz);
         });
         int nrecs;
         if (screen && !has_scan) nrecs = 0;  // (a window event: the tail of k_track decides; no decide kernel follows)
@@ -3262,6 +3522,7 @@ struct HipBackend {
             if (rx_helpers > 0) hipLaunchKernelGGL(k_decide<true>, dim3(1 + TRK_NHELP), dim3(CH_T), 0, stream, d, src, nrecs, track_tag);
             else hipLaunchKernelGGL(k_decide<false>, dim3(1), dim3(CH_T), 0, stream, d, src, nrecs, track_tag);
         });
+        if (nrecs == 0 && fused_last) return;  // (the window event's k_track has done the update itself)
         timed(TC_UPDATE, tall, [&]() { hipLaunchKernelGGL(k_update, dim3(g1.x + 1), dim3(256), 0, stream, d, defer_chain ? 1 : 0, ticks ? 1 : 0); });
         if (!defer_chain) timed(TC_OTHER, tall, [&]() { hipLaunchKernelGGL(k_finalize, dim3(1), dim3(CH_T), 0, stream, d); });
     }
@@ -3418,6 +3679,10 @@ int32_t fnn_get_counts(fnn_handle* h, int32_t* num_active, int32_t* num_clusters
 int32_t fnn_get_nodes(fnn_handle* h, int32_t* id, int32_t* nbr_id, double* Sx) {
     FNN_NEED(h);
     FNN_TRY(return h->eng.get_nodes(id, nbr_id, Sx);)
+}
+int32_t fnn_get_matrix(fnn_handle* h, double* out, int64_t ld_out) {
+    FNN_NEED(h);
+    FNN_TRY(return h->eng.get_matrix(out, ld_out);)
 }
 int32_t fnn_get_live_matrix(fnn_handle* h, double* out) {
     FNN_NEED(h);

@@ -824,6 +824,7 @@ struct Solver {
     } bk;
     bool blas_ok = true;
     double gemm_flops = 0.0;
+    int64_t cap_want = 0;        // > 0: the factor's capacity for this attempt (a retry after FNN_SW_GIVEUP_CAPACITY), else the default for n
     int giveup = 0;              // FNN_SW_GIVEUP_* of the block method
     const char* giveup_text = "";
     double final_tol_rel = 0.0, t_alloc_s = 0.0;
@@ -949,12 +950,15 @@ struct Solver {
         const int rad = (int)envd("FNN_SW_NMS", 3);
         const int64_t N = (int64_t)n * (n - 1) / 2;
         Blk& b = bk;
+        b = Blk{};  // (a retry with a larger capacity starts from nothing)
+        giveup = 0; giveup_text = ""; blas_ok = true; ok = true;
         block_mark = allocs.size();
         // Capacity of the factor (splits that are in + the departed ones still inside + the entering block): random distances end
         // with ~2.4 n positive splits, tree-like ones with more (tree + 5 % noise: 3.8 n) - as many as device memory allows, up
         // to 6 n: the factor takes cap^2 doubles, the block buffers, the departed columns and their Gram matrices 0.61 cap^2 more.
         auto sized = [&](double factor, int kdiv, int rdiv) {
             b.cap = up64(std::min<int64_t>(N, std::max<int64_t>({(int64_t)(factor * n) + 1024, std::min<int64_t>(8 * (int64_t)n + 64, 20000), 512})));
+            if (cap_want > 0) b.cap = up64(std::min<int64_t>(N, cap_want));
             b.kmax = std::min<int64_t>({b.cap, std::max<int64_t>(64, up64(b.cap / kdiv)), (int64_t)8192});  // (a block costs 4 k^2 f beside its 4 k f^2: keep k / f small)
             b.rcap = std::min<int64_t>(b.cap, up64(b.cap / rdiv) + 64);
             b.pw = std::max<int64_t>(1024, up64(b.cap / 8));
@@ -971,10 +975,21 @@ struct Solver {
         struct Shape { double f; int kdiv, rdiv; };
         const Shape shapes[] = {{6.0, 12, 5}, {5.0, 12, 5}, {4.5, 12, 5}, {4.0, 12, 5}, {4.0, 16, 8}, {3.5, 12, 5}, {3.25, 12, 5}};
         Shape pick = shapes[6];
+        if (cap_want > 0) {
+            // a retry with a larger factor: the wanted capacity with the roomiest side buffers that fit, else as much as fits
+            const Shape tries[] = {{0.0, 12, 5}, {0.0, 16, 8}, {0.0, 24, 12}};
+            bool fits = false;
+            for (int round = 0; round < 40 && !fits; round++) {
+                for (const Shape& sh : tries) { pick = sh; if (sized(0.0, sh.kdiv, sh.rdiv) <= budget) { fits = true; break; } }
+                if (!fits) cap_want = (int64_t)(0.9 * (double)cap_want);
+            }
+            if (!fits) { giveup = FNN_SW_GIVEUP_SETUP; giveup_text = "no factor fits the device memory"; return false; }
+        } else {
         for (const Shape& sh : shapes) {
             pick = sh;
             if (want > 0.0) { pick.f = want; break; }
             if (sized(sh.f, sh.kdiv, sh.rdiv) <= budget) break;
+        }
         }
         (void)sized(pick.f, pick.kdiv, pick.rdiv);
         rfrac = std::min(rfrac, 0.75 * (double)b.rcap / (double)b.cap);  // (the departed columns' buffers bound how many may stay in the factor)
@@ -1550,13 +1565,35 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
     hipLaunchKernelGGL(k_unconstrained, dim3((unsigned)((n + T - 1) / T), (unsigned)n), dim3(T), 0, S.s, S.d, S.x, n, S.ld);
     if (S.reduce_sum<RD_COUNT_NEG>(S.x, nullptr) != 0.0) {
         const bool want_reference = std::getenv("FNN_SW_REFERENCE_METHOD") != nullptr;
-        const bool from_below = !want_reference && S.block_active_set();
+        // The block method's factor is sized for the common case (random or tree-like distances: 2.4 n ... 3.8 n positive splits) so
+        // that small problems do not pay for a 100-GB allocation; distances whose optimum has more positive splits (nearly
+        // circular metrics: measured 19.5 n at 1024 taxa with 1 % noise) outgrow it: try again with four times the capacity, up to
+        // what device memory holds (~150 000 splits, whatever n) or all n (n - 1) / 2 splits.
+        bool from_below = false;
+        if (!want_reference) {
+            const int64_t Nall = (int64_t)n * (n - 1) / 2;
+            for (int attempt = 0; attempt < 6; attempt++) {
+                from_below = S.block_active_set();
+                if (from_below || S.giveup != FNN_SW_GIVEUP_CAPACITY || S.capacity >= Nall || std::getenv("FNN_SW_CAP")) break;
+                const int64_t prev = S.capacity;
+                S.release_block_buffers();
+                S.cap_want = std::min<int64_t>(Nall, 4 * prev);
+                size_t fb = 0, tb = 0;
+                if (hipMemGetInfo(&fb, &tb) != hipSuccess) break;
+                // (the largest factor that can fit at all: cap^2 * 8 B * 9/16 for the factor alone)
+                const int64_t hard = (int64_t)std::sqrt(0.9 * (double)fb / (8.0 * 0.62 * 1.7));
+                if (S.cap_want > hard) S.cap_want = hard;
+                if (S.cap_want < prev + prev / 4) { S.cap_want = 0; break; }  // no meaningful growth left: the give-up stands
+                std::fprintf(stderr, "fnn_split_weights_f64: the free set outgrew the factor's capacity of %lld splits at n = %d; once more with %lld\n",
+                             (long long)prev, n, (long long)S.cap_want);
+            }
+        }
         route = from_below ? FNN_SW_ROUTE_FROM_BELOW : FNN_SW_ROUTE_REFERENCE;
         if (!from_below) {
             if (!want_reference) {
                 // The block method gave up.  Say so, always: the route that follows is the reference's own - correct, but
                 // O(n^2) work per conjugate-gradient iteration and thousands of iterations on large problems.
-                int64_t max_n = 4096;
+                int64_t max_n = 1024;  // (measured: a 1024-taxon nearly circular input takes 80 s on that route, 2048 taxa more than 5 min)
                 if (const char* e = std::getenv("FNN_SW_REFERENCE_MAX_N")) max_n = std::atoll(e);
                 const bool allow = std::getenv("FNN_SW_ALLOW_REFERENCE_ROUTE") != nullptr || n <= max_n;
                 std::fprintf(stderr, "fnn_split_weights_f64: the block active-set method gave up at n = %d (%s; capacity %lld splits, free set peaked at %lld): %s\n",

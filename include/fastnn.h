@@ -159,6 +159,11 @@ int32_t fnn_set_matrix_device(fnn_handle* h, const double* d_matrix, int64_t ld_
  * (SplitMix64; dist 0 = uniform53, 1 = dec4), bit-identical to the host generator. */
 int32_t fnn_synth(fnn_handle* h, uint64_t seed, int32_t dist);
 
+/* The matrix as it is resident on the device (after an upload or fnn_synth, before the run consumes it), to host memory with
+ * row stride ld_out doubles: what a caller needs who generated the distances on the device and wants them for the split
+ * weights or the Nexus document afterwards (the reference re-parses its file for that, FastNN.java:438). */
+int32_t fnn_get_matrix(fnn_handle* h, double* out, int64_t ld_out);
+
 /* runNeighborNet (NetMakerOriginal.java:129-162): order_out has n+1 entries,
  * order_out[0] = 0, order_out[1] = 1, 1-based taxon ids in circular order; n <= 3
  * gives the identity (:133-140).  Consumes the device matrix (a new upload or
@@ -298,7 +303,8 @@ enum { FNN_SW_GIVEUP_NONE = 0, FNN_SW_GIVEUP_CAPACITY = 1,   /* the free set out
 /* Returns FNN_OK with the certified optimum; FNN_EINEXACT with weights that failed the check (from below only: the
  * reference route stops by its own rule, CG_EPSILON = 1e-8, ~1e-5 short of the optimum, and reports certified = 0 with
  * FNN_OK); FNN_ECAPACITY when the block method's factor cannot hold the free set and n is above the size up to which the
- * reference route is taken automatically (FNN_SW_REFERENCE_MAX_N, default 4096: measured in DESIGN.md section 7). */
+ * reference route is taken automatically (FNN_SW_REFERENCE_MAX_N, default 1024: measured in DESIGN.md section 7).  Before
+ * that the block method retries with a factor of four times the capacity, up to what device memory holds (~150 000 splits). */
 int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ld, const int32_t* ordering, int32_t device,
                               double* weights_out, fnn_sw_stats* stats);
 

@@ -730,6 +730,7 @@ int32_t emu_get_counts(void* h, int32_t* m, int32_t* c, int32_t* nn) {
 }
 int32_t emu_get_nodes(void* h, int32_t* id, int32_t* nbr, double* sx) { return ((EmuEngine*)h)->get_nodes(id, nbr, sx); }
 int32_t emu_get_live_matrix(void* h, double* out) { return ((EmuEngine*)h)->get_live_matrix(out); }
+int32_t emu_get_matrix(void* h, double* out, int64_t ld_out) { return ((EmuEngine*)h)->get_matrix(out, ld_out); }
 int32_t emu_comm_init_host(void* h, int32_t world, int32_t rank, fnn_allgather_fn fn, void* ctx) {
     auto* e = (EmuEngine*)h;
     int32_t rc = e->comm_set(2, world, rank);

@@ -42,6 +42,29 @@ def _tree(n, seed, dyadic):
     return np.ascontiguousarray(D[np.ix_(p, p)])
 
 
+def circ_noise(n, seed, noise=0.01, density=1.0):
+    """A circular metric (random hidden cycle; a fraction `density` of the circular splits carries a random positive weight)
+    with multiplicative noise: every distance times 1 + noise * U(-1, 1).  Built with the split-weight oracle's prefix-sum
+    operator (test infrastructure).  The optimum of such distances has O(n^2) positive splits - the case that the dense
+    factor of the block active-set method cannot hold ("capacity")."""
+    from oracle import csw_oracle as W
+    r = np.random.default_rng(seed)
+    npairs = n * (n - 1) // 2
+    x = r.random(npairs) + 0.01
+    if density < 1.0:
+        x *= r.random(npairs) < density
+    dpos = W.calculate_ab(n, x)                   # distances between cycle POSITIONS (packed strict upper triangle)
+    P = np.zeros((n, n))
+    P[np.triu_indices(n, 1)] = dpos
+    N = np.triu(1.0 + noise * (2.0 * r.random((n, n)) - 1.0), 1)
+    P *= N
+    P = P + P.T
+    tax = r.permutation(n)                        # position -> taxon
+    D = np.empty((n, n))
+    D[np.ix_(tax, tax)] = P
+    return np.ascontiguousarray(D)
+
+
 def make(n, dist, seed, oracle):
     """The n x n matrix of an input class (host side; `oracle` = the oracle module, for the SplitMix64 generators)."""
     if dist in DEVICE_DISTS:
@@ -52,6 +75,8 @@ def make(n, dist, seed, oracle):
         T = _tree(n, seed, False)
         N = np.triu(np.random.default_rng(seed + 1000).random((n, n)) * 0.05, 1)
         return np.ascontiguousarray(T + N + N.T)
+    if dist == "circnoise":
+        return circ_noise(n, seed)
     if dist == "neg":
         D = oracle.synth(n, seed, "uniform53")
         D -= 0.25

@@ -184,3 +184,19 @@ def test_lookahead_windows_keep_the_exact_result(emu_api, oracle, monkeypatch):
         h.set_matrix(neg)
         _, st = h.run()
     assert st.n_window_hits == 0
+
+
+def test_get_matrix_returns_the_resident_matrix_until_the_run_consumes_it(emu_api, oracle):
+    """fnn_get_matrix (include/fastnn.h): bit-exact copy of what was uploaded; FNN_ESTATE without a resident matrix."""
+    from fastneighbornet_amd._capi import FnnError
+    n = 37
+    D = oracle.synth(n, 2)
+    with Handle(emu_api, n) as h:
+        with pytest.raises(FnnError):
+            h.matrix()
+        h.set_matrix(D)
+        assert (h.matrix().view(np.int64) == D.view(np.int64)).all()
+        h.run()
+        with pytest.raises(FnnError) as ei:
+            h.matrix()
+        assert ei.value.code == -5

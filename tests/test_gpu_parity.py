@@ -60,6 +60,7 @@ def test_device_synth_is_bit_identical(hip_api, oracle):
         o_ref, _, _ = oracle.run(D, threads=8)
         with Handle(hip_api, n) as h:
             h.synth(seed, dist)
+            assert (bits(h.matrix()) == bits(D)).all()   # fnn_get_matrix: the resident matrix, before the run consumes it
             h.begin()
             assert (bits(h.live_matrix()) == bits(D)).all()
             while h.step() is not None:

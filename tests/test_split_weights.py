@@ -176,10 +176,12 @@ def test_gpu_split_weights_kkt_at_baseline_sizes(hip_api, oracle, n, seed, dist,
     D = inputs.make(n, dist, seed, oracle)
     order = fa.canonical_order(D)
     got, st = fa.split_weights(D, order)
-    assert st["method"] == "from below"
+    assert st["method"] == "from below" and st["certified"] == 1 and st["giveup_reason"] == 0
     assert st["t_solve_s"] <= budget_s, st
     v = kkt_violation(D, order, got)
     assert v < 1e-9, (n, v, st)
+    # the solver's own check (device operators) and the independent one (host, the oracle's operators) see the same violation
+    assert st["kkt_violation"] < 1e-9 and abs(st["kkt_violation"] - v) <= 1e-10 + 0.5 * max(v, st["kkt_violation"]), (v, st)
     assert (got >= 0).all() and st["nsplits"] == int((got > 1e-6).sum())
 
 
@@ -191,3 +193,57 @@ def test_gpu_split_weights_argument_errors(hip_api, oracle):
     bad = np.array([0, 1, 2, 3, 4, 5, 6, 7, 7], dtype=np.int32)   # not a permutation
     with pytest.raises(FnnError):
         fa.split_weights(D, bad)
+
+
+@pytest.mark.gpu
+def test_config5_end_to_end_32768(hip_api, oracle, hostlib_nexus):
+    """BASELINE.json configs[4]: 32768 taxa end to end on one MI355X - circular order, circular split weights, Nexus document
+    (FastNN.java:369-491).  The order must be the oracle's golden; the weights are solved from below (block active-set
+    method), pass the solver's own certificate AND the solver-independent Kuhn-Tucker check with the oracle's operators on
+    the host (violation < 1e-9 of max|A^T d|); the document is written by the routine the CLI runs (printNexusFromWeights)
+    with nsplits = the number of weights above the reference's 1e-6 threshold (FastNN.java:455).  Time budgets: weights
+    <= 100 s of device time, document <= 30 s."""
+    import ctypes as C
+    import hashlib
+    import json
+    import os
+    import time
+    import fastneighbornet_amd as fa
+    from fastneighbornet_amd._capi import Handle
+    n, seed = 32768, 1
+    gold = {(c["n"], c["dist"], c["seed"]): c for c in
+            json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_big.json")))["cases"]}[(n, "uniform53", seed)]
+    with Handle(hip_api, n) as h:
+        h.synth(seed, "uniform53")
+        order, st = h.run()
+    assert hashlib.sha256(order.tobytes()).hexdigest() == gold["order_sha256"]
+    D = oracle.synth(n, seed)                      # the same matrix, generated on the host by the oracle's generator
+    t0 = time.time()
+    w, sw = fa.split_weights(D, order)
+    t_w = time.time() - t0
+    assert sw["method"] == "from below" and sw["certified"] == 1 and sw["kkt_violation"] < 1e-9, sw
+    assert sw["t_solve_s"] <= 100.0, sw
+    ns_expected = int((w > 1e-6).sum())
+    assert (w >= 0).all() and sw["nsplits"] == ns_expected and 2.0 * n < ns_expected < 3.0 * n, (ns_expected, sw)
+    names = b"".join((f"t{i + 1}".encode()).ljust(256, b"\0") for i in range(n))
+    t0 = time.time()
+    ns = hostlib_nexus.fnnh_write_nexus(b"/dev/null", n, D.ctypes.data_as(C.POINTER(C.c_double)), names,
+                                        order.ctypes.data_as(C.POINTER(C.c_int32)), w.ctypes.data_as(C.POINTER(C.c_double)))
+    t_doc = time.time() - t0
+    assert ns == ns_expected and t_doc <= 30.0, (ns, ns_expected, t_doc)
+    v = kkt_violation(D, order, w)
+    print(f"config 5: order {st.t_total_s:.2f} s, weights {sw['t_solve_s']:.1f} s device / {t_w:.1f} s wall, document {t_doc:.1f} s, "
+          f"{ns} splits, Kuhn-Tucker violation {v:.2e} (solver's own: {sw['kkt_violation']:.2e})")
+    assert v < 1e-9, (v, sw)
+
+
+@pytest.fixture(scope="module")
+def hostlib_nexus():
+    import ctypes as C
+    import os
+    from fastneighbornet_amd import build
+    build.build()
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(build.__file__)), "libfastnn_host.so"))
+    lib.fnnh_write_nexus.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    lib.fnnh_write_nexus.restype = C.c_int32
+    return lib
