@@ -1472,6 +1472,7 @@ struct DecideLds {
     // workgroup's copy of the involved slots' block
     PlanMsg msg;
     int32_t msg_pU, berr;
+    int32_t fz[6];             // {chain_pending, chain_buf, chain_U, event tag, column blocks} at the start of the launch, the workgroup's index
     double blk[MAX_S * MAX_S], sxl[MAX_S], tl[MAX_S];
 };
 
@@ -1619,8 +1620,10 @@ __device__ __forceinline__ void decide_step(const Dev& d, DecideLds& S, ChainLds
             for (int off = 32; off >= 1; off >>= 1) { tu += __shfl_down(tu, off, 64); tv += __shfl_down(tv, off, 64); }
             if (lane == 0) {
                 S.tfin[0] = tu; S.tfin[1] = tv;
-                d.T[lst.tp_U] = tu;
-                d.T[lst.tp_U + 1] = tv;
+                // write-through: in the fused event kernel a column thread of the same launch (another compute unit, maybe another L2
+                // slice) stores to the same address later; two dirty copies would be written back in an undefined order
+                __hip_atomic_store(reinterpret_cast<uint64_t*>(d.T + lst.tp_U), __builtin_bit_cast(uint64_t, tu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(reinterpret_cast<uint64_t*>(d.T + lst.tp_U + 1), __builtin_bit_cast(uint64_t, tv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -2205,6 +2208,19 @@ __device__ __forceinline__ void sweep_exact_item(const Dev& d, int64_t r, const 
 constexpr int TRK_REC_U = 1024;  // offset of the swept-pair records in d.recs
 
 struct SpecialOut { double val, tu, tv; };
+// WGB: the phases are separated by workgroup barriers (k_update: the other waves of the workgroup keep them company); without
+// it the calling wave is alone with the block - its LDS accesses execute in program order, a fence keeps the compiler from
+// moving them - and no other wave of the workgroup has to take part (the fused event kernel)
+template <bool WGB>
+__device__ __forceinline__ void special_sync() {
+    if (WGB) __syncthreads();
+    else {  // (LDS instructions of one wave execute in order: only the compiler has to be kept from moving them - no s_waitcnt on the
+            //  global stores and loads that are in flight, which a workgroup-scope fence would insert)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+template <bool WGB>
 __device__ __forceinline__ SpecialOut special_wave(const Dev& d, const State& lst, double* blk, double* sxl, double* tl, int32_t* berr, double* chain_dst) {
     const int lane = threadIdx.x & 63;
     const int nS = __builtin_amdgcn_readfirstlane(lst.nS);
@@ -2267,7 +2283,7 @@ __device__ __forceinline__ SpecialOut special_wave(const Dev& d, const State& ls
             }
         }
     }
-    __syncthreads();
+    special_sync<WGB>();
     // ---- the micro-ops, one phase each (fnn_core.h: op_thread)
     for (int ph = 0; ph < nops; ph++) {
         const int kind = __builtin_amdgcn_readfirstlane(lst.ops[ph].kind), mcur = __builtin_amdgcn_readfirstlane(lst.ops[ph].mcur);
@@ -2317,7 +2333,7 @@ __device__ __forceinline__ SpecialOut special_wave(const Dev& d, const State& ls
                 }
             }
         }
-        __syncthreads();
+        special_sync<WGB>();
     }
     // ---- add (new layout), NetMakerOriginal.java:520-533
     if (!ev_finish) {
@@ -2353,7 +2369,7 @@ __device__ __forceinline__ SpecialOut special_wave(const Dev& d, const State& ls
             out.val = val;
         }
     }
-    __syncthreads();
+    special_sync<WGB>();
     return out;
 }
 
@@ -2437,7 +2453,10 @@ __device__ __forceinline__ void bulk_column(const Dev& d, const PlanView& pv, co
 #pragma unroll
         for (int t = 0; t < MAX_TGT; t++) {
             if (t < pv.ntgt) {
-                // the entry and its mirror; of the two only the one at or below the diagonal has a bf16 copy
+                // the entry and its mirror; of the two only the one at or below the diagonal has a bf16 copy.  (Tried, round 4: the two
+                // mirror entries of the new cluster's adjacent rows U, U + 1 as ONE 16-byte store and their bf16 copies as one 4-byte
+                // store - half the scattered stores, but the extra selects lengthen every thread's instruction stream: 1.54 s instead
+                // of 1.41 s at 32768 taxa.)
                 const int32_t dst = pv.tdst[t];
                 const int64_t rb = (int64_t)dst * d.ld;
                 d.D[rb + k] = nv[t];
@@ -2495,7 +2514,7 @@ __device__ __forceinline__ void plan_wait(const Dev& d, PlanMsg& m, unsigned tag
                 if (lane == 0) atomicOr(d.ticket + TRK_ERR, 2u);
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(6);
         }
     }
     __syncthreads();
@@ -2511,32 +2530,91 @@ __device__ __forceinline__ void plan_wait(const Dev& d, PlanMsg& m, unsigned tag
 // thread - T of the previous event's cluster (decide step), its exact row sum (chain workgroup), reference positions the plan
 // moved - travels in the message or is read write-through (BulkFix); the row-sum addends alternate between two chain buffers
 // (State.chain_buf) because the chain workgroup of this launch is still reading the other one.
-template <bool HELP>
-__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed, int has_scan, int tgroup, int ticks, unsigned jobtag, int fuse) {
+// ---- a COLUMN workgroup of the fused event kernel: block `block` of BULK_COLS columns by its first BULK_COLS threads (one wave per
+// SIMD, as in k_update: the column thread is a chain of latencies and scattered stores - a 1024-column block on one compute unit
+// took 7 us, 256 columns take 4); the other waves only keep the barriers company.
+constexpr int BULK_COLS = 256;
+__device__ __forceinline__ void column_workgroup(const Dev& d, PlanMsg& M, int block, double (*shp)[4], unsigned tag, int prof2) {
+    long long tk0 = prof2 ? (long long)wall_clock64() : 0;
+    // the plan cannot be there before the tracking, the fan-in and the decide step of this launch have run (>= 12 us): sleep through
+    // most of that instead of polling (the polls of all column workgroups go to the same few cache lines)
+    if (threadIdx.x < 64) {
+        const long long t0 = (long long)wall_clock64();
+        while ((long long)wall_clock64() - t0 < 1400) __builtin_amdgcn_s_sleep(32);  // 14 us of the 100 MHz clock
+    }
+    plan_wait(d, M, tag);
+    if (prof2) { const long long now_ = (long long)wall_clock64(); d.ticks[12] += now_ - tk0; tk0 = now_; }
+    if (M.kind != 1 || block >= M.nbulk) return;
+    double dsum = 0.0, dabs = 0.0, tu = 0.0, tv = 0.0;
+    if (threadIdx.x < BULK_COLS) {
+        const PlanView pv = plan_view(M, UniLane{});
+        BulkFix fx;
+        fx.cU = __builtin_amdgcn_readfirstlane(M.cU); fx.chain_wait = __builtin_amdgcn_readfirstlane(M.chain_wait);
+        fx.evtag = (unsigned)__builtin_amdgcn_readfirstlane(M.evtag);
+        fx.pU = __builtin_amdgcn_readfirstlane(M.pU);
+        fx.tfin0 = __builtin_bit_cast(double, ((uint64_t)(uint32_t)M.tfin[1] << 32) | (uint32_t)M.tfin[0]);
+        fx.tfin1 = __builtin_bit_cast(double, ((uint64_t)(uint32_t)M.tfin[3] << 32) | (uint32_t)M.tfin[2]);
+        fx.pov_n = __builtin_amdgcn_readfirstlane(M.pov_n);
+        fx.pov_slot[0] = __builtin_amdgcn_readfirstlane(M.pov_slot[0]); fx.pov_slot[1] = __builtin_amdgcn_readfirstlane(M.pov_slot[1]);
+        fx.pov_pos[0] = __builtin_amdgcn_readfirstlane(M.pov_pos[0]); fx.pov_pos[1] = __builtin_amdgcn_readfirstlane(M.pov_pos[1]);
+        const int chain_dst = __builtin_amdgcn_readfirstlane(M.chain_dst);
+        if (prof2) { const long long now_ = (long long)wall_clock64(); d.ticks[13] += now_ - tk0; tk0 = now_; }
+        bulk_column<true>(d, pv, (int32_t)(block * BULK_COLS + (int)threadIdx.x), d.chain + (size_t)chain_dst * d.cstride, fx, dsum, dabs, tu, tv);
+        if (prof2) { const long long now_ = (long long)wall_clock64(); d.ticks[14] += now_ - tk0; tk0 = now_; }
+        // per-workgroup partial sums (tree order), as k_update's
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            dsum += __shfl_down(dsum, off, 64); dabs += __shfl_down(dabs, off, 64);
+            tu += __shfl_down(tu, off, 64); tv += __shfl_down(tv, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { double* r = shp[threadIdx.x >> 6]; r[0] = dsum; r[1] = dabs; r[2] = tu; r[3] = tv; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        d.upart[4 * (size_t)block + k] = ((shp[0][k] + shp[1][k]) + shp[2][k]) + shp[3][k];
+    }
+    if (prof2) d.ticks[15] += (long long)wall_clock64() - tk0;
+}
+
+// FUSE: a WINDOW event in ONE launch.  The launch sequence has no scan kernels (has_scan == 0) and no k_update: the grid carries
+// `ncol` COLUMN workgroups behind the tracking (and helper) workgroups.  When the window serves the event, the deciding workgroup
+// (the tracking workgroup that arrives last) posts the plan as a message (plan_post), runs the involved slots' phases itself - wave 0
+// alone, no workgroup barrier - and closes the event; column workgroup b has waited for the message and updates the columns
+// [256 b, 256 b + 256) (bulk_column<true>).  Saves a kernel boundary per event (~4.5 us: dispatch, the release at the end of one
+// kernel and the acquire at the start of the next) at the price of one message round trip (~1 us), and the chain workgroup's exact
+// row sum (14-23 us) runs beside tracking AND update.  What the launch itself produces for a column thread - T of the previous
+// event's cluster (decide step), its exact row sum (chain workgroup), reference positions the plan moved - travels in the message
+// or is read write-through (BulkFix); the row-sum addends alternate between two chain buffers (State.chain_buf) because the chain
+// workgroup of this launch is still reading the other one.  No address is written twice in one launch by different workgroups
+// with plain stores (their L2 slices would write back in an undefined order): T of the previous cluster goes out write-through.
+template <bool HELP, bool FUSE>
+__global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, int timed, int has_scan, int tgroup, int ticks, unsigned jobtag, int ncol) {
     __shared__ ChainLds<CH_EPT> L;
     __shared__ DecideLds S;
     __shared__ Cand sh[TRK_THREADS / 64], shu[TRK_THREADS / 64];
     __shared__ int lastflag;
     __shared__ double shs[2];
     __shared__ unsigned hword;
-    __shared__ double shp[TRK_THREADS / 64][4];
+    __shared__ double shp[BULK_COLS / 64][4];
     State* st = d.st;
     if (blockIdx.x == 0) {  // the chain workgroup
         chain_workgroup(d, L);
         return;
     }
-    const bool spare = fuse != 0 && blockIdx.x == gridDim.x - 1;
-    const int wg = (int)blockIdx.x - 1, G = (int)gridDim.x - 1 - (HELP ? TRK_NHELP : 0) - (fuse ? 1 : 0);
-    if (HELP && !spare && wg >= G) {  // a helper workgroup of the exact ComputeRx sums (see decide_step)
+    const int wg = (int)blockIdx.x - 1, G = (int)gridDim.x - 1 - (HELP ? TRK_NHELP : 0) - (FUSE ? ncol : 0);
+    if (FUSE && wg >= G + (HELP ? TRK_NHELP : 0)) {  // a column workgroup
+        const int block = wg - G - (HELP ? TRK_NHELP : 0);
+        column_workgroup(d, S.msg, block, shp, jobtag, (ticks != 0 && threadIdx.x == 0 && block == 0) ? 1 : 0);
+        return;
+    }
+    if (HELP && wg >= G) {  // a helper workgroup of the exact ComputeRx sums (see decide_step)
         rx_helper_workgroup(d, L, wg - G, jobtag, &hword);
         return;
     }
     // phase split of the last-arriving workgroup (diagnostic, FNN_TICKS=1): thread 0 stamps the 100 MHz clock
     const bool prof = ticks != 0 && threadIdx.x == 0;
 #define TRK_TICK(slot) do { if (prof) S.tk[(slot) + 1] = (long long)wall_clock64(); } while (0)
-    // The tracking part.  Returns the block of columns this workgroup updates once the plan message is there (-1: none, -2: it
-    // has to wait for the message to know).
-    auto track = [&]() -> int {
     if (threadIdx.x == 0) S.tkon = ticks;
     if (prof) S.tk[0] = (long long)wall_clock64();
     // (this thread's first tracked pair is fetched beside the control block: its address depends on nothing)
@@ -2546,46 +2624,43 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
     rec0.e[0] = rec0.e[1] = rec0.e[2] = rec0.e[3] = 0.0;
     if (start < LA_PCAP) rec0 = track_pair_load(d, start);
     if (st->done) {
-        if (wg == 0) {
-            if (threadIdx.x == 0) {
-                st->ev_active = 0;  // (a launch sequence without a decide kernel must not replay the last event)
-                if (HELP) job_post(d, jobtag, 0u);
-            }
-            if (fuse && threadIdx.x < 64) plan_post_none(d, jobtag);
+        if (wg == 0 && threadIdx.x == 0) {
+            st->ev_active = 0;  // (a launch sequence without a decide kernel must not replay the last event)
+            if (HELP) job_post(d, jobtag, 0u);
         }
-        return -1;
+        if (FUSE && wg == 0 && threadIdx.x < 64) plan_post_none(d, jobtag);
+        return;
     }
     // every tracking workgroup fetches the control block now (nothing writes to it while they track): the one that
     // arrives last continues on this LDS copy and writes it back at the end
     state_in(S.lst, st);
     if (!has_scan && st->stall) {  // (the launch sequence has no scan kernels and the window is gone: nothing to do)
-        if (wg == 0) {
-            if (threadIdx.x == 0) {
-                st->n_stalled++;
-                if (HELP) job_post(d, jobtag, 0u);
-            }
-            if (fuse && threadIdx.x < 64) plan_post_none(d, jobtag);
+        if (wg == 0 && threadIdx.x == 0) {
+            st->n_stalled++;
+            if (HELP) job_post(d, jobtag, 0u);
         }
-        return -1;
+        if (FUSE && wg == 0 && threadIdx.x < 64) plan_post_none(d, jobtag);
+        return;
     }
     if (force_base || !la_active(*st)) {
-        if (wg == 0) {
-            if (threadIdx.x == 0) {
-                if (HELP) job_post(d, jobtag, 0u);
-                st->ev_timed = timed;
-                if (st->la_valid) st->la_prev_end = 0;  // the window ends on schedule
-                la_prepare_base(*st, d.lacnt);
-                st->stall = has_scan ? 0 : 1;
-                if (!has_scan) st->n_stalled++;
-            }
-            if (fuse && threadIdx.x < 64) plan_post_none(d, jobtag);
+        if (wg == 0 && threadIdx.x == 0) {
+            if (HELP) job_post(d, jobtag, 0u);
+            st->ev_timed = timed;
+            if (st->la_valid) st->la_prev_end = 0;  // the window ends on schedule
+            la_prepare_base(*st, d.lacnt);
+            st->stall = has_scan ? 0 : 1;
+            if (!has_scan) st->n_stalled++;
         }
-        return -1;
+        if (FUSE && wg == 0 && threadIdx.x < 64) plan_post_none(d, jobtag);
+        return;
     }
     // (fused event kernel) the pending row sum as the control block describes it at the START of the launch
     const int32_t chain_pending0 = st->chain_pending, chain_buf0 = st->chain_buf, chain_U0 = st->chain_U, m0 = st->m;
     const unsigned evtag0 = (unsigned)st->n_events;
-    const int nbulk = (m0 + TRK_THREADS - 1) / TRK_THREADS;
+    if (FUSE && threadIdx.x == 0) {  // (parked in LDS for the tail: no scalar register stays live across the decide step for them)
+        S.fz[0] = chain_pending0; S.fz[1] = chain_buf0; S.fz[2] = chain_U0; S.fz[3] = (int32_t)evtag0;
+        S.fz[4] = (m0 + BULK_COLS - 1) / BULK_COLS; S.fz[5] = 0;
+    }
     TrackArgs ta = track_args(*st);
     const int64_t items = track_item_count(ta);
     // The swept cluster's exact row sum is being computed by workgroup 0: the sweep runs on the tree-ordered
@@ -2669,7 +2744,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         lastflag = last;
     }
     __syncthreads();
-    if (!lastflag) return (fuse && wg < nbulk) ? -2 : -1;  // (fused: its block of columns, once the plan is there)
+    if (!lastflag) return;
     // (no acquire fence: the records are read past the caches, rec_fetch, after the barrier above)
     TRK_TICK(4);
     // from here on this workgroup works on its LDS copy of the control block (no other workgroup writes to it
@@ -2683,7 +2758,7 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         b = cand_none();
         bu = b;
         const unsigned badword = __hip_atomic_load(d.ticket + TRK_BAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned errword = fuse ? __hip_atomic_load(d.ticket + TRK_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const unsigned errword = FUSE ? __hip_atomic_load(d.ticket + TRK_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         const uint32_t tag = evtag0;
         bool stale = false, reread = false;
         for (int pass = 0; pass < 2; pass++) {
@@ -2777,154 +2852,103 @@ __global__ __launch_bounds__(TRK_THREADS) void k_track(Dev d, int force_base, in
         for (int q = 0; q < 8; q++) d.ticks[q] += S.tk[q + 1] - S.tk[q];
     }
     __syncthreads();
-    if (fuse) {
-        long long tk0 = prof ? (long long)wall_clock64() : 0;
+    if (FUSE) {
+        // The rest of the event by WAVE 0 alone (the other waves wait at the barrier in front of the write-back): no workgroup
+        // barrier on this stretch - one wave's LDS accesses execute in program order (special_sync<false>).
+        if (threadIdx.x < 64) {
+            const int lane = (int)threadIdx.x;
+            const int32_t chain_pending0 = S.fz[0], chain_buf0 = S.fz[1], chain_U0 = S.fz[2], nbulk = S.fz[4];
+            const unsigned evtag0 = (unsigned)S.fz[3];
+            long long tk0 = prof ? (long long)wall_clock64() : 0;
 #define FUS_TICK(slot) do { if (prof) { const long long now_ = (long long)wall_clock64(); d.ticks[8 + (slot)] += now_ - tk0; tk0 = now_; } } while (0)
-        const bool upd = lst.la_hit && lst.ev_active;
-        if (!upd) {
-            if (threadIdx.x < 64) plan_post_none(d, jobtag);
-        } else {
-            // ---- the plan message: the tail of the control block (nS .. tgt) word for word, the scalars by thread 0
-            PlanMsg& M = S.msg;
-            const int chain_wait = chain_pending0 ? 1 : 0;
-            const int chain_dst = (chain_pending0 && chain_buf0 == 0) ? CHAIN_ALT : 0;
-            static_assert(offsetof(PlanMsg, fill) - offsetof(PlanMsg, nS) == 60 * 4 && sizeof(State) - offsetof(State, nS) == 60 * 4, "plan tail layout");
-            if (threadIdx.x >= 64 && threadIdx.x < 64 + 60) (&M.nS)[threadIdx.x - 64] = (&lst.nS)[threadIdx.x - 64];
-            if (threadIdx.x >= 128 && threadIdx.x < 128 + 44) M.fill[threadIdx.x - 128] = 0;
-            if (threadIdx.x == 0) {
-                M.kind = 1; M.last_wg = wg; M.pU = S.msg_pU; M.cU = chain_pending0 ? chain_U0 : -2; M.chain_wait = chain_wait;
-                M.evtag = (int32_t)evtag0; M.chain_dst = chain_dst; M.nbulk = nbulk;
-                M.pov_n = lst.pov_n; M.pov_slot[0] = lst.pov_slot[0]; M.pov_slot[1] = lst.pov_slot[1];
-                M.pov_pos[0] = lst.pov_pos[0]; M.pov_pos[1] = lst.pov_pos[1]; M.pad0 = 0;
-                const uint64_t t0b = __builtin_bit_cast(uint64_t, S.tfin[0]), t1b = __builtin_bit_cast(uint64_t, S.tfin[1]);
-                M.tfin[0] = (int32_t)(uint32_t)t0b; M.tfin[1] = (int32_t)(uint32_t)(t0b >> 32);
-                M.tfin[2] = (int32_t)(uint32_t)t1b; M.tfin[3] = (int32_t)(uint32_t)(t1b >> 32);
-                M.m_old = lst.m_old; M.P_old = lst.P_old; M.ev_finish = lst.ev_finish; M.xs = lst.xs; M.ys = lst.ys; M.pad1 = 0;
-            }
-            __syncthreads();
-            if (threadIdx.x < 64) plan_post(d, M, jobtag);
-            FUS_TICK(0);
-            // ---- the involved slots' phases on this LDS copy (k_update's special workgroup, here without fetching the control block)
-            double* blk = S.blk; double* sxl = S.sxl; double* tl = S.tl;
-            if (threadIdx.x == 0) {
-                S.berr = 0;
-                bool needs = false;
-                for (int i = 0; i < lst.nS; i++) needs = needs || (chain_wait && (lst.S[i] == chain_U0 || lst.S[i] == chain_U0 + 1));
-                if (needs) {  // an involved slot's exact row sum is still on its way from the chain workgroup of this launch
-                    const long long t_wait = (long long)wall_clock64();
-                    while (__hip_atomic_load(d.ticket + TRK_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != evtag0) {
-                        if ((long long)wall_clock64() - t_wait > TRK_WAIT_TICKS) { lst.error = 10; break; }
-                        __builtin_amdgcn_s_sleep(2);
+            const bool upd = lst.la_hit && lst.ev_active;
+            if (!upd) plan_post_none(d, jobtag);
+            else {
+                // ---- the plan message: the tail of the control block (nS .. tgt) word for word, the scalars by three lanes
+                PlanMsg& M = S.msg;
+                const int chain_wait = chain_pending0 ? 1 : 0;
+                const int chain_dst = (chain_pending0 && chain_buf0 == 0) ? CHAIN_ALT : 0;
+                static_assert(offsetof(PlanMsg, fill) - offsetof(PlanMsg, nS) == 60 * 4 && sizeof(State) - offsetof(State, nS) == 60 * 4, "plan tail layout");
+                if (lane < 60) (&M.nS)[lane] = (&lst.nS)[lane];
+                if (lane < 44) M.fill[lane] = 0;
+                if (lane == 61) {
+                    M.kind = 1; M.last_wg = wg; M.pU = S.msg_pU; M.cU = chain_pending0 ? chain_U0 : -2; M.chain_wait = chain_wait;
+                    M.evtag = (int32_t)evtag0; M.chain_dst = chain_dst; M.nbulk = nbulk;
+                }
+                if (lane == 62) {
+                    M.pov_n = lst.pov_n; M.pov_slot[0] = lst.pov_slot[0]; M.pov_slot[1] = lst.pov_slot[1];
+                    M.pov_pos[0] = lst.pov_pos[0]; M.pov_pos[1] = lst.pov_pos[1]; M.pad0 = 0;
+                    M.m_old = lst.m_old; M.P_old = lst.P_old; M.ev_finish = lst.ev_finish; M.xs = lst.xs; M.ys = lst.ys; M.pad1 = 0;
+                }
+                if (lane == 63) {
+                    const uint64_t t0b = __builtin_bit_cast(uint64_t, S.tfin[0]), t1b = __builtin_bit_cast(uint64_t, S.tfin[1]);
+                    M.tfin[0] = (int32_t)(uint32_t)t0b; M.tfin[1] = (int32_t)(uint32_t)(t0b >> 32);
+                    M.tfin[2] = (int32_t)(uint32_t)t1b; M.tfin[3] = (int32_t)(uint32_t)(t1b >> 32);
+                }
+                special_sync<false>();
+                plan_post(d, M, jobtag);
+                FUS_TICK(0);
+                // ---- the involved slots' phases on this LDS copy (k_update's special workgroup, here without fetching the control block)
+                double* blk = S.blk; double* sxl = S.sxl; double* tl = S.tl;
+                if (lane == 0) S.berr = 0;
+                {
+                    bool mine = lane < lst.nS && chain_wait && (lst.S[lane < MAX_S ? lane : 0] == chain_U0 || lst.S[lane < MAX_S ? lane : 0] == chain_U0 + 1);
+                    if (__ballot(mine) != 0ULL) {  // an involved slot's exact row sum is still on its way from the chain workgroup of this launch
+                        const long long t_wait = (long long)wall_clock64();
+                        while (__hip_atomic_load(d.ticket + TRK_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != evtag0) {
+                            if ((long long)wall_clock64() - t_wait > TRK_WAIT_TICKS) { if (lane == 0) lst.error = 10; break; }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
                     }
                 }
-            }
-            __syncthreads();
-            if (threadIdx.x < MAX_S * MAX_S) {
-                const int32_t e = (int32_t)threadIdx.x, i = e / MAX_S, j = e % MAX_S;
-                special_block_load(dl, blk, sxl, tl, e);
-                if (i < lst.nS && j == 0 && chain_wait && (lst.S[i] == chain_U0 || lst.S[i] == chain_U0 + 1))
-                    sxl[i] = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const uint64_t*>(d.Sx + lst.S[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                if (i < lst.nS && j == 1 && S.msg_pU >= 0 && (lst.S[i] == S.msg_pU || lst.S[i] == S.msg_pU + 1)) tl[i] = S.tfin[lst.S[i] - S.msg_pU];
-            }
-            __syncthreads();
-            FUS_TICK(1);
-            double dsum = 0.0, dabs = 0.0, tu = 0.0, tv = 0.0;
-            if (threadIdx.x < 64) {  // (the other waves only keep the barriers company)
-                const SpecialOut o = special_wave(d, lst, blk, sxl, tl, &S.berr, d.chain + (size_t)chain_dst * d.cstride);
-                dsum = o.val;
-                dabs = o.val < 0.0 ? -o.val : o.val;
-                tu = o.tu;
-                tv = o.tv;
+                {
+                    const int32_t e = (int32_t)lane, i = e / MAX_S, j = e % MAX_S;
+                    special_block_load(dl, blk, sxl, tl, e);
+                    if (i < lst.nS && j == 0 && chain_wait && (lst.S[i] == chain_U0 || lst.S[i] == chain_U0 + 1))
+                        sxl[i] = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const uint64_t*>(d.Sx + lst.S[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (i < lst.nS && j == 1 && S.msg_pU >= 0 && (lst.S[i] == S.msg_pU || lst.S[i] == S.msg_pU + 1)) tl[i] = S.tfin[lst.S[i] - S.msg_pU];
+                }
+                special_sync<false>();
+                FUS_TICK(1);
+                const SpecialOut o = special_wave<false>(d, lst, blk, sxl, tl, &S.berr, d.chain + (size_t)chain_dst * d.cstride);
+                double dsum = o.val, dabs = o.val < 0.0 ? -o.val : o.val, tu = o.tu, tv = o.tv;
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) {
                     dsum += __shfl_down(dsum, off, 64); dabs += __shfl_down(dabs, off, 64);
                     tu += __shfl_down(tu, off, 64); tv += __shfl_down(tv, off, 64);
                 }
-                if (threadIdx.x == 0) {  // this workgroup's partial sums: record nbulk (behind the column blocks')
+                if (lane == 0) {  // this workgroup's partial sums: record nbulk (behind the column blocks')
                     double* r = d.upart + 4 * (size_t)nbulk;
                     r[0] = dsum; r[1] = dabs; r[2] = tu; r[3] = tv;
                 }
-            } else {
-                const int nb = 2 + lst.nops;
-                for (int q = 0; q < nb; q++) __syncthreads();
-            }
-            FUS_TICK(2);
-            if (threadIdx.x < MAX_S * MAX_S) special_block_store(dl, blk, sxl, tl, (int32_t)threadIdx.x);
-            // the close of the event (nothing in the update reads what it writes)
-            if (threadIdx.x == 64) {
-                lst.tp_n = lst.ev_finish ? 0 : nbulk + 1;  // partial sums of T of the new cluster's nodes: the next decide step adds them up
-                lst.tp_U = lst.U;
-                if (S.berr) lst.error = S.berr;
-                lst.upart_n = nbulk + 1;
-                lst.chain_m = lst.m;
-                lst.chain_U = lst.U;
-                lst.chain_buf = chain_dst;
-                lst.chain_pending = lst.ev_finish ? 0 : 1;
-                close_event(dl);
-                if (lst.ev_finish) {  // special finish: u, v keep the default Sx (NetNode.java:15); nothing to sum
-                    d.Sx[lst.U] = 0.0;
-                    d.Sx[lst.U + 1] = 0.0;
+                FUS_TICK(2);
+                special_block_store(dl, blk, sxl, tl, (int32_t)lane);
+                // the close of the event (nothing in the update reads what it writes)
+                if (lane == 0) {
+                    lst.tp_n = lst.ev_finish ? 0 : nbulk + 1;  // partial sums of T of the new cluster's nodes: the next decide step adds them up
+                    lst.tp_U = lst.U;
+                    if (S.berr) lst.error = S.berr;
+                    lst.upart_n = nbulk + 1;
+                    lst.chain_m = lst.m;
+                    lst.chain_U = lst.U;
+                    lst.chain_buf = chain_dst;
+                    lst.chain_pending = lst.ev_finish ? 0 : 1;
+                    close_event(dl);
+                    if (lst.ev_finish) {  // special finish: u, v keep the default Sx (NetNode.java:15); nothing to sum
+                        d.Sx[lst.U] = 0.0;
+                        d.Sx[lst.U + 1] = 0.0;
+                    }
                 }
+                FUS_TICK(3);
             }
-            __syncthreads();
-            FUS_TICK(3);
-        }
 #undef FUS_TICK
+        }
+        __syncthreads();
     }
     state_out(st, lst);
-    return -1;
-    };  // track
-    int block = -1;
-    {
-        const int r = spare ? -2 : track();
-        if (r == -2) {  // wait for the plan of this launch
-            const bool prof2 = ticks != 0 && threadIdx.x == 0 && !spare && wg == 0;
-            long long tk0 = prof2 ? (long long)wall_clock64() : 0;
-            plan_wait(d, S.msg, jobtag);
-            if (prof2) d.ticks[12] += (long long)wall_clock64() - tk0;
-            const PlanMsg& M = S.msg;
-            if (M.kind == 1) block = spare ? (M.last_wg < M.nbulk ? M.last_wg : -1) : wg;
-        } else block = r;
-    }
-    if (block < 0) return;
-    // ---- this workgroup's block of 1024 columns
-    {
-        const bool prof2 = ticks != 0 && threadIdx.x == 0 && !spare && wg == 0;
-        long long tk0 = prof2 ? (long long)wall_clock64() : 0;
-        const PlanMsg& M = S.msg;
-        const PlanView pv = plan_view(M, UniLane{});
-        BulkFix fx;
-        fx.cU = __builtin_amdgcn_readfirstlane(M.cU); fx.chain_wait = __builtin_amdgcn_readfirstlane(M.chain_wait);
-        fx.evtag = (unsigned)__builtin_amdgcn_readfirstlane(M.evtag);
-        fx.pU = __builtin_amdgcn_readfirstlane(M.pU);
-        fx.tfin0 = __builtin_bit_cast(double, ((uint64_t)(uint32_t)M.tfin[1] << 32) | (uint32_t)M.tfin[0]);
-        fx.tfin1 = __builtin_bit_cast(double, ((uint64_t)(uint32_t)M.tfin[3] << 32) | (uint32_t)M.tfin[2]);
-        fx.pov_n = __builtin_amdgcn_readfirstlane(M.pov_n);
-        fx.pov_slot[0] = __builtin_amdgcn_readfirstlane(M.pov_slot[0]); fx.pov_slot[1] = __builtin_amdgcn_readfirstlane(M.pov_slot[1]);
-        fx.pov_pos[0] = __builtin_amdgcn_readfirstlane(M.pov_pos[0]); fx.pov_pos[1] = __builtin_amdgcn_readfirstlane(M.pov_pos[1]);
-        const int chain_dst = __builtin_amdgcn_readfirstlane(M.chain_dst);
-        if (prof2) { const long long now_ = (long long)wall_clock64(); d.ticks[13] += now_ - tk0; tk0 = now_; }
-        double dsum = 0.0, dabs = 0.0, tu = 0.0, tv = 0.0;
-        bulk_column<true>(d, pv, (int32_t)(block * TRK_THREADS + (int)threadIdx.x), d.chain + (size_t)chain_dst * d.cstride, fx, dsum, dabs, tu, tv);
-        if (prof2) { const long long now_ = (long long)wall_clock64(); d.ticks[14] += now_ - tk0; tk0 = now_; }
-        // per-workgroup partial sums (tree order), as k_update's
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            dsum += __shfl_down(dsum, off, 64); dabs += __shfl_down(dabs, off, 64);
-            tu += __shfl_down(tu, off, 64); tv += __shfl_down(tv, off, 64);
-        }
-        if ((threadIdx.x & 63) == 0) { double* r = shp[threadIdx.x >> 6]; r[0] = dsum; r[1] = dabs; r[2] = tu; r[3] = tv; }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            const int k = threadIdx.x;
-            double acc = 0.0;
-            for (int w = 0; w < TRK_THREADS / 64; w++) acc += shp[w][k];
-            d.upart[4 * (size_t)block + k] = acc;
-        }
-        if (prof2) d.ticks[15] += (long long)wall_clock64() - tk0;
-    }
 #undef TRK_TICK
 }
+
 
 // ------------------------------------------------------------------ k_update
 // subtract + every micro-op + add of one event in ONE launch (fnn_core.h: update_bulk /
@@ -2967,7 +2991,7 @@ __global__ __launch_bounds__(256) void k_update(Dev d, int defer, int ticks) {
         __syncthreads();
         UPD_TICK(1);
         if (threadIdx.x < 64) {  // (the other waves only keep the barriers company)
-            const SpecialOut o = special_wave(d, lst, blk, sxl, tl, &berr, d.chain);
+            const SpecialOut o = special_wave<true>(d, lst, blk, sxl, tl, &berr, d.chain);
             dsum = o.val;
             dabs = o.val < 0.0 ? -o.val : o.val;
             tu = o.tu;
@@ -3210,7 +3234,7 @@ struct HipBackend {
     bool skip_unsched_scans = true; // FNN_UNSCHED_SCANS=1: keep the (mostly idle) scan kernels in unscheduled events
     int track_group = TRK_GROUP;  // k_track: workgroups per first-level arrival counter (FNN_TRACK_GROUP)
     bool defer_chain = false; // set by the engine: k_update closes the event, the exact u.Sx sum runs inside the next k_track
-    bool fuse_events = true;  // window events as ONE launch (k_track with fuse; FNN_FUSE=0: k_track + k_update as before)
+    bool fuse_events = false; // window events as ONE launch (k_track<.., true>; FNN_FUSE=1).  Off: measured 1.456 s against 1.408 s at 32768 taxa
     bool fused_last = false;  // the launch sequence being enqueued is such a fused one
     bool scan_nt = true;    // non-temporal matrix loads in the scan (FNN_SCAN_NT)
     bool ticks = false;     // FNN_TICKS=1: k_track records the phase split of its last workgroup (fnn_debug_event_ticks)
@@ -3461,16 +3485,15 @@ struct HipBackend {
         const bool has_scan = sched || !screen || !skip_unsched_scans;
         // a WINDOW event in one launch (k_track with fuse: tracking, decide step and the update; no k_update follows): only launch
         // sequences without scan kernels, with the row sum deferred, and while every block of 1024 columns finds a tracking workgroup
-        fused_last = fuse_events && d.la && screen && !has_scan && defer_chain && (m_bound + TRK_THREADS - 1) / TRK_THREADS <= track_grid;
-        const int fz = fused_last ? 1 : 0;
+        fused_last = fuse_events && d.la && screen && !has_scan && defer_chain;
+        const int fz = fused_last ? (m_bound + BULK_COLS - 1) / BULK_COLS : 0;  // column workgroups of a fused launch
         if (d.la) timed(TC_TRACK, tall, [&]() {
             track_tag = (track_tag % 0x7FFFFFEu) + 1u;  // (never 0: the JOB word and the plan message start out as 0)
-            if (rx_helpers > 0)
-                hipLaunchKernelGGL(k_track<true>, dim3(track_grid + 1 + TRK_NHELP + fz), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0,
-                                   has_scan ? 1 : 0, track_group, ticks ? 1 : 0, track_tag, fz);
-            else
-                hipLaunchKernelGGL(k_track<false>, dim3(track_grid + 1 + fz), dim3(TRK_THREADS), 0, stream, d, (sched || !screen) ? 1 : 0, (sched || !screen) ? 1 : 0,
-                                   has_scan ? 1 : 0, track_group, ticks ? 1 : 0, track_tag, fz);
+            const int fb = (sched || !screen) ? 1 : 0, hs = has_scan ? 1 : 0, tk = ticks ? 1 : 0;
+            if (rx_helpers > 0 && fz) hipLaunchKernelGGL((k_track<true, true>), dim3(track_grid + 1 + TRK_NHELP + fz), dim3(TRK_THREADS), 0, stream, d, fb, fb, hs, track_group, tk, track_tag, fz);
+            else if (rx_helpers > 0) hipLaunchKernelGGL((k_track<true, false>), dim3(track_grid + 1 + TRK_NHELP), dim3(TRK_THREADS), 0, stream, d, fb, fb, hs, track_group, tk, track_tag, 0);
+            else if (fz) hipLaunchKernelGGL((k_track<false, true>), dim3(track_grid + 1 + fz), dim3(TRK_THREADS), 0, stream, d, fb, fb, hs, track_group, tk, track_tag, fz);
+            else hipLaunchKernelGGL((k_track<false, false>), dim3(track_grid + 1), dim3(TRK_THREADS), 0, stream, d, fb, fb, hs, track_group, tk, track_tag, 0);
         });
         int nrecs;
         if (screen && !has_scan) nrecs = 0;  // (a window event: the tail of k_track decides; no decide kernel follows)

@@ -108,3 +108,15 @@ def test_default_mode_matches_oracle_golden(hip_api, oracle, n, dist, seed):
     # the write-through hand-over of k_track's fan-in is measured behaviour of the part: a reread means
     # that form failed here and its cause has to be found, even though the result above is right
     assert st.n_handover_retries == 0, f"{st.n_handover_retries} window events reread the records of k_track's fan-in"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,dist,seed", [(4096, "dec4", 1), (4096, "tree", 5), (8192, "treenoise", 8)])
+def test_fused_window_events_match_oracle_golden(hip_api, oracle, n, dist, seed, monkeypatch):
+    """FNN_FUSE=1 (off by default: measured slower): a window event as ONE launch - tracking, decide step and
+    update in k_track<.., true>, the plan handed to column workgroups of the same launch as a message.  Tie-rich inputs are the
+    sensitive ones: an address written twice in one launch from different L2 slices (T of the previous cluster) showed up there
+    first, as a run-to-run flicker of the 4-candidate choice.  Twice, to catch such a flicker."""
+    monkeypatch.setenv("FNN_FUSE", "1")
+    for _ in range(2):
+        test_default_mode_matches_oracle_golden(hip_api, oracle, n, dist, seed)

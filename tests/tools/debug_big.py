@@ -36,7 +36,11 @@ def main():
     c = {(c["n"], c["dist"], c["seed"]): c for c in json.load(open(os.path.join(GOLD, "oracle_big.json")))["cases"]}[(n, dist, seed)]
     z = np.load(os.path.join(GOLD, c["npz"]))
     for name, env, hkw in [("default", {}, {}), ("windows off", {"FNN_LA_K": "-1"}, {}), ("screening off", {}, {"disable_screen": True}),
-                           ("exact rx forced", {}, {"force_exact_rx": True}), ("no deferred chain", {"FNN_NO_DEFER": "1"}, {})]:
+                           ("exact rx forced", {}, {"force_exact_rx": True}), ("no deferred chain", {"FNN_NO_DEFER": "1"}, {}),
+                           ("default again", {}, {}), ("default, third time", {}, {}),
+                           ("window events as two launches (FNN_FUSE=0)", {"FNN_FUSE": "0"}, {}),
+                           ("fused, ComputeRx helpers off", {"FNN_RX_HELPERS": "0"}, {}),
+                           ("two launches, ComputeRx helpers off", {"FNN_FUSE": "0", "FNN_RX_HELPERS": "0"}, {})]:
         try:
             order, st, ev = run(n, dist, seed, env, **hkw)
         except Exception as e:  # noqa: BLE001
