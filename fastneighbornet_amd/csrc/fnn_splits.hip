@@ -806,7 +806,7 @@ struct Solver {
     }
 
     // ------------------------------------------------------------ block active-set method (see the comment above h_entry)
-    int64_t st_lh_steps = 0, st_lh_refactor = 0, st_solves = 0, st_adds = 0, st_dels = 0, st_rejects = 0, st_ratio_steps = 0, st_screened = 0, st_dead_wanting = 0;
+    int64_t st_lh_steps = 0, st_lh_refactor = 0, st_solves = 0, st_adds = 0, st_dels = 0, st_rejects = 0, st_ratio_steps = 0, st_screened = 0, st_dead_wanting = 0, st_revived = 0;
     double t_ops = 0, t_sel = 0, t_append = 0, t_solve = 0, t_dead = 0, t_refactor = 0;  // host wall clock per phase (FNN_SW_LOG)
     struct Blk {
         rocblas_handle bh = nullptr;
@@ -1218,6 +1218,38 @@ struct Solver {
             if (log) t_dead += wall() - t0;
             return fine && blas_ok;
         };
+        // Departed splits (factor positions `rev`) come BACK: a split that left is only constrained to zero - its row is still in the
+        // factor - so un-constraining it costs the compaction of Y's columns and of the Gram matrix and a fresh Gram factor
+        // (r^3, milliseconds), where the route through a rebuild and the candidates re-appends it at f^2 per split.
+        auto revive = [&](const std::vector<int32_t>& rev) -> bool {
+            const double t0 = log ? wall() : 0.0;
+            const int64_t r = b.r, f = b.f;
+            std::vector<uint8_t> back((size_t)f, 0);
+            for (int32_t p : rev) { back[(size_t)p] = 1; dead[(size_t)p] = 0; }
+            std::vector<int32_t> keepcols, newdead;
+            for (int64_t q = 0; q < r; q++)
+                if (!back[(size_t)deadlist[(size_t)q]]) { keepcols.push_back((int32_t)q); newdead.push_back(deadlist[(size_t)q]); }
+            const int64_t rn = (int64_t)keepcols.size();
+            st_revived += r - rn;
+            if (rn > 0) {
+                (void)hipMemcpyAsync(b.dlist2, keepcols.data(), sizeof(int32_t) * (size_t)rn, hipMemcpyHostToDevice, s);
+                hipLaunchKernelGGL(k_gather_sym, g2(rn, rn), dim3(T), 0, s, b.CR, b.rcap, b.dlist2, rn, b.CRw, b.rcap);
+                hipLaunchKernelGGL(k_copy2d, g2(rn, rn), dim3(T), 0, s, b.CRw, b.rcap, b.CR, b.rcap, rn, rn);
+                // (a kept column's new index is never larger than its old one: chunks of new columns can be written in place)
+                for (int64_t c0 = 0; c0 < rn; c0 += b.kmax) {
+                    const int64_t cnt = std::min<int64_t>(b.kmax, rn - c0);
+                    hipLaunchKernelGGL(k_gather_cols, g2(f, cnt), dim3(T), 0, s, b.Y, b.cap, f, b.dlist2 + c0, cnt, b.B, b.cap);
+                    hipLaunchKernelGGL(k_copy2d, g2(f, cnt), dim3(T), 0, s, b.B, b.cap, b.Y + c0 * b.cap, b.cap, f, cnt);
+                }
+                (void)hipMemcpyAsync(b.dlist, newdead.data(), sizeof(int32_t) * (size_t)rn, hipMemcpyHostToDevice, s);
+                (void)hipStreamSynchronize(s);  // (the host vectors are temporaries)
+            }
+            deadlist.swap(newdead);
+            b.r = rn;
+            const bool fine = factor_gram();
+            if (log) t_dead += wall() - t0;
+            return fine && blas_ok;
+        };
         // minimiser of the sub-problem on the splits that are in: xs = W^T (z - Y (Y^T Y)^-1 Y^T z), copied to `out`
         auto solve = [&](std::vector<double>& out) -> bool {
             const double t0 = log ? wall() : 0.0;
@@ -1268,6 +1300,10 @@ struct Solver {
         const int64_t kmin = std::max<int64_t>(8, n / 32);
         int64_t k_limit = b.kmax;
         bool ratio_mode = false, done = false, good = ok, fresh = false, banned_rechecked = false;
+        const bool revive_on = envd("FNN_SW_REVIVE", 1.0) != 0.0;
+        const int64_t revive_min_f = (int64_t)envd("FNN_SW_REVIVE_MINF", 8192.0);
+        bool revive_blocked = false;   // a step that only brought departed splits back did not descend: not again before a step moves
+        int fail_streak = 0, ratio_left = 0;
         auto give = [&](int why, const char* text) { giveup = why; giveup_text = text; good = false; };
         int stall = 0;  // steps in a row whose descent is not measurable (below 1e-13 |objective|)
         const int64_t max_outer = 40 * (int64_t)n + 1000;
@@ -1299,9 +1335,14 @@ struct Solver {
             // (gF holds A^T A x at the factor's splits: c - gF is the multiplier of a split that left, the drift at one that is in)
             double drift = 0.0, wdead = 0.0;
             int64_t dead_wanting = 0;
+            std::vector<int32_t> rev;  // departed splits whose multiplier is positive again: they come back with this step (revive)
             for (size_t p = 0; p < (size_t)b.f; p++) {
                 const double g = cF[p] - gF[p];
-                if (dead[p]) { wdead = std::max(wdead, g); dead_wanting += g > tol ? 1 : 0; } else drift = std::max(drift, std::fabs(g));
+                if (dead[p]) {
+                    wdead = std::max(wdead, g); dead_wanting += g > tol ? 1 : 0;
+                    // (only while the factor is large: below ~8000 splits a rebuild is cheaper than the churn of early returns)
+                    if (g > tol && revive_on && !revive_blocked && b.f >= revive_min_f) rev.push_back((int32_t)p);
+                } else drift = std::max(drift, std::fabs(g));
             }
             st_dead_wanting += dead_wanting;
             const int64_t nlive = b.f - b.r;
@@ -1309,7 +1350,9 @@ struct Solver {
             k = std::max<int64_t>(1, std::min<int64_t>({k, ncand, k_limit}));
             const bool no_cand = ncand == 0;
             if (!no_cand && b.r == 0 && b.f + k > b.cap && b.f < b.cap) k = b.cap - b.f;  // (nothing to rebuild away: fill the factor to the brim first)
-            if ((no_cand && (wdead > tol || (drift > 1e-10 * cmax && !fresh))) || (!no_cand && (b.f + k > b.cap || (double)b.r > rfrac * (double)b.f))) {
+            // (the drift of the gradient on the splits that are in: half of what the solver's own Kuhn-Tucker check allows at the end)
+            if ((no_cand && rev.empty() && (wdead > tol || (drift > 5e-10 * cmax && !fresh))) ||
+                (!no_cand && (b.f + k > b.cap || (double)(b.r - (int64_t)rev.size()) > rfrac * (double)b.f))) {
                 // a split that left wants back in, the factor has drifted or is full of departed splits: rebuild it, solve, look again
                 if (!no_cand && b.r == 0) { give(FNN_SW_GIVEUP_CAPACITY, "the free set outgrew the dense factor"); break; }  // the caller decides about the reference's route
                 if (!refactor()) { give(FNN_SW_GIVEUP_NUMERIC, "rebuild of the factor failed"); break; }
@@ -1317,46 +1360,55 @@ struct Solver {
                 xw = sbuf; phi = objective(xw); fresh = true;
                 continue;
             }
-            if (no_cand) {
+            if (no_cand && rev.empty()) {
                 // Splits that were set aside (numerically dependent on the factor at the time, or no measurable descent) are still
                 // masked: before the method may call this the optimum they get one more look against the current factor.
                 if (!banned.empty() && !banned_rechecked) { set_mask(banned, 0); banned.clear(); banned_rechecked = true; continue; }
                 n_set_aside = (int64_t)banned.size();
                 done = true; break;
             }
-            // ---- the block: the largest local maxima of the multiplier
-            if (hipcub::DeviceRadixSort::SortPairsDescending(b.sort_tmp, b.sort_bytes, b.ckey, b.ckey2, b.cidx, b.cidx2, (int)ncand, 0, 64, s) != hipSuccess) {
-                give(FNN_SW_GIVEUP_NUMERIC, "candidate sort failed"); break;
-            }
-            hipLaunchKernelGGL(k_idx_to_split, g1(k), dim3(T), 0, s, b.cidx2, k, ld, b.dF + b.f);
-            F.resize((size_t)(b.f + k));
-            (void)hipMemcpyAsync(F.data() + b.f, b.dF + b.f, sizeof(int2) * (size_t)k, hipMemcpyDeviceToHost, s);
-            (void)hipStreamSynchronize(s);
-            if (log) t_sel += wall() - t0;
-            // ---- it enters, the weights that are not positive leave, the objective decides
+            // ---- the block: the largest local maxima of the multiplier (none: a step that only brings departed splits back)
             const int64_t f0 = b.f, r0 = b.r;
-            const int2 first = F[(size_t)f0];
             const std::vector<uint8_t> dead0 = dead;
             const std::vector<double> x0 = xw;
             const std::vector<int32_t> deadlist0 = deadlist;
             if (r0 > 0) hipLaunchKernelGGL(k_copy2d, g2(r0, r0), dim3(T), 0, s, b.CR, b.rcap, b.CRb, b.rcap, r0, r0);
-            std::vector<int32_t> kept;
-            const int64_t kin = append(k, b.ckey2, kept);
-            if (kin < 0) { give(FNN_SW_GIVEUP_NUMERIC, "append failed (BLAS / Cholesky)"); break; }
-            if (kin == 0) {  // the first split is numerically dependent on the factor: set it aside until progress is made
-                F.resize((size_t)f0);
-                banned.push_back(first); set_mask({first}, 1);
-                continue;
+            int64_t kin = 0;
+            int2 entered = make_int2(-1, -1);
+            if (!no_cand) {
+                if (hipcub::DeviceRadixSort::SortPairsDescending(b.sort_tmp, b.sort_bytes, b.ckey, b.ckey2, b.cidx, b.cidx2, (int)ncand, 0, 64, s) != hipSuccess) {
+                    give(FNN_SW_GIVEUP_NUMERIC, "candidate sort failed"); break;
+                }
+                hipLaunchKernelGGL(k_idx_to_split, g1(k), dim3(T), 0, s, b.cidx2, k, ld, b.dF + b.f);
+                F.resize((size_t)(b.f + k));
+                (void)hipMemcpyAsync(F.data() + b.f, b.dF + b.f, sizeof(int2) * (size_t)k, hipMemcpyDeviceToHost, s);
+                (void)hipStreamSynchronize(s);
+                // (tried: returns only for multipliers that would have made the block - fewer returns, but more one-split solves: 78.0 s
+                //  instead of 74.4 s at 32768 taxa)
+                if (log) t_sel += wall() - t0;
+                // ---- it enters, the weights that are not positive leave, the objective decides
+                const int2 first = F[(size_t)f0];
+                std::vector<int32_t> kept;
+                kin = append(k, b.ckey2, kept);
+                if (kin < 0) { give(FNN_SW_GIVEUP_NUMERIC, "append failed (BLAS / Cholesky)"); break; }
+                if (kin == 0) {  // the first split is numerically dependent on the factor: set it aside until progress is made
+                    F.resize((size_t)f0);
+                    banned.push_back(first); set_mask({first}, 1);
+                    if (rev.empty()) continue;
+                } else {
+                    for (int64_t q = 0; q < kin; q++) F[(size_t)(f0 + q)] = F[(size_t)(f0 + kept[(size_t)q])];
+                    F.resize((size_t)(f0 + kin));
+                    entered = F[(size_t)f0];
+                    hipLaunchKernelGGL(k_mask, g1(kin), dim3(T), 0, s, b.dF + f0, kin, act, ld, (uint8_t)1);
+                    st_adds += kin;
+                    xw.resize((size_t)b.f, 0.0); dead.resize((size_t)b.f, 0); cF.resize((size_t)b.f);
+                    hipLaunchKernelGGL(k_gather, g1(kin), dim3(T), 0, s, b.dF + f0, kin, atwd, ld, b.xs);
+                    (void)hipMemcpyAsync(cF.data() + f0, b.xs, sizeof(double) * (size_t)kin, hipMemcpyDeviceToHost, s);
+                    (void)hipStreamSynchronize(s);
+                }
             }
-            for (int64_t q = 0; q < kin; q++) F[(size_t)(f0 + q)] = F[(size_t)(f0 + kept[(size_t)q])];
-            F.resize((size_t)(f0 + kin));
-            const int2 entered = F[(size_t)f0];
-            hipLaunchKernelGGL(k_mask, g1(kin), dim3(T), 0, s, b.dF + f0, kin, act, ld, (uint8_t)1);
-            st_adds += kin;
-            xw.resize((size_t)b.f, 0.0); dead.resize((size_t)b.f, 0); cF.resize((size_t)b.f);
-            hipLaunchKernelGGL(k_gather, g1(kin), dim3(T), 0, s, b.dF + f0, kin, atwd, ld, b.xs);
-            (void)hipMemcpyAsync(cF.data() + f0, b.xs, sizeof(double) * (size_t)kin, hipMemcpyDeviceToHost, s);
-            (void)hipStreamSynchronize(s);
+            const bool revived = !rev.empty();
+            if (revived && !revive(rev)) { give(FNN_SW_GIVEUP_NUMERIC, "Gram factor of the departed columns failed"); break; }
             bool feasible = true;
             if (!ratio_mode) feasible = settle_all();
             else {  // Lawson & Hanson: as far towards the sub-problem's minimiser as feasibility allows; what reaches zero leaves
@@ -1389,17 +1441,21 @@ struct Solver {
             const double phi_eps = 1e-13 * std::fabs(phi);
             if (!(ratio_mode ? phi_new < phi + phi_eps : phi_new < phi)) {  // no descent: the factor as it was before this block
                 st_rejects++;
-                if (log) std::fprintf(stderr, "  [sw] step %lld: block of %lld at |F| = %lld taken back (%.17g vs %.17g)%s\n", (long long)st_lh_steps, (long long)kin,
-                                      (long long)(f0 - r0), phi_new, phi, ratio_mode ? " [ratio step]" : "");
-                hipLaunchKernelGGL(k_mask, g1(b.f - f0), dim3(T), 0, s, b.dF + f0, b.f - f0, act, ld, (uint8_t)0);
+                if (log) std::fprintf(stderr, "  [sw] step %lld: block of %lld (+%lld departed splits back) at |F| = %lld taken back (%.17g vs %.17g)%s\n", (long long)st_lh_steps,
+                                      (long long)kin, (long long)rev.size(), (long long)(f0 - r0), phi_new, phi, ratio_mode ? " [ratio step]" : "");
+                if (b.f > f0) hipLaunchKernelGGL(k_mask, g1(b.f - f0), dim3(T), 0, s, b.dF + f0, b.f - f0, act, ld, (uint8_t)0);
                 b.f = f0; b.r = r0;
                 F.resize((size_t)f0); dead = dead0; xw = x0; deadlist = deadlist0; cF.resize((size_t)f0);
                 if (r0 > 0) {
                     hipLaunchKernelGGL(k_copy2d, g2(r0, r0), dim3(T), 0, s, b.CRb, b.rcap, b.CR, b.rcap, r0, r0);
                     (void)hipMemcpyAsync(b.dlist, deadlist.data(), sizeof(int32_t) * (size_t)r0, hipMemcpyHostToDevice, s);
+                    // (departed splits had come back with this step: Y's columns were compacted - fetch them from the factor again)
+                    if (revived) hipLaunchKernelGGL(k_gather_cols_tri, g2(f0, r0), dim3(T), 0, s, b.Ws, f0, b.dlist, r0, b.Y, b.cap);
                     (void)hipStreamSynchronize(s);
                     if (!factor_gram()) { give(FNN_SW_GIVEUP_NUMERIC, "Gram factor of the departed columns failed"); break; }
                 }
+                if (revived) revive_blocked = true;    // (no returns again before a step has moved)
+                if (revived && kin == 0) continue;     // (nothing had entered: only the returns are taken back)
                 // the same block once more with Lawson & Hanson's step, which cannot ascend; if that made no progress either (rounding
                 // noise at this level): a quarter of the block, and a single split that does not move is set aside
                 if (ratio_mode) {
@@ -1421,7 +1477,10 @@ struct Solver {
                     }
                     k_limit = std::max<int64_t>(1, kin / 4);
                 } else {
+                    // the guaranteed step for the retry of this block; block steps again afterwards - unless they keep failing
                     ratio_mode = true; k_limit = kin;
+                    fail_streak++;
+                    ratio_left = fail_streak >= 3 ? 8 : 1;
                 }
                 continue;
             }
@@ -1445,7 +1504,12 @@ struct Solver {
                 }
             }
             k_limit = k_limit > b.kmax / 2 ? b.kmax : 2 * k_limit;
-            ratio_mode = ratio_mode && ncand <= 2 * kmin;  // near the end (few candidates, each displacing one split) the guaranteed step stays on
+            // (round 3 kept the guaranteed step on for the rest of the run once few candidates were left: 875 one-split solves in the last
+            //  15 steps of a 32768-taxon solve, 9387 on distances with negative entries.  Now it is on for the retry of a block that did
+            //  not descend and - after three such blocks in a row - for the next eight steps.)
+            if (ratio_mode) { if (--ratio_left <= 0) ratio_mode = false; }
+            else fail_streak = 0;
+            if (moved) revive_blocked = false;
             if (moved) banned_rechecked = false;
             if (moved && !banned.empty()) { set_mask(banned, 0); banned.clear(); }  // progress: the splits set aside may be looked at again
             if (log && (st_lh_steps % 10 == 0 || st_lh_steps < 5))
@@ -1468,8 +1532,8 @@ struct Solver {
                               "sel %.2f append %.2f solve %.2f depart %.2f refactor %.2f s\n", good ? "done" : "gave up", (long long)st_lh_steps, (long long)st_solves,
                               (long long)st_adds, (long long)st_screened, (long long)st_dels, (long long)st_rejects, (long long)st_ratio_steps, (long long)st_lh_refactor, (long long)(b.f - b.r),
                               t_ops, t_sel, t_append, t_solve, t_dead, t_refactor);
-        if (log) std::fprintf(stderr, "  [sw]   GEMM work through gemm(): %.3e flop; departed splits with a positive multiplier, summed over the steps: %lld\n", gemm_flops,
-                              (long long)st_dead_wanting);
+        if (log) std::fprintf(stderr, "  [sw]   GEMM work through gemm(): %.3e flop; departed splits with a positive multiplier, summed over the steps: %lld; brought back: %lld\n",
+                              gemm_flops, (long long)st_dead_wanting, (long long)st_revived);
         if (log) for (const auto& kv : tsub) std::fprintf(stderr, "  [sw]   %-28s %8.3f s\n", kv.first.c_str(), kv.second);
         return good;
     }

@@ -128,17 +128,20 @@ def test_gpu_split_weights_reach_the_nnls_optimum(hip_api, oracle):
         os.environ.pop("FNN_SW_REFERENCE_METHOD", None)
     # circular metrics: the known weights come back (closed form where every split of the metric is positive,
     # from below or from above where zeros have to be found)
+    # (n > 40: built with the prefix-sum operator - the dense live design matrix of 300 taxa has 2e9 entries and took the GPU box 140 s)
     for n, seed, dens in [(12, 7, 0.4), (40, 8, 0.4), (120, 9, 0.4), (300, 10, 0.05), (1024, 11, 1.0)]:
-        D, order, w = circ_instance(n, seed, dens) if n <= 300 else circ_instance_fast(n, seed)
+        D, order, w = circ_instance(n, seed, dens) if n <= 40 else circ_instance_fast(n, seed, dens)
         got, st = fa.split_weights(D, order)
         assert np.abs(got - w).max() < 1e-6 * max(1.0, w.max()), (n, np.abs(got - w).max(), st)
 
 
-def circ_instance_fast(n, seed):
-    """A large circular metric with ALL splits positive, built with the prefix-sum operator instead of the dense matrix."""
+def circ_instance_fast(n, seed, density=1.0):
+    """A large circular metric (a fraction `density` of the splits positive), built with the prefix-sum operator instead of the dense matrix."""
     rng = np.random.default_rng(seed)
     order = np.concatenate([[0, 1], 2 + rng.permutation(n - 1)]).astype(np.int32)
     x = rng.random(W.npairs(n)) + 0.01          # fast index space
+    if density < 1.0:
+        x *= rng.random(W.npairs(n)) < density
     dpos = W.calculate_ab(n, x)                 # distances between cycle POSITIONS
     D = np.zeros((n, n))
     iu = np.triu_indices(n, 1)
@@ -247,3 +250,42 @@ def hostlib_nexus():
     lib.fnnh_write_nexus.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     lib.fnnh_write_nexus.restype = C.c_int32
     return lib
+
+
+@pytest.mark.gpu
+def test_gpu_split_weights_nearly_circular_inputs_and_the_capacity_status(hip_api, oracle, monkeypatch):
+    """Distances whose optimum has far more positive splits than random or tree-like ones: a circular metric with 1 %
+    multiplicative noise (tests/inputs.py: circ_noise) ends with ~20 n positive splits (measured: 21 877 at 1024 taxa, 41 034 at
+    2048, 73 946 at 4096).  The block method's default factor (8 n splits at this size) cannot hold them: it gives up for
+    CAPACITY and is run again with four times the capacity (as much as device memory holds: ~150 000 splits whatever n) -
+    3.8 s at 1024 taxa where the reference's conjugate-gradient route took 80 s and stopped 1.5e-7 short of the Kuhn-Tucker
+    conditions.  Where even the largest factor is too small (16384 taxa of this class: ~330 000 splits) the call returns
+    FNN_ECAPACITY with the reason in the stats instead of running that route for hours; here the capacity is pinned to provoke it."""
+    import time
+    import fastneighbornet_amd as fa
+    import inputs
+    from fastneighbornet_amd._capi import FnnError
+    n = 1024
+    D = inputs.circ_noise(n, 11)
+    order = fa.canonical_order(D)
+    t0 = time.time()
+    w, st = fa.split_weights(D, order)
+    dt = time.time() - t0
+    assert st["method"] == "from below" and st["certified"] == 1 and st["giveup_reason"] == 0, st
+    assert st["capacity"] > 8 * n + 64 and st["nsplits"] > 15 * n, st      # the retry happened, and it was needed
+    assert dt <= 20.0, (dt, st)
+    assert kkt_violation(D, order, w) < 1e-9
+    n2 = 2048
+    D2 = inputs.circ_noise(n2, 12)
+    order2 = fa.canonical_order(D2)
+    monkeypatch.setenv("FNN_SW_CAP", "2")                                   # factor capacity 2 n + 1024 splits, no retry
+    with pytest.raises(FnnError) as ei:
+        fa.split_weights(D2, order2)
+    assert ei.value.code == -6 and "FNN_ECAPACITY" in str(ei.value), ei.value
+    assert ei.value.stats["giveup_reason"] == 1 and ei.value.stats["free_set_peak"] > 0, ei.value.stats
+    monkeypatch.setenv("FNN_SW_REFERENCE_MAX_N", "4096")                    # ... and the reference's route where the caller allows it
+    monkeypatch.setenv("FNN_SW_CAP", "0.05")
+    D3 = inputs.circ_noise(96, 13)
+    order3 = fa.canonical_order(D3)
+    w3, st3 = fa.split_weights(D3, order3)
+    assert st3["method"] == "reference" and st3["giveup_reason"] == 1 and kkt_violation(D3, order3, w3) < 1e-5, st3
