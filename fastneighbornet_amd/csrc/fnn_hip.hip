@@ -394,10 +394,13 @@ __global__ __launch_bounds__(256) void k_emit(Dev d) {
     // some when the live matrix is small): lane l < per fetches one unit's mask; the marked 32 x 8
     // blocks of these units are then dealt out evenly, one block per lane and round (a node with an
     // extreme row sum marks a whole row of blocks in ONE unit)
+    // The units of a step are dealt to the waves ROUND-ROBIN (unit (ustep + lane) nwaves + wave): the units of one row of tiles are
+    // consecutive, and a node with an extreme row sum marks all 64 blocks of every unit of its row - given to one wave as a
+    // contiguous chunk (round 3) that wave walked 4096 blocks in 64 rounds while the others idled: 98 us at 32768 live nodes.
     int per = 4;
     while (per < 64 && per * nwaves < nunits) per <<= 1;
-    for (int ub = wave * per; ub < nunits; ub += nwaves * per) {
-        const int myu = ub + lane;
+    for (int ustep = 0; ustep * nwaves < nunits; ustep += per) {
+        const int myu = (ustep + lane) * nwaves + wave;
         unsigned long long mymask = 0;
         if (lane < per && myu < nunits && (myu >> 2) % d.world == d.rank && d.srec[myu] <= tp) mymask = d.shit[myu];
         int incl = __builtin_popcountll(mymask);
@@ -406,9 +409,11 @@ __global__ __launch_bounds__(256) void k_emit(Dev d) {
             const int o = __shfl_up(incl, off, 64);
             if (lane >= off) incl += o;
         }
+        // (an item is a QUARTER of a marked block - 8 of its 32 rows, one batch of loads: four lanes share a block, so that a wave's
+        //  ~14 blocks keep 56 lanes busy for one round trip instead of 14 lanes for four)
         const int T = __shfl(incl, 63, 64);
-        for (int t0 = 0; t0 < T; t0 += 64) {
-            const int t = t0 + lane;
+        for (int t0 = 0; t0 < 4 * T; t0 += 64) {
+            const int t = (t0 + lane) >> 2, part = (t0 + lane) & 3;
             // owner = first lane whose inclusive prefix exceeds t (binary search over the lanes)
             int lo = 0, hi = 63;
 #pragma unroll
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(256) void k_emit(Dev d) {
             int k = t - (oincl - __builtin_popcountll(omask));  // index of the block among the owner's marked ones
             while (k-- > 0) omask &= omask - 1;
             const int l = __builtin_ctzll(omask);
-            const int u = ub + owner;
+            const int u = (ustep + owner) * nwaves + wave;
             int rt, ct;
             tri_tile_decode(u >> 2, SCR_R, rt, ct);
             const int rbase = rt * SCR_TH, c0 = ct * SCR_TW + (u & 3) * SCR_UW + 8 * l;
@@ -437,10 +442,10 @@ __global__ __launch_bounds__(256) void k_emit(Dev d) {
                 sxc[q + 1] = (float)sv.y;
             }
             const uint16_t* colbase = d.H + c0;
-#pragma unroll 1
-            for (int part = 0; part < SCR_TH / 8; part++) {  // 4 row pairs (8 x 16-byte loads) in flight
+            static_assert(SCR_TH / 8 == 4, "an item is a quarter of a block");
+            {  // 4 row pairs (8 x 16-byte loads) in flight
                 const int rb = rbase + 8 * part;
-                if (rb >= m) break;
+                if (rb >= m) continue;
                 uint4 a[4], b[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
