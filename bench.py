@@ -38,8 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 measured copy rate
-PMC_SUMMARY = os.path.join("profiles", "r03", "r03_pmc_screen_windows_summary_n32768.json")
-ISA_RESOURCES = os.path.join("profiles", "r03", "isa_resources.json")
+PMC_SUMMARY = os.path.join("profiles", "r04", "r04_pmc_screen_windows_summary_n32768.json")
+ISA_RESOURCES = os.path.join("profiles", "r04", "isa_resources.json")
 
 
 def source_sha256():
@@ -121,7 +121,7 @@ def chain_kernel(st, chain, sec):
         return None
     k = chain["kernels"]["k_track"]
     bytes_per_launch = (float(st.bytes_total) - float(st.scan_bytes) - float(st.plain_bytes)) / max(k["launches"], 1)
-    out = {"kernel": "fnn::k_track<false> (the instantiation without the ComputeRx helper workgroups: inputs without exact ties)", "bound": "instruction stream / fan-in latency (one wave's issue rate), not HBM",
+    out = {"kernel": "fnn::k_track<false, false> (the instantiation without the ComputeRx helper workgroups - inputs without exact ties - and without the fused update)", "bound": "instruction stream / fan-in latency (one wave's issue rate), not HBM",
            "launches": k["launches"], "avg_us": k["avg_us"], "share_of_kernel_time": k["share_of_kernel_time"],
            "bytes_per_launch": round(bytes_per_launch, 1),
            "achieved": round(bytes_per_launch / (k["avg_us"] * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -129,7 +129,7 @@ def chain_kernel(st, chain, sec):
     try:
         doc = json.load(open(os.path.join(ROOT, ISA_RESOURCES)))
         if doc.get("fnn_hip_sha256") == source_sha256():
-            r = doc["kernels"]["void fnn::k_track<false>"]
+            r = doc["kernels"]["void fnn::k_track<false, false>"]
             out.update({"vgpr": r["vgpr"], "scratch_bytes_per_lane": r["scratch_bytes_per_lane"], "lds_bytes_per_block": r["lds_bytes_per_block"],
                         "sgpr_spills": r["sgpr_spills"], "vgpr_spills": r["vgpr_spills"], "resources_from": ISA_RESOURCES})
         else:

@@ -65,10 +65,10 @@ typedef struct fnn_opts {
                               error bound, the few 32 x 512 tile units that can hold the minimum; only those are
                               rescanned in fp64 (same result) */
     int32_t lookahead;     /* events one screening pass may serve ("lookahead window"): 0 = default
-                              (min(16 + n / 1024, 64) at most, and min(that, 16 + m / 1024) for a window opened
+                              (min(16 + n / 1024, 64) at most, and min(that, 16 + m / 512) for a window opened
                               with m live nodes: 48 at n = 32768), < 0 = off (every event scans), > 0 = that
                               many (capped at 512); same result either way */
-    int32_t lookahead_pairs;/* wanted number of tracked pairs per window (0 = default 32768) */
+    int32_t lookahead_pairs;/* wanted number of tracked pairs per window (0 = default 49152; the list holds 65536) */
     int32_t mode;          /* FNN_MODE_CANONICAL (0, default) or FNN_MODE_RELAXED: `-mode Relaxed` without `-additive`
                               (FastNN.java:329-338, NeighborNetLocal.java:170-264) - while more than 1024 nodes are
                               active the pair to merge is found by the randomised search for mutual row minima instead

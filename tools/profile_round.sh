@@ -12,10 +12,10 @@ set -o pipefail
 TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd $GRAFT_REPO_ROOT
-python3 bench.py --steps 1 --warmup 1 > $OUT/${TAG}_bench_n32768.json 2> $OUT/${TAG}_bench.err || exit 1
+python3 bench.py --steps 5 --warmup 2 > $OUT/${TAG}_bench_n32768.json 2> $OUT/${TAG}_bench.err || exit 1
 tail -c 600 $OUT/${TAG}_bench_n32768.json; echo
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-chain > $OUT/${TAG}_bench_under_rocprof_n32768.json 2> $OUT/${TAG}_rocprof.err || exit 2
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG} -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-chain --no-config5 > $OUT/${TAG}_bench_under_rocprof_n32768.json 2> $OUT/${TAG}_rocprof.err || exit 2
 find /tmp/prof_${TAG} -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats_n32768.csv \;
 find /tmp/prof_${TAG} -name "*domain_stats.csv" -exec cp {} $OUT/${TAG}_domain_stats_n32768.csv \;
 head -12 $OUT/${TAG}_kernel_stats_n32768.csv | cut -c1-140
