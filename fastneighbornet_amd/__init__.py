@@ -56,8 +56,11 @@ def api() -> _capi.Api:
         a._fn("split_weights_f64", _C.c_int32,
               [_C.POINTER(_C.c_double), _C.c_int32, _C.c_int64, _C.POINTER(_C.c_int32), _C.c_int32,
                _C.POINTER(_C.c_double), _C.POINTER(_capi.FnnSwStats)])
+        a._fn("split_weights_sparse_f64", _C.c_int32,
+              [_C.POINTER(_C.c_double), _C.c_int32, _C.c_int64, _C.POINTER(_C.c_int32), _C.c_int32, _C.c_double,
+               _C.POINTER(_C.c_int64), _C.POINTER(_C.c_double), _C.c_int64, _C.POINTER(_C.c_int64), _C.POINTER(_capi.FnnSwStats)])
         _api = a
     return _api
 
 
-from .canonical import NeighborNetCanonical, NeighborNetLocal, canonical_order, split_weights  # noqa: E402,F401
+from .canonical import NeighborNetCanonical, NeighborNetLocal, canonical_order, split_weights, split_weights_sparse  # noqa: E402,F401

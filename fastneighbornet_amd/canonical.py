@@ -124,3 +124,28 @@ def split_weights(D: np.ndarray, ordering: np.ndarray, device: int = 0, allow_in
     out["refactorizations"] = int(st.reserved[1])
     out["solves"] = int(st.reserved[2])
     return w, out
+
+
+def split_weights_sparse(D: np.ndarray, ordering: np.ndarray, threshold: float = 1e-6, device: int = 0, capacity: int = 0):
+    """`fnn_split_weights_sparse_f64`: only the weights above `threshold` (the reference's list, FastNN.java:455-466), as
+    (indices[k], weights[k]) in ascending live index.  Returns (indices, weights, stats dict)."""
+    from . import api
+    a = api()
+    D = np.ascontiguousarray(D, dtype=np.float64)
+    n = D.shape[0]
+    o = np.ascontiguousarray(ordering, dtype=np.int32)
+    cap = int(capacity) if capacity > 0 else min(n * (n - 1) // 2, max(64 * n, 4096))
+    while True:
+        idx = np.zeros(cap, dtype=np.int64)
+        w = np.zeros(cap, dtype=np.float64)
+        cnt = C.c_int64(0)
+        st = _capi.FnnSwStats()
+        a.check(a.split_weights_sparse_f64(D.ctypes.data_as(C.POINTER(C.c_double)), n, n, o.ctypes.data_as(C.POINTER(C.c_int32)), device,
+                                           float(threshold), idx.ctypes.data_as(C.POINTER(C.c_int64)), w.ctypes.data_as(C.POINTER(C.c_double)),
+                                           cap, C.byref(cnt), C.byref(st)))
+        if cnt.value <= cap:
+            break
+        cap = int(cnt.value)   # (more splits than room: once more with exactly enough)
+    out = {k: getattr(st, k) for k, _ in st._fields_ if not k.startswith(("reserved", "pad_"))}
+    out["method"] = ("closed form", "from below", "reference")[st.route]
+    return idx[:cnt.value], w[:cnt.value], out

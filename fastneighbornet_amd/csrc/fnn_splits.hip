@@ -328,6 +328,21 @@ __global__ __launch_bounds__(T) void k_to_live(const double* x, double* live, in
     live[k] = v;
 }
 
+// the weights above `thr` (live index order, FastNN.java:455), appended in any order: {index, weight}; *count receives their number
+__global__ __launch_bounds__(T) void k_pick_positive(const double* live, int64_t N, double thr, int64_t* idx, double* w, unsigned long long* count, unsigned long long cap) {
+    const int64_t k = (int64_t)blockIdx.x * T + threadIdx.x;
+    const bool take = k < N && live[k] > thr;
+    const unsigned long long ball = __ballot(take);
+    if (ball == 0) return;
+    const int lane = threadIdx.x & 63, first = __ffsll((long long)ball) - 1;
+    unsigned long long base = 0;
+    if (lane == first) base = atomicAdd(count, (unsigned long long)__popcll(ball));
+    base = __shfl(base, first, 64);
+    if (take) {
+        const unsigned long long at = base + __popcll(ball & ((1ULL << lane) - 1ULL));
+        if (at < cap) { idx[at] = k; w[at] = live[k]; }
+    }
+}
 // The solver's own Kuhn-Tucker check of the returned weights (g = A^T (A x - d) from the implicit operators): per workgroup
 // {max -x, max |g| over x > 0, max -g over x <= 0, max |c|} over the strict upper triangle
 __global__ __launch_bounds__(T) void k_kkt(const double* x, const double* g, const double* c, int n, int64_t ld, double* partial) {
@@ -1301,9 +1316,9 @@ struct Solver {
         int64_t k_limit = b.kmax;
         bool ratio_mode = false, done = false, good = ok, fresh = false, banned_rechecked = false;
         const bool revive_on = envd("FNN_SW_REVIVE", 1.0) != 0.0;
-        const int64_t revive_min_f = (int64_t)envd("FNN_SW_REVIVE_MINF", 8192.0);
+        const int64_t revive_min_f = (int64_t)envd("FNN_SW_REVIVE_MINF", 0.0);
         bool revive_blocked = false;   // a step that only brought departed splits back did not descend: not again before a step moves
-        int fail_streak = 0, ratio_left = 0;
+
         auto give = [&](int why, const char* text) { giveup = why; giveup_text = text; good = false; };
         int stall = 0;  // steps in a row whose descent is not measurable (below 1e-13 |objective|)
         const int64_t max_outer = 40 * (int64_t)n + 1000;
@@ -1340,7 +1355,7 @@ struct Solver {
                 const double g = cF[p] - gF[p];
                 if (dead[p]) {
                     wdead = std::max(wdead, g); dead_wanting += g > tol ? 1 : 0;
-                    // (only while the factor is large: below ~8000 splits a rebuild is cheaper than the churn of early returns)
+                    // (FNN_SW_REVIVE_MINF: only from that many splits on - 8192 was tried: 82.2 s instead of 73.0 s at 32768 taxa)
                     if (g > tol && revive_on && !revive_blocked && b.f >= revive_min_f) rev.push_back((int32_t)p);
                 } else drift = std::max(drift, std::fabs(g));
             }
@@ -1477,10 +1492,7 @@ struct Solver {
                     }
                     k_limit = std::max<int64_t>(1, kin / 4);
                 } else {
-                    // the guaranteed step for the retry of this block; block steps again afterwards - unless they keep failing
                     ratio_mode = true; k_limit = kin;
-                    fail_streak++;
-                    ratio_left = fail_streak >= 3 ? 8 : 1;
                 }
                 continue;
             }
@@ -1504,11 +1516,10 @@ struct Solver {
                 }
             }
             k_limit = k_limit > b.kmax / 2 ? b.kmax : 2 * k_limit;
-            // (round 3 kept the guaranteed step on for the rest of the run once few candidates were left: 875 one-split solves in the last
-            //  15 steps of a 32768-taxon solve, 9387 on distances with negative entries.  Now it is on for the retry of a block that did
-            //  not descend and - after three such blocks in a row - for the next eight steps.)
-            if (ratio_mode) { if (--ratio_left <= 0) ratio_mode = false; }
-            else fail_streak = 0;
+            // near the end (few candidates, each displacing one split) the guaranteed step stays on.  (Tried, round 4: the guaranteed step
+            // only for the retry of a block that did not descend, and for eight steps after three such blocks in a row - 75.6 s instead
+            // of 73.0 s at 32768 taxa, 13.9 s instead of 13.4 s at 16384: the method's path is sensitive to such rules, +-10 %.)
+            ratio_mode = ratio_mode && ncand <= 2 * kmin;
             if (moved) revive_blocked = false;
             if (moved) banned_rechecked = false;
             if (moved && !banned.empty()) { set_mask(banned, 0); banned.clear(); }  // progress: the splits set aside may be looked at again
@@ -1575,10 +1586,12 @@ struct Solver {
 
 }  // namespace fnnsw
 
-extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD, const int32_t* ordering, int32_t device,
-                                         double* weights_out, fnn_sw_stats* stats) {
+// weights_out != nullptr: all n (n - 1) / 2 weights; else the weights above `thr` as (index, weight) pairs in index order
+static int32_t split_weights_impl(const double* D, int32_t n, int64_t ldD, const int32_t* ordering, int32_t device, double* weights_out,
+                                  double thr, int64_t* idx_out, double* w_out, int64_t cap_out, int64_t* count_out, fnn_sw_stats* stats) {
     using namespace fnnsw;
-    if (!D || !ordering || !weights_out || n < 2 || ldD < n) return fnn::fail(FNN_EINVAL, "fnn_split_weights_f64: bad arguments");
+    if (!D || !ordering || n < 2 || ldD < n || (!weights_out && (!idx_out || !w_out || !count_out || cap_out < 0)))
+        return fnn::fail(FNN_EINVAL, "fnn_split_weights_f64: bad arguments");
     {
         std::vector<char> seen((size_t)n + 1, 0);
         for (int i = 1; i <= n; i++) {
@@ -1708,8 +1721,40 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
     const double scale = kk[3] > 0.0 ? kk[3] : 1.0;
     const double viol = std::max({kk[0], kk[1] / scale, kk[2] / scale});
     const bool certified = viol <= 1e-9;  // (NaN compares false)
-    if (!SWOK(hipMemcpy(weights_out, S.live, sizeof(double) * (size_t)n * (n - 1) / 2, hipMemcpyDeviceToHost)))
-        return fnn::fail(FNN_EHIP, "fnn_split_weights_f64: download failed");
+    // what goes back to the host: every weight, or only those above the threshold (the reference keeps x[k] > 1e-6, FastNN.java:455:
+    // 77 000 of 5.4e8 weights at 32768 taxa - the dense array is 4.3 GB over the bus and a host pass over it)
+    const int64_t Nw = (int64_t)n * (n - 1) / 2;
+    int64_t npos = 0;
+    {
+        unsigned long long* dcount = S.alloc<unsigned long long>(1);
+        const int64_t pcap = weights_out ? 0 : cap_out;
+        int64_t* didx = S.alloc<int64_t>((size_t)std::max<int64_t>(pcap, 1));
+        double* dw = S.alloc<double>((size_t)std::max<int64_t>(pcap, 1));
+        if (!S.ok) return fnn::fail(FNN_ENOMEM, "fnn_split_weights_f64: device allocation failed");
+        (void)hipMemsetAsync(dcount, 0, sizeof(unsigned long long), S.s);
+        hipLaunchKernelGGL(k_pick_positive, dim3((unsigned)((Nw + T - 1) / T)), dim3(T), 0, S.s, S.live, Nw, weights_out ? 0.000001 : thr, didx, dw, dcount,
+                           (unsigned long long)pcap);
+        unsigned long long c = 0;
+        if (!SWOK(hipMemcpyAsync(&c, dcount, sizeof(c), hipMemcpyDeviceToHost, S.s)) || !SWOK(hipStreamSynchronize(S.s)))
+            return fnn::fail(FNN_EHIP, "fnn_split_weights_f64: download failed");
+        npos = (int64_t)c;
+        if (weights_out) {
+            if (!SWOK(hipMemcpy(weights_out, S.live, sizeof(double) * (size_t)Nw, hipMemcpyDeviceToHost)))
+                return fnn::fail(FNN_EHIP, "fnn_split_weights_f64: download failed");
+        } else {
+            *count_out = npos;
+            const int64_t take = std::min(npos, cap_out);
+            std::vector<int64_t> hi((size_t)take);
+            std::vector<double> hw((size_t)take);
+            if (take > 0 && (!SWOK(hipMemcpy(hi.data(), didx, sizeof(int64_t) * (size_t)take, hipMemcpyDeviceToHost)) ||
+                             !SWOK(hipMemcpy(hw.data(), dw, sizeof(double) * (size_t)take, hipMemcpyDeviceToHost))))
+                return fnn::fail(FNN_EHIP, "fnn_split_weights_f64: download failed");
+            std::vector<int64_t> perm((size_t)take);
+            for (int64_t q = 0; q < take; q++) perm[(size_t)q] = q;
+            std::sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return hi[(size_t)a] < hi[(size_t)b]; });  // the reference's list order
+            for (int64_t q = 0; q < take; q++) { idx_out[q] = hi[(size_t)perm[(size_t)q]]; w_out[q] = hw[(size_t)perm[(size_t)q]]; }
+        }
+    }
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         const bool from_below = route == FNN_SW_ROUTE_FROM_BELOW;
@@ -1720,9 +1765,7 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
         stats->reserved[1] = S.st_lh_refactor;
         stats->reserved[2] = S.st_solves;               // sub-problems solved (from below)
         stats->t_solve_s = ms * 1e-3;
-        int64_t pos = 0;
-        for (int64_t k = 0; k < (int64_t)n * (n - 1) / 2; k++) pos += weights_out[k] > 0.000001 ? 1 : 0;  // FastNN.java:455 threshold
-        stats->nsplits = pos;
+        stats->nsplits = npos;                          // weights above the threshold (FastNN.java:455: 1e-6; the sparse call: its own)
         stats->route = route;
         stats->certified = certified ? 1 : 0;
         stats->kkt_violation = viol;
@@ -1743,4 +1786,14 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
         return fnn::fail(FNN_EINEXACT, buf);
     }
     return FNN_OK;
+}
+
+extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD, const int32_t* ordering, int32_t device,
+                                         double* weights_out, fnn_sw_stats* stats) {
+    if (!weights_out) return fnn::fail(FNN_EINVAL, "fnn_split_weights_f64: bad arguments");
+    return split_weights_impl(D, n, ldD, ordering, device, weights_out, 0.0, nullptr, nullptr, 0, nullptr, stats);
+}
+extern "C" int32_t fnn_split_weights_sparse_f64(const double* D, int32_t n, int64_t ldD, const int32_t* ordering, int32_t device, double threshold,
+                                                int64_t* index_out, double* weight_out, int64_t capacity, int64_t* count_out, fnn_sw_stats* stats) {
+    return split_weights_impl(D, n, ldD, ordering, device, nullptr, threshold, index_out, weight_out, capacity, count_out, stats);
 }

@@ -289,3 +289,19 @@ def test_gpu_split_weights_nearly_circular_inputs_and_the_capacity_status(hip_ap
     order3 = fa.canonical_order(D3)
     w3, st3 = fa.split_weights(D3, order3)
     assert st3["method"] == "reference" and st3["giveup_reason"] == 1 and kkt_violation(D3, order3, w3) < 1e-5, st3
+
+
+@pytest.mark.gpu
+def test_gpu_sparse_output_equals_the_dense_one(hip_api, oracle):
+    """fnn_split_weights_sparse_f64 returns exactly the entries of the dense result above the threshold, in the order of the
+    reference's list (ascending live index, FastNN.java:455-466) - also when the first call's room was too small."""
+    import fastneighbornet_amd as fa
+    for n, seed in [(9, 2), (257, 6), (1500, 7)]:
+        D = oracle.synth(n, seed)
+        order = fa.canonical_order(D)
+        dense, st = fa.split_weights(D, order)
+        for thr, cap in [(1e-6, 0), (0.01, 0), (1e-6, 3)]:
+            idx, w, st2 = fa.split_weights_sparse(D, order, threshold=thr, capacity=cap)
+            want = np.nonzero(dense > thr)[0]
+            assert (idx == want).all() and (w == dense[want]).all(), (n, thr, cap)
+            assert st2["nsplits"] == len(want) and st2["certified"] == 1
