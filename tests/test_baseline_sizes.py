@@ -28,7 +28,10 @@ TRAJ_FIELDS = ["m_before", "c_before", "cx_id", "cy_id", "x_id", "y_id", "kind",
 BIG_CASES = [(4096, "uniform53", 1), (4096, "dec4", 1), (16384, "uniform53", 1), (32768, "uniform53", 1),
              (4096, "uniform53", 2), (4096, "uniform53", 3), (4096, "tree", 5), (4096, "treenoise", 6), (4096, "neg", 1),
              (8192, "tree", 7), (8192, "treenoise", 8), (8192, "neg", 2), (16384, "uniform53", 2), (16384, "uniform53", 3),
-             (16384, "tree", 9), (16384, "treenoise", 10), (16384, "neg", 3)]
+             (16384, "tree", 9), (16384, "treenoise", 10), (16384, "neg", 3),
+             # round 4: nearly circular distances (a circular metric with 1 % noise, tests/inputs.py: circ_noise - the class whose split
+             # weights outgrow the solver's default factor) and the 4-decimal generator at 16384 taxa
+             (4096, "circnoise", 11), (8192, "circnoise", 12), (16384, "dec4", 1)]
 
 
 
