@@ -56,6 +56,7 @@ def api() -> _capi.Api:
         a._fn("split_weights_f64", _C.c_int32,
               [_C.POINTER(_C.c_double), _C.c_int32, _C.c_int64, _C.POINTER(_C.c_int32), _C.c_int32,
                _C.POINTER(_C.c_double), _C.POINTER(_capi.FnnSwStats)])
+        a._fn("split_weights_release_cache", _C.c_int32, [])
         a._fn("split_weights_sparse_f64", _C.c_int32,
               [_C.POINTER(_C.c_double), _C.c_int32, _C.c_int64, _C.POINTER(_C.c_int32), _C.c_int32, _C.c_double,
                _C.POINTER(_C.c_int64), _C.POINTER(_C.c_double), _C.c_int64, _C.POINTER(_C.c_int64), _C.POINTER(_capi.FnnSwStats)])

@@ -3331,7 +3331,12 @@ struct HipBackend {
     void* alloc(size_t b) {
         void* p = nullptr;
         (void)hipSetDevice(device);
-        if (!HIPOK(hipMalloc(&p, b ? b : 8))) return nullptr;
+        if (!HIPOK(hipMalloc(&p, b ? b : 8))) {
+            // the split-weight solver keeps its large buffers in a pool between calls (fnn_splits.hip): give them back and try again
+            (void)hipGetLastError();
+            (void)fnn_split_weights_release_cache();
+            if (!HIPOK(hipMalloc(&p, b ? b : 8))) return nullptr;
+        }
         return p;
     }
     void free(void* p) {

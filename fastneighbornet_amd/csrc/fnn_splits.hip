@@ -35,6 +35,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -666,12 +667,49 @@ __global__ __launch_bounds__(T) void k_idx_to_split(const int64_t* idx, int64_t 
     if (p < cnt) out[p] = make_int2((int)(idx[p] / ld), (int)(idx[p] % ld));
 }
 
+// ---------------------------------------------------------------- device buffers kept between calls
+// hipMalloc of the solver's ~220 GB costs 0.5-4.8 s from box to box (page tables: `fnn_sw_stats.t_alloc_s`).  Buffers of >= 64 MiB
+// go back to a per-process pool instead of the driver and are handed out again to a request of exactly that size on that
+// device (a second solve of the same n: every one of them); a failed hipMalloc - or a caller who wants the memory,
+// fnn_split_weights_release_cache - empties the pool.  The pool's bytes count as free when the factor is sized.
+struct BufferPool {
+    struct Item { void* p; size_t bytes; int dev; };
+    std::vector<Item> items;
+    std::mutex mu;
+    static constexpr size_t kMin = (size_t)64 << 20;
+    void* take(size_t bytes, int dev) {
+        std::lock_guard<std::mutex> g(mu);
+        for (size_t i = 0; i < items.size(); i++)
+            if (items[i].bytes == bytes && items[i].dev == dev) { void* p = items[i].p; items.erase(items.begin() + (long)i); return p; }
+        return nullptr;
+    }
+    void give(void* p, size_t bytes, int dev) {
+        if (bytes < kMin) { (void)hipFree(p); return; }
+        std::lock_guard<std::mutex> g(mu);
+        items.push_back(Item{p, bytes, dev});
+    }
+    size_t pooled(int dev) {
+        std::lock_guard<std::mutex> g(mu);
+        size_t t = 0;
+        for (const Item& it : items) if (it.dev == dev) t += it.bytes;
+        return t;
+    }
+    void flush() {
+        std::lock_guard<std::mutex> g(mu);
+        for (const Item& it : items) (void)hipFree(it.p);
+        items.clear();
+    }
+};
+inline BufferPool& pool() { static BufferPool* p = new BufferPool; return *p; }  // (never destroyed: no hipFree after the runtime has gone)
+
 // ---------------------------------------------------------------- host driver
 struct Solver {
     int n = 0;
     int64_t ld = 0;
     hipStream_t s = nullptr;
     std::vector<void*> allocs;
+    std::vector<size_t> alloc_bytes;  // (parallel to allocs)
+    int dev = 0;
     double *d = nullptr, *x = nullptr, *r = nullptr, *w = nullptr, *p = nullptr, *y = nullptr, *old_x = nullptr, *atwd = nullptr;
     double *P = nullptr, *Pt = nullptr, *rs = nullptr, *partial = nullptr, *live = nullptr, *Dm = nullptr, *sc = nullptr;
     int32_t* ord = nullptr;
@@ -683,25 +721,32 @@ struct Solver {
 
     template <class Tp>
     Tp* alloc(size_t count) {
-        void* p_ = nullptr;
-        if (!SWOK(hipMalloc(&p_, sizeof(Tp) * (count ? count : 1)))) { ok = false; return nullptr; }
+        const size_t bytes = sizeof(Tp) * (count ? count : 1);
+        void* p_ = pool().take(bytes, dev);
+        if (!p_ && !SWOK(hipMalloc(&p_, bytes))) {
+            (void)hipGetLastError();
+            pool().flush();  // (what the pool holds may be what is missing)
+            if (!SWOK(hipMalloc(&p_, bytes))) { ok = false; return nullptr; }
+        }
         allocs.push_back(p_);
+        alloc_bytes.push_back(bytes);
         return (Tp*)p_;
     }
     void release(void* p_) {  // one allocation back to the device (after the work queued on it)
         (void)hipStreamSynchronize(s);
         for (size_t i = 0; i < allocs.size(); i++)
-            if (allocs[i] == p_) { (void)hipFree(p_); allocs.erase(allocs.begin() + (long)i); return; }
+            if (allocs[i] == p_) { pool().give(p_, alloc_bytes[i], dev); allocs.erase(allocs.begin() + (long)i); alloc_bytes.erase(alloc_bytes.begin() + (long)i); return; }
     }
     size_t block_mark = SIZE_MAX;  // allocs[block_mark ..) belong to the block active-set method
     void release_block_buffers() {
         (void)hipStreamSynchronize(s);
         if (block_mark == SIZE_MAX) return;
-        while (allocs.size() > block_mark) { (void)hipFree(allocs.back()); allocs.pop_back(); }
+        while (allocs.size() > block_mark) { pool().give(allocs.back(), alloc_bytes.back(), dev); allocs.pop_back(); alloc_bytes.pop_back(); }
         ok = true;
     }
     ~Solver() {
-        for (void* p_ : allocs) (void)hipFree(p_);
+        if (s) (void)hipStreamSynchronize(s);
+        for (size_t i = 0; i < allocs.size(); i++) pool().give(allocs[i], alloc_bytes[i], dev);
         if (s) (void)hipStreamDestroy(s);
     }
     // 2-D inclusive prefix of src (upper triangle, zeros elsewhere) -> Pt (transposed)
@@ -983,6 +1028,7 @@ struct Solver {
         };
         size_t free_b = 0, total_b = 0;
         if (!SWOK(hipMemGetInfo(&free_b, &total_b))) free_b = 0;
+        free_b += pool().pooled(dev);  // (handed out again to this very call, or flushed if the sizes differ)
         const double budget = 0.92 * (double)free_b;
         const double want = envd("FNN_SW_CAP", 0.0);
         // {capacity / n, block = capacity / kdiv, departed columns = capacity / rdiv}: the roomy shapes first; where memory is
@@ -1607,6 +1653,7 @@ static int32_t split_weights_impl(const double* D, int32_t n, int64_t ldD, const
         ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
     } ev;
     Solver S;
+    S.dev = device;
     S.n = n;
     S.ld = ((int64_t)n + 31) / 32 * 32 + 32;
     if (!SWOK(hipStreamCreateWithFlags(&S.s, hipStreamNonBlocking))) return fnn::fail(FNN_EHIP, "hipStreamCreate failed");
@@ -1657,6 +1704,7 @@ static int32_t split_weights_impl(const double* D, int32_t n, int64_t ldD, const
                 S.cap_want = std::min<int64_t>(Nall, 4 * prev);
                 size_t fb = 0, tb = 0;
                 if (hipMemGetInfo(&fb, &tb) != hipSuccess) break;
+                fb += pool().pooled(device);
                 // (the largest factor that can fit at all: cap^2 * 8 B * 9/16 for the factor alone)
                 const int64_t hard = (int64_t)std::sqrt(0.9 * (double)fb / (8.0 * 0.62 * 1.7));
                 if (S.cap_want > hard) S.cap_want = hard;
@@ -1792,6 +1840,10 @@ extern "C" int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ldD
                                          double* weights_out, fnn_sw_stats* stats) {
     if (!weights_out) return fnn::fail(FNN_EINVAL, "fnn_split_weights_f64: bad arguments");
     return split_weights_impl(D, n, ldD, ordering, device, weights_out, 0.0, nullptr, nullptr, 0, nullptr, stats);
+}
+extern "C" int32_t fnn_split_weights_release_cache(void) {
+    fnnsw::pool().flush();
+    return FNN_OK;
 }
 extern "C" int32_t fnn_split_weights_sparse_f64(const double* D, int32_t n, int64_t ldD, const int32_t* ordering, int32_t device, double threshold,
                                                 int64_t* index_out, double* weight_out, int64_t capacity, int64_t* count_out, fnn_sw_stats* stats) {

@@ -313,6 +313,10 @@ int32_t fnn_split_weights_f64(const double* D, int32_t n, int64_t ld, const int3
  * 77 000 pairs instead of 5.4e8 doubles (4.3 GB) over the bus.  FNN_EINEXACT / FNN_ECAPACITY as above. */
 int32_t fnn_split_weights_sparse_f64(const double* D, int32_t n, int64_t ld, const int32_t* ordering, int32_t device, double threshold,
                                      int64_t* index_out, double* weight_out, int64_t capacity, int64_t* count_out, fnn_sw_stats* stats);
+/* The solver keeps its large device buffers (>= 64 MiB each, ~220 GB at 32768 taxa) in a per-process pool between calls - hipMalloc of
+ * them costs 0.5-4.8 s - and hands them out again to a later call of the same size; this call gives them back to the driver.  (The
+ * pool is also emptied when a device allocation of the solver fails; the order engine's own 10 GiB at 32768 taxa fit beside it.) */
+int32_t fnn_split_weights_release_cache(void);
 
 /* Diagnostic: the exact block-parallel evaluation of the sequential fp64 sum
  * (((0 + b[0]) + b[1]) + ...) used for ComputeRx / u.Sx (NetMakerOriginal.java:551-560,

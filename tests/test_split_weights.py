@@ -305,3 +305,20 @@ def test_gpu_sparse_output_equals_the_dense_one(hip_api, oracle):
             want = np.nonzero(dense > thr)[0]
             assert (idx == want).all() and (w == dense[want]).all(), (n, thr, cap)
             assert st2["nsplits"] == len(want) and st2["certified"] == 1
+
+
+@pytest.mark.gpu
+def test_gpu_buffer_pool_between_calls(hip_api, oracle):
+    """The solver's large device buffers stay in a per-process pool between calls (hipMalloc of ~220 GB costs 0.5-4.8 s at 32768
+    taxa): a second solve of the same size allocates next to nothing, gives bit-identical weights on the recycled (dirty) buffers,
+    and fnn_split_weights_release_cache hands the memory back."""
+    import fastneighbornet_amd as fa
+    D = oracle.synth(3000, 5)
+    order = fa.canonical_order(D)
+    w1, st1 = fa.split_weights(D, order)
+    w2, st2 = fa.split_weights(D, order)
+    assert (w1.view(np.int64) == w2.view(np.int64)).all()
+    assert st2["t_alloc_s"] < 0.05, (st1["t_alloc_s"], st2["t_alloc_s"])
+    assert fa.api().split_weights_release_cache() == 0
+    w3, st3 = fa.split_weights(D, order)
+    assert (w1.view(np.int64) == w3.view(np.int64)).all()
