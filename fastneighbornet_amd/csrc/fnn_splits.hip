@@ -866,7 +866,7 @@ struct Solver {
     }
 
     // ------------------------------------------------------------ block active-set method (see the comment above h_entry)
-    int64_t st_lh_steps = 0, st_lh_refactor = 0, st_solves = 0, st_adds = 0, st_dels = 0, st_rejects = 0, st_ratio_steps = 0, st_screened = 0, st_dead_wanting = 0, st_revived = 0;
+    int64_t st_lh_steps = 0, st_lh_refactor = 0, st_solves = 0, st_adds = 0, st_dels = 0, st_rejects = 0, st_ratio_steps = 0, st_screened = 0, st_dead_wanting = 0, st_revived = 0, st_dels_new = 0;
     double t_ops = 0, t_sel = 0, t_append = 0, t_solve = 0, t_dead = 0, t_refactor = 0;  // host wall clock per phase (FNN_SW_LOG)
     struct Blk {
         rocblas_handle bh = nullptr;
@@ -1345,6 +1345,7 @@ struct Solver {
         std::vector<double> sbuf;
         // every weight that is not positive leaves, until the sub-problem's minimiser is feasible (false: out of room / failure)
         bool over_rcap = false;  // settle_all failed for lack of room for the departed columns (not a numerical failure)
+        int64_t f_step0 = 0;     // (statistics: factor size before this step's block entered)
         auto settle_all = [&]() -> bool {
             over_rcap = false;
             for (;;) {
@@ -1354,6 +1355,7 @@ struct Solver {
                 if (out.empty()) return true;
                 if (b.r + (int64_t)out.size() > b.rcap) { over_rcap = true; return false; }
                 st_dels += (int64_t)out.size();
+                for (int32_t p : out) st_dels_new += p >= f_step0 ? 1 : 0;
                 if (!depart(out)) return false;
             }
         };
@@ -1370,6 +1372,7 @@ struct Solver {
         const int64_t max_outer = 40 * (int64_t)n + 1000;
         while (good && !done && st_lh_steps < max_outer) {
             st_lh_steps++;
+            f_step0 = INT64_MAX;
             // ---- multipliers: r = c - A^T A x on the grid; the entries at the factor's splits go to the host
             double t0 = log ? wall() : 0.0;
             (void)hipMemsetAsync(this->x, 0, sizeof(double) * (size_t)n * (size_t)ld, s);
@@ -1430,6 +1433,7 @@ struct Solver {
             }
             // ---- the block: the largest local maxima of the multiplier (none: a step that only brings departed splits back)
             const int64_t f0 = b.f, r0 = b.r;
+            f_step0 = f0;
             const std::vector<uint8_t> dead0 = dead;
             const std::vector<double> x0 = xw;
             const std::vector<int32_t> deadlist0 = deadlist;
@@ -1491,6 +1495,7 @@ struct Solver {
                     }
                     if (b.r + (int64_t)out.size() > b.rcap) { feasible = false; break; }
                     st_dels += (int64_t)out.size();
+                    for (int32_t p : out) st_dels_new += p >= f_step0 ? 1 : 0;
                     if (!depart(out)) { feasible = false; break; }
                 }
             }
@@ -1589,8 +1594,8 @@ struct Solver {
                               "sel %.2f append %.2f solve %.2f depart %.2f refactor %.2f s\n", good ? "done" : "gave up", (long long)st_lh_steps, (long long)st_solves,
                               (long long)st_adds, (long long)st_screened, (long long)st_dels, (long long)st_rejects, (long long)st_ratio_steps, (long long)st_lh_refactor, (long long)(b.f - b.r),
                               t_ops, t_sel, t_append, t_solve, t_dead, t_refactor);
-        if (log) std::fprintf(stderr, "  [sw]   GEMM work through gemm(): %.3e flop; departed splits with a positive multiplier, summed over the steps: %lld; brought back: %lld\n",
-                              gemm_flops, (long long)st_dead_wanting, (long long)st_revived);
+        if (log) std::fprintf(stderr, "  [sw]   GEMM work through gemm(): %.3e flop; departed splits with a positive multiplier, summed over the steps: %lld; brought back: %lld; "
+                              "departures of splits in the step they entered: %lld\n", gemm_flops, (long long)st_dead_wanting, (long long)st_revived, (long long)st_dels_new);
         if (log) for (const auto& kv : tsub) std::fprintf(stderr, "  [sw]   %-28s %8.3f s\n", kv.first.c_str(), kv.second);
         return good;
     }
