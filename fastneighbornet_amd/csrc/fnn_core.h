@@ -257,6 +257,7 @@ struct Dev {
     int32_t strict;       // non-zero (several ranks): a window event that gives up for a reason other ranks cannot see - a record of
                           // k_track's fan-in that could not be read back - is an ERROR: the ranks must take identical decisions
     int32_t fault_event;  // test hook (FNN_FAULT_GIVEUP=rank:event, -1 = none): this rank's window gives that event up
+    int32_t plan_ticks;   // diagnostic (FNN_TICKS=1): decide_plan stamps its stages into ticks[20 .. 23]
     // Relaxed mode: NeighborNetLocal.rowPermutation (positions), and the per-call HashMap foundRowMinimums as per-slot
     // entries {stamp == n_events + 1 of the call, value, number of tied rows, their slots in position order}
     int32_t* rperm;
@@ -1527,10 +1528,19 @@ struct RlSerialEnv {
 // handleAgglomerationEvent: candidate choice (:422-452), bookkeeping of the merge
 // (:462-488) and the micro-op plan for the matrix.  rx = {Rx(Cx), Rx(Cx.nbr),
 // Rx(Cy), Rx(Cy.nbr)}, 0.0 where the reference leaves the 0.0 initialiser.
+// (diagnostic, FNN_TICKS=1 on the GPU: 100 MHz stamps of the plan's stages into Dev::ticks[20 .. 23]; nothing elsewhere)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FNN_PLAN_TICK(k) do { if (d.plan_ticks && (threadIdx.x & 63) == 0) { const long long now_ = (long long)wall_clock64(); d.ticks[20 + (k)] += now_ - ptk_; ptk_ = now_; } } while (0)
+#define FNN_PLAN_TICK0() long long ptk_ = d.plan_ticks ? (long long)wall_clock64() : 0
+#else
+#define FNN_PLAN_TICK(k) do { } while (0)
+#define FNN_PLAN_TICK0() do { } while (0)
+#endif
 template <class Tab>
 FNN_HD void decide_plan(const Dev& d, Tab& T, const Quad& qd, const double rx[4]) {
     State& st = *d.st;
     Event& cur = st.cur;
+    FNN_PLAN_TICK0();
     int32_t a = st.sa, ap = st.sap, b = st.sb, bp = st.sbp;
     double q[4], fd[4];
     bool ok[4];
@@ -1544,10 +1554,12 @@ FNN_HD void decide_plan(const Dev& d, Tab& T, const Quad& qd, const double rx[4]
     int32_t xn = x < twoP ? (x ^ 1) : -1;
     int32_t yn = y < twoP ? (y ^ 1) : -1;
     st.xs = x; st.ys = y;
+    FNN_PLAN_TICK(0);  // the candidates' values and the choice
     const int32_t idx = T.sid(x), idy = T.sid(y);
     cur.x_id = idx;
     cur.y_id = idy;
     int32_t m = st.m, P = st.P, nn = st.num_nodes;
+    FNN_PLAN_TICK(1);  // the chosen nodes' ids, the counters
 
     if (xn < 0 && yn < 0) {
         // agg2way (:570-577): both isolated. New two-node cluster goes to slots 2P, 2P+1,
@@ -1564,7 +1576,9 @@ FNN_HD void decide_plan(const Dev& d, Tab& T, const Quad& qd, const double rx[4]
         st.U = t0;  // u = x, and x always has the smaller id (Cx.id < Cy.id, :376-380)
         // slot t0 now holds the smaller id, t1 the larger one
         if ((idx < idy ? idx : idy) != cur.u_id) st.error = 3;
+        FNN_PLAN_TICK(2);  // the slot operations
         la_note_cluster(d, st, idx < idy ? idx : idy, idx < idy ? idy : idx);
+        FNN_PLAN_TICK(3);
     } else if (xn < 0 || yn < 0) {
         // agg3way(x, y, y.nbr) (:466) or agg3way(y, x, x.nbr) (:476)
         cur.kind = KIND_3WAY;
@@ -1579,7 +1593,9 @@ FNN_HD void decide_plan(const Dev& d, Tab& T, const Quad& qd, const double rx[4]
         st.m = m - 1;
         st.c -= 1;
         st.U = 2 * k;
+        FNN_PLAN_TICK(2);
         la_note_cluster(d, st, nn + 1, nn + 2);
+        FNN_PLAN_TICK(3);
     } else {
         if (m == 4) st.error = 4;  // (:474) unreachable: m == 4 with two pairs is the special finish
         // agg4way(x.nbr, x, y, y.nbr) (:484, :707-726): two agg3way calls
@@ -1606,7 +1622,9 @@ FNN_HD void decide_plan(const Dev& d, Tab& T, const Quad& qd, const double rx[4]
         st.m = m - 2;
         st.c -= 1;
         st.U = U;
+        FNN_PLAN_TICK(2);
         la_note_cluster(d, st, nn + 3, nn + 4);
+        FNN_PLAN_TICK(3);
     }
 }
 

@@ -278,6 +278,7 @@ class Engine {
             dev.wx = (comm_mode != 0 && hst.la_on) ? 1 : 0;
             dev.strict = dev.wx;
             dev.fault_event = -1;
+            dev.plan_ticks = std::getenv("FNN_TICKS") ? 1 : 0;
             if (const char* e = std::getenv("FNN_FAULT_GIVEUP")) {  // test hook: "rank:event"
                 int fr = -1, fe = -1;
                 if (std::sscanf(e, "%d:%d", &fr, &fe) == 2 && fr == rank) dev.fault_event = fe;

@@ -3754,6 +3754,12 @@ int32_t fnn_debug_decide_ticks(fnn_handle* h, int64_t* out4) {
     if (h->eng.be.d2h(out4, h->eng.dev.ticks + 16, sizeof(int64_t) * 4) != FNN_OK) return FNN_EHIP;
     return FNN_OK;
 }
+int32_t fnn_debug_plan_ticks(fnn_handle* h, int64_t* out4) {
+    FNN_NEED(h);
+    if (!out4) return fnn::fail(FNN_EINVAL, "fnn_debug_plan_ticks: out4 is NULL");
+    if (h->eng.be.d2h(out4, h->eng.dev.ticks + 20, sizeof(int64_t) * 4) != FNN_OK) return FNN_EHIP;
+    return FNN_OK;
+}
 int32_t fnn_set_scan_timing(fnn_handle* h, int32_t enable) {
     FNN_NEED(h);
     h->eng.be.timing = enable < 0 ? 0 : (enable > 2 ? 2 : enable);

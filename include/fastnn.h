@@ -206,6 +206,9 @@ int32_t fnn_debug_update_ticks(fnn_handle* h, int64_t* out8);
 /* ... and the decide step inside k_track's tail: {the one round trip of loads, Cx/Cy + certified choice, merge plan,
  * symbolic replay of the micro-ops}. */
 int32_t fnn_debug_decide_ticks(fnn_handle* h, int64_t* out4);
+/* ... and inside the merge plan (wave 0; all decide steps of the run, k_decide's included): {the <= 4 candidates' values and the choice,
+ * the chosen nodes' ids, the slot operations of the merge (swaps / agg3way plans / moves), the window's bookkeeping for the new cluster}. */
+int32_t fnn_debug_plan_ticks(fnn_handle* h, int64_t* out4);
 /* Relaxed mode, FNN_TICKS=1: 100 MHz ticks summed over the run in {the workgroup's row-minimum passes, their finish by
  * the control lane, the whole search kernels}, and the number of row minima computed. */
 int32_t fnn_debug_relaxed_ticks(fnn_handle* h, int64_t* out4);

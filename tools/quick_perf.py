@@ -32,6 +32,11 @@ for n in sizes:
         if st.n_window_hits:
             print("  decide step in the tail: " + " ".join(f"{nm}={tk[i] / 100.0 / st.n_window_hits:.2f}" for i, nm in
                   enumerate(["loads", "pick+choice", "plan", "replay"])), flush=True)
+        a._fn("debug_plan_ticks", C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)])
+        a.debug_plan_ticks(h._h, tk)
+        if st.n_events and tk[0]:
+            print("  merge plan (all decide steps): " + " ".join(f"{nm}={tk[i] / 100.0 / st.n_events:.2f}" for i, nm in
+                  enumerate(["candidates+choice", "ids+counters", "slot_operations", "window_bookkeeping"])), flush=True)
         a._fn("debug_update_ticks", C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)])
         a.debug_update_ticks(h._h, tk)
         if tk[0] or tk[4]:
