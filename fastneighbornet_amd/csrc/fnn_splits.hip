@@ -372,6 +372,13 @@ __global__ __launch_bounds__(T) void k_kkt(const double* x, const double* g, con
         partial[4 * (blockIdx.y * gridDim.x + blockIdx.x) + threadIdx.x] = m;
     }
 }
+// test hook (FNN_SW_FAULT_PERTURB=1): the first positive weight of the grid is doubled, so that the call's own check has something to find
+__global__ void k_fault_perturb(double* x, int n, int64_t ld) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < n; i++)
+        for (int j = i + 1; j < n; j++)
+            if (x[(int64_t)i * ld + j] > 0.0) { x[(int64_t)i * ld + j] *= 2.0; return; }
+}
 // a = a - c over the strict upper triangle
 __global__ __launch_bounds__(T) void k_sub(double* a, const double* c, int n, int64_t ld) {
     const int j = blockIdx.x * T + threadIdx.x, i = blockIdx.y;
@@ -1753,6 +1760,7 @@ static int32_t split_weights_impl(const double* D, int32_t n, int64_t ldD, const
             S.have_atwd = true;
         }
     }
+    if (std::getenv("FNN_SW_FAULT_PERTURB")) hipLaunchKernelGGL(k_fault_perturb, dim3(1), dim3(1), 0, S.s, S.x, n, S.ld);
     hipLaunchKernelGGL(k_to_live, S.grid2, dim3(T), 0, S.s, S.x, S.live, n, S.ld);
     (void)hipEventRecord(ev.e1, S.s);
     // The solver's own Kuhn-Tucker check of what it returns: g = A^T (A x - d) from the implicit operators, which share

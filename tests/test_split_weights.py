@@ -322,3 +322,22 @@ def test_gpu_buffer_pool_between_calls(hip_api, oracle):
     assert fa.api().split_weights_release_cache() == 0
     w3, st3 = fa.split_weights(D, order)
     assert (w1.view(np.int64) == w3.view(np.int64)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_split_weights_report_a_result_that_fails_their_own_check(hip_api, oracle, monkeypatch):
+    """FNN_EINEXACT: the call checks what it returns (g = A^T (A x - d) from the implicit operators) and does not claim the optimum for
+    weights that fail - here provoked by a test hook that doubles one weight behind the solver's back."""
+    import fastneighbornet_amd as fa
+    from fastneighbornet_amd._capi import FnnError
+    D = oracle.synth(200, 4)
+    order = fa.canonical_order(D)
+    good, st = fa.split_weights(D, order)
+    assert st["certified"] == 1
+    monkeypatch.setenv("FNN_SW_FAULT_PERTURB", "1")
+    with pytest.raises(FnnError) as ei:
+        fa.split_weights(D, order)
+    assert ei.value.code == -7 and "Kuhn-Tucker" in str(ei.value)
+    w, st2 = fa.split_weights(D, order, allow_inexact=True)       # the weights are there for a caller who wants them anyway
+    assert st2["certified"] == 0 and st2["kkt_violation"] > 1e-9
+    assert int((w != good).sum()) == 1
