@@ -1,11 +1,14 @@
+#!/bin/bash
+# Development aid: policy variants of the split-weight solver on ONE box in ONE call (the method's path is sensitive to its rules and
+# boxes differ by a few per cent, so variants are only comparable this way).  profiles/r04/r04_splits_policy_ab.md holds round 4's table
+# (its variant C - the ratio step only for the retry of a block - was removed from the code after that measurement).
 run() { # name env...
   name=$1; shift
-  env "$@" FNN_SW_LOG=1 timeout -k 10 200 python tests/tools/splits_perf.py $N > gpurun_out/r4_ab2_${name}_$N.log 2>&1 || return 1
-  grep "^n=" gpurun_out/r4_ab2_${name}_$N.log | cut -c1-200 | sed "s/^/$name: /"
+  env "$@" FNN_SW_LOG=1 timeout -k 10 200 python tests/tools/splits_perf.py $N > gpurun_out/sw_ab_${name}_$N.log 2>&1 || return 1
+  grep "^n=" gpurun_out/sw_ab_${name}_$N.log | cut -c1-200 | sed "s/^/$name: /"
 }
 for N in 16384 32768; do
-run A_r03ratio_revive0 FNN_SW_RATIO_POLICY=0 FNN_SW_REVIVE_MINF=0 || exit 1
-run B_r03ratio_revive8k FNN_SW_RATIO_POLICY=0 || exit 1
-run C_newratio_revive0 FNN_SW_REVIVE_MINF=0 || exit 1
-run D_r03ratio_norevive FNN_SW_RATIO_POLICY=0 FNN_SW_REVIVE=0 || exit 1
+run A_shipped || exit 1
+run B_returns_from_8192_splits FNN_SW_REVIVE_MINF=8192 || exit 1
+run D_no_returns FNN_SW_REVIVE=0 || exit 1
 done
