@@ -279,6 +279,8 @@ struct Dev {
 constexpr int CHAIN_ALT = 5;             // the second row-sum buffer of Dev.chain (see State.chain_buf)
 constexpr int CHAIN_BUFS = 6;
 constexpr int PLAN_WORDS = 128;
+constexpr int TICK_WG = 256;                      // diagnostics per workgroup of k_update (FNN_TICKS=1): sums of its start and end stamps
+constexpr int TICK_WORDS = 32 + 3 * TICK_WG;      // Dev::ticks
 constexpr int CH_T = 1024;               // threads of the chain workgroup
 constexpr int CH_EPT = 32;               // addends per thread
 constexpr int CH_SC = CH_T * CH_EPT;     // addends per super-chunk

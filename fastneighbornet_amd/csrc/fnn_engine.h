@@ -110,7 +110,7 @@ class Engine {
             !(dev.fresh = (int32_t*)be.alloc(sizeof(int32_t) * 3 * LA_KMAX)) ||
             !(dev.ticket = (uint32_t*)be.alloc(sizeof(uint32_t) * 32 * 72)) ||
             !(dev.lacnt = (int32_t*)be.alloc(256)) ||
-            !(dev.ticks = (int64_t*)be.alloc(sizeof(int64_t) * 32)) ||
+            !(dev.ticks = (int64_t*)be.alloc(sizeof(int64_t) * TICK_WORDS)) ||
             !(dev.lalog = (double*)be.alloc(sizeof(double) * 5 * LA_LOGCAP)) ||
             // k_update (deferred close) leaves {sum, sum of magnitudes} per workgroup: ceil(m / 256) + 1 workgroups;
             // -> sized from the update grid like rxpart
@@ -292,7 +292,7 @@ class Engine {
             return fail(FNN_EHIP, "fnn_begin: state upload failed (" + be.err() + ")");
         if (be.memset(dev.islot, 0xFF, sizeof(int32_t) * (3 * (size_t)(n > 0 ? n : 1) + 8)) != FNN_OK ||
             be.memset(dev.cstamp, 0, sizeof(int32_t) * (3 * (size_t)(n > 0 ? n : 1) + 8)) != FNN_OK ||
-            be.memset(dev.ticket, 0, sizeof(uint32_t) * 32 * 72) != FNN_OK || be.memset(dev.plan, 0, sizeof(uint64_t) * PLAN_WORDS) != FNN_OK || be.memset(dev.lacnt, 0, 256) != FNN_OK || be.memset(dev.ticks, 0, sizeof(int64_t) * 32) != FNN_OK)
+            be.memset(dev.ticket, 0, sizeof(uint32_t) * 32 * 72) != FNN_OK || be.memset(dev.plan, 0, sizeof(uint64_t) * PLAN_WORDS) != FNN_OK || be.memset(dev.lacnt, 0, 256) != FNN_OK || be.memset(dev.ticks, 0, sizeof(int64_t) * TICK_WORDS) != FNN_OK)
             return fail(FNN_EHIP, "fnn_begin: memset failed (" + be.err() + ")");
         if (n > 3) {
             // max |D| (error bounds of the screening pass and of the certified 4-candidate choice), the bf16 copy if wanted

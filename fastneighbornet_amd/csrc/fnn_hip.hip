@@ -2975,6 +2975,8 @@ __global__ __launch_bounds__(256) void k_update(Dev d, int defer, int ticks) {
     const int tkb = blockIdx.x == gridDim.x - 1 ? 0 : 4;
 #define UPD_TICK(slot) do { if (prof) { const long long now_ = (long long)wall_clock64(); d.ticks[8 + tkb + (slot)] += now_ - tk0; tk0 = now_; } } while (0)
     if (prof) tk0 = (long long)wall_clock64();
+    // (... and, per workgroup, the sums of its start and end stamps over the events: which workgroup ends last, and how much later)
+    const long long wg_t0 = (ticks != 0 && threadIdx.x == 0) ? (long long)wall_clock64() : 0;
     state_in(lst, st);
     __syncthreads();
     if (!lst.ev_active || lst.stall) return;
@@ -3051,6 +3053,13 @@ __global__ __launch_bounds__(256) void k_update(Dev d, int defer, int ticks) {
         d.upart[4 * blockIdx.x + k] = ((shp[0][k] + shp[1][k]) + shp[2][k]) + shp[3][k];
     }
     UPD_TICK(3);
+    if (ticks != 0 && threadIdx.x == 0) {
+        // (slot TICK_WG - 1 is the workgroup of the involved slots, whatever the grid; bulk workgroups beyond TICK_WG - 2 share a slot)
+        const int slot = blockIdx.x == gridDim.x - 1 ? TICK_WG - 1 : ((int)blockIdx.x < TICK_WG - 2 ? (int)blockIdx.x : TICK_WG - 2);
+        d.ticks[32 + slot] += wg_t0;
+        d.ticks[32 + TICK_WG + slot] += (long long)wall_clock64();
+        d.ticks[32 + 2 * TICK_WG + slot] += 1;
+    }
 #undef UPD_TICK
 }
 
@@ -3752,6 +3761,12 @@ int32_t fnn_debug_decide_ticks(fnn_handle* h, int64_t* out4) {
     FNN_NEED(h);
     if (!out4) return fnn::fail(FNN_EINVAL, "fnn_debug_decide_ticks: out4 is NULL");
     if (h->eng.be.d2h(out4, h->eng.dev.ticks + 16, sizeof(int64_t) * 4) != FNN_OK) return FNN_EHIP;
+    return FNN_OK;
+}
+int32_t fnn_debug_update_wg_ticks(fnn_handle* h, int64_t* out768) {
+    FNN_NEED(h);
+    if (!out768) return fnn::fail(FNN_EINVAL, "fnn_debug_update_wg_ticks: out768 is NULL");
+    if (h->eng.be.d2h(out768, h->eng.dev.ticks + 32, sizeof(int64_t) * 3 * fnn::TICK_WG) != FNN_OK) return FNN_EHIP;
     return FNN_OK;
 }
 int32_t fnn_debug_plan_ticks(fnn_handle* h, int64_t* out4) {

@@ -209,6 +209,10 @@ int32_t fnn_debug_decide_ticks(fnn_handle* h, int64_t* out4);
 /* ... and inside the merge plan (wave 0; all decide steps of the run, k_decide's included): {the <= 4 candidates' values and the choice,
  * the chosen nodes' ids, the slot operations of the merge (swaps / agg3way plans / moves), the window's bookkeeping for the new cluster}. */
 int32_t fnn_debug_plan_ticks(fnn_handle* h, int64_t* out4);
+/* ... and k_update per workgroup: out768[w] = sum over the events of workgroup w's start stamp, out768[256 + w] = of its end stamp,
+ * out768[512 + w] = the number of events it took part in (w = 255: the workgroup of the involved slots; bulk workgroups >= 254
+ * share slot 254): which workgroup ends last, and by how much. */
+int32_t fnn_debug_update_wg_ticks(fnn_handle* h, int64_t* out768);
 /* Relaxed mode, FNN_TICKS=1: 100 MHz ticks summed over the run in {the workgroup's row-minimum passes, their finish by
  * the control lane, the whole search kernels}, and the number of row minima computed. */
 int32_t fnn_debug_relaxed_ticks(fnn_handle* h, int64_t* out4);

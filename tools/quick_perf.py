@@ -42,6 +42,18 @@ for n in sizes:
         if tk[0] or tk[4]:
             print("k_update us/event: " + " ".join(f"{nm}={tk[i] / 100.0 / st.n_events:.2f}" for i, nm in
                   enumerate(["sp_state", "sp_load", "sp_phases", "sp_tail", "bulk_state", "bulk_-", "bulk_columns", "bulk_tail"])), flush=True)
+        if os.environ.get("FNN_TICKS"):
+            wt = (C.c_int64 * 768)()
+            a._fn("debug_update_wg_ticks", C.c_int32, [C.c_void_p, C.POINTER(C.c_int64)])
+            a.debug_update_wg_ticks(h._h, wt)
+            used = [w for w in range(256) if wt[512 + w]]
+            if used:
+                # per workgroup: average start and end, relative to the involved slots' workgroup (slot 255: it takes part in every event)
+                ref = wt[255] / wt[512 + 255]
+                rows = [(w, wt[512 + w], (wt[w] / wt[512 + w] - ref) / 100.0, (wt[256 + w] / wt[512 + w] - ref) / 100.0) for w in used]
+                print("k_update per workgroup (events: us from the start of the involved slots' workgroup to this one's start - end; the averages are over "
+                      "different sets of events, compare workgroups with similar counts): "
+                      + " ".join(f"wg{w}({c}):{a0:+.2f}..{a1:.2f}" for w, c, a0, a1 in rows[:8] + rows[-10:]), flush=True)
         gb = st.scan_bytes / 1e9
         print(f"n={n} total={st.t_total_s:.3f}s init={st.t_init_s:.4f} agglom={st.t_agglom_s:.3f} "
               f"scan={st.t_scan_s:.3f}s events={st.n_events} sumE/n^3={st.sum_entries / n**3:.4f} "
