@@ -1370,7 +1370,10 @@ struct Solver {
         const int64_t kmin = std::max<int64_t>(8, n / 32);
         int64_t k_limit = b.kmax;
         bool ratio_mode = false, done = false, good = ok, fresh = false, banned_rechecked = false;
-        const bool revive_on = envd("FNN_SW_REVIVE", 1.0) != 0.0;
+        // FNN_SW_REVIVE: 0 = departed splits only come back through a rebuild (round 3), 1 = at the start of every step, 2 = only when no
+        // candidate is left (the case that used to force a rebuild "to look again")
+        const int revive_mode = (int)envd("FNN_SW_REVIVE", 2.0);
+        const bool revive_on = revive_mode != 0;
         const int64_t revive_min_f = (int64_t)envd("FNN_SW_REVIVE_MINF", 0.0);
         bool revive_blocked = false;   // a step that only brought departed splits back did not descend: not again before a step moves
 
@@ -1416,6 +1419,7 @@ struct Solver {
                 } else drift = std::max(drift, std::fabs(g));
             }
             st_dead_wanting += dead_wanting;
+            if (revive_mode == 2 && ncand != 0) rev.clear();
             const int64_t nlive = b.f - b.r;
             int64_t k = (int64_t)std::min<double>((double)b.kmax, std::max<double>((double)kmin, kfrac * (double)std::max<int64_t>(nlive, 1)));
             k = std::max<int64_t>(1, std::min<int64_t>({k, ncand, k_limit}));
