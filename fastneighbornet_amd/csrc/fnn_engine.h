@@ -10,6 +10,7 @@
 
 #include <chrono>
 #include <climits>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -60,6 +61,8 @@ class Engine {
     int32_t comm_mode = 0, world = 1, rank = 0;
     fnn_allgather_fn host_fn = nullptr;
     void* host_ctx = nullptr;
+    int32_t* d_status = nullptr;  // several ranks over RCCL: every rank's State::error, gathered before each host round trip
+    int fault_error_rank = -1, fault_error_event = -1;  // test hook FNN_FAULT_ERROR="rank:event": an error code on one rank only
 
     bool relaxed() const { return opts.mode == FNN_MODE_RELAXED; }
 
@@ -140,7 +143,7 @@ class Engine {
 
     void destroy() {
         be.free(dev.D); be.free(dev.Sx); be.free(dev.sid); be.free(dev.spos); be.free(dev.pslot);
-        be.free(dev.chain); be.free(dev.plan); be.free(dev.recs); be.free(dev.rchk); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.wsend); be.free(dev.wrecv); be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.rperm); be.free(dev.rl_stamp); be.free(dev.rl_cnt); be.free(dev.rl_list); be.free(dev.rl_val); be.free(dev.rl_mail); be.free(dev.ticks); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
+        be.free(dev.chain); be.free(dev.plan); be.free(dev.recs); be.free(dev.rchk); be.free(dev.T); be.free(dev.gsend); be.free(dev.grecv); be.free(dev.wsend); be.free(dev.wrecv); be.free(d_status); d_status = nullptr; be.free(dev.H); be.free(dev.srec); be.free(dev.stile); be.free(dev.clist); be.free(dev.shit); be.free(dev.islot); be.free(dev.cstamp); be.free(dev.tpairs); be.free(dev.fresh); be.free(dev.ticket); be.free(dev.lacnt); be.free(dev.rperm); be.free(dev.rl_stamp); be.free(dev.rl_cnt); be.free(dev.rl_list); be.free(dev.rl_val); be.free(dev.rl_mail); be.free(dev.ticks); be.free(dev.lalog); be.free(dev.upart); be.free(dev.st); be.free(dev.evlog); be.free(dev.agglog);
         dev = Dev{};
         be.close();
     }
@@ -208,6 +211,42 @@ class Engine {
     int32_t pull_state() {
         if (be.d2h(&hst, dev.st, sizeof(State)) != FNN_OK)
             return fail(FNN_EHIP, "state download failed (" + be.err() + ")");
+        if (hst.error) return fail(FNN_ESTATE, "engine reached an unreachable branch, code " + std::to_string(hst.error));
+        return FNN_OK;
+    }
+    // Several ranks: an error in ONE rank's device state (codes 12 / 13: an exchange block of another event; any internal-consistency
+    // code) must stop EVERY rank at the same host round trip - a rank that stopped alone would leave the others waiting in their next
+    // all-gather for ever.  So the ranks exchange their error word whenever the host looks at the state: 4 bytes per
+    // rank, once per batch of events.  enqueue_status_exchange() goes on the stream BEFORE the synchronisation (RCCL transport);
+    // pull_state_ranks() after it.
+    int32_t enqueue_status_exchange() {
+        if (fault_error_rank == rank && ev_counter > fault_error_event && fault_error_event >= 0) {
+            const int32_t code = 99;
+            fault_error_event = -1;
+            if (be.sync() != FNN_OK || be.h2d((uint8_t*)dev.st + offsetof(State, error), &code, sizeof(code)) != FNN_OK)
+                return fail(FNN_EHIP, "fault injection failed (" + be.err() + ")");
+        }
+        if (comm_mode != 1) return FNN_OK;
+        if (be.allgather_bytes_on_stream((const uint8_t*)dev.st + offsetof(State, error), d_status, sizeof(int32_t)) != FNN_OK)
+            return fail(FNN_ERCCL, "all-gather of the ranks' status failed (" + be.err() + ")");
+        return FNN_OK;
+    }
+    int32_t pull_state_ranks() {
+        if (comm_mode == 0) return pull_state();
+        if (be.d2h(&hst, dev.st, sizeof(State)) != FNN_OK) return fail(FNN_EHIP, "state download failed (" + be.err() + ")");
+        std::vector<int32_t> codes((size_t)world, 0);
+        if (comm_mode == 1) {
+            if (be.d2h(codes.data(), d_status, sizeof(int32_t) * (size_t)world) != FNN_OK)
+                return fail(FNN_EHIP, "status download failed (" + be.err() + ")");
+        } else {
+            const int32_t mine = hst.error;
+            if (!host_fn || host_fn(host_ctx, &mine, codes.data(), (int32_t)sizeof(int32_t)) != 0)
+                return fail(FNN_ERCCL, "host all-gather callback failed");
+        }
+        for (int32_t r = 0; r < world; r++)
+            if (codes[(size_t)r])
+                return fail(FNN_ESTATE, "engine reached an unreachable branch, code " + std::to_string(codes[(size_t)r]) + " on rank " + std::to_string(r) +
+                                            " (every rank stops here; this is rank " + std::to_string(rank) + ")");
         if (hst.error) return fail(FNN_ESTATE, "engine reached an unreachable branch, code " + std::to_string(hst.error));
         return FNN_OK;
     }
@@ -336,12 +375,18 @@ class Engine {
         dev.world = world_;
         dev.rank = rank_;
         dev.gather = comm_mode != 0 ? 1 : 0;
-        be.free(dev.wsend); be.free(dev.wrecv);
+        be.free(dev.wsend); be.free(dev.wrecv); be.free(d_status);
         dev.wsend = dev.wrecv = nullptr;
+        d_status = nullptr;
         if (comm_mode != 0) {
             const size_t bb = (size_t)wx_block_bytes(world_);
-            if (!(dev.wsend = (uint8_t*)be.alloc(bb)) || !(dev.wrecv = (uint8_t*)be.alloc(bb * (size_t)world_)))
+            if (!(dev.wsend = (uint8_t*)be.alloc(bb)) || !(dev.wrecv = (uint8_t*)be.alloc(bb * (size_t)world_)) ||
+                !(d_status = (int32_t*)be.alloc(sizeof(int32_t) * 64)))
                 return fail(FNN_ENOMEM, "fnn_comm_init: device allocation failed (" + be.err() + ")");
+        }
+        fault_error_rank = fault_error_event = -1;
+        if (const char* e = std::getenv("FNN_FAULT_ERROR")) {  // test hook: "rank:event"
+            if (std::sscanf(e, "%d:%d", &fault_error_rank, &fault_error_event) != 2) fault_error_rank = fault_error_event = -1;
         }
         return FNN_OK;
     }
@@ -462,8 +507,10 @@ class Engine {
             }
             if (be.defer_chain && be.launch_chain_flush(dev) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
             be.defer_chain = false;
+            int32_t rc = enqueue_status_exchange();
+            if (rc != FNN_OK) return rc;
             if (be.sync() != FNN_OK) return fail(FNN_EHIP, "fnn_run: sync failed (" + be.err() + ")");
-            int32_t rc = pull_state();
+            rc = pull_state_ranks();
             if (rc != FNN_OK) return rc;
             m_bound = hst.m;
             resync_schedule();

@@ -3285,6 +3285,13 @@ struct HipBackend {
         }
         return FNN_OK;
     }
+    // (the ranks' status words before a host round trip, fnn_engine.h: enqueue_status_exchange)
+    int32_t allgather_bytes_on_stream(const void* send, void* recv, size_t bytes_per_rank) {
+        if (!rccl_comm) { comm_err = "RCCL communicator not initialised"; return FNN_ERCCL; }
+        int rc = p_ncclAllGather(send, recv, bytes_per_rank, /*ncclInt8*/ 0, rccl_comm, stream);
+        if (rc != 0) { comm_err = std::string("ncclAllGather: ") + (p_ncclGetErrorString ? p_ncclGetErrorString(rc) : "error"); return FNN_ERCCL; }
+        return FNN_OK;
+    }
     int32_t allgather_on_stream(const Dev& d, int nper) {
         if (!rccl_comm) { comm_err = "RCCL communicator not initialised"; return FNN_ERCCL; }
         int rc = p_ncclAllGather(d.gsend, d.grecv, sizeof(Cand) * (size_t)nper, /*ncclInt8*/ 0, rccl_comm, stream);

@@ -318,6 +318,7 @@ struct EmuBackend {
     }
     int32_t allgather_on_stream(const fnn::Dev&, int32_t) { return FNN_ERCCL; }  // no RCCL in the emulation
     int32_t allgather_wx_on_stream(const fnn::Dev&, size_t) { return FNN_ERCCL; }
+    int32_t allgather_bytes_on_stream(const void*, void*, size_t) { return FNN_ERCCL; }
     bool use_screen(const fnn::Dev& d, int32_t m_bound) const { return d.H != nullptr && !screen_off && m_bound >= screen_min_m; }
     // several ranks with lookahead windows: the sharded part of a base scan ... (exchange) ... merge + the rest
     int32_t launch_wx_scan(const fnn::Dev& d, int32_t) {

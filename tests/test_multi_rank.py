@@ -114,6 +114,29 @@ def test_a_give_up_on_one_rank_is_an_error_on_all_ranks(emu_api, tmp_path):
     assert all("code 12" in o for o in outs), outs
 
 
+def test_an_error_on_one_rank_stops_every_rank_at_the_same_round_trip(emu_api, tmp_path):
+    """An internal-consistency error in ONE rank's device state (injected: FNN_FAULT_ERROR=rank:event writes code 99 into rank 1's
+    state after that event) would stop that rank alone and leave the others waiting in their next exchange.  The ranks gather
+    their error words at every host round trip (fnn_engine.h: pull_state_ranks): both must raise, both naming rank 1 - no hang."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29871", WORLD_SIZE="2", FNN_FAULT_ERROR="1:40", FNN_BATCH="16")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_worker.py"), "emu", "300", "4", "uniform53", str(tmp_path)],
+                                      env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("the ranks hang after an error on one of them")
+        outs.append(o)
+    assert all(p.returncode != 0 for p in procs), outs
+    assert all("code 99 on rank 1" in o for o in outs), outs
+
+
 def test_rccl_bootstrap_fails_on_every_rank_when_one_rank_cannot_load_the_library(tmp_path):
     """distributed.bootstrap_rccl is symmetric: rank 1 is pointed at a library that does not exist; BOTH ranks must raise,
     and the message must name rank 1 (no rank may go on to ncclCommInitRank and hang there)."""
@@ -163,7 +186,8 @@ def test_hip_ranks_negative_entries_shard_every_scan(hip_api, tmp_path):
 def test_rccl_plumbing_single_rank(oracle, torch_first):
     """RCCL needs one GPU per rank, so on a one-GPU box only a 1-rank communicator can be made;
     FNN_COMM_FORCE keeps the exchange path on: dlopen, unique id, ncclCommInitRank, one
-    ncclAllGather per event on the engine's stream, ncclCommDestroy."""
+    ncclAllGather per event on the engine's stream, the all-gather of the ranks' status words at every host round trip,
+    ncclCommDestroy."""
     code = r'''
 import os, sys
 sys.path.insert(0, os.environ["FNN_ROOT"]); sys.path.insert(0, os.path.join(os.environ["FNN_ROOT"], "tests"))
@@ -187,6 +211,19 @@ with Handle(a, n) as h:   # HIP is initialised before RCCL is touched, as in ben
     h.set_matrix(D)
     order, st = h.run()
 assert (order == o_ref).all()
+# the ranks' status words travel over the same communicator before every host round trip: an error injected into the device
+# state (code 99 after event 40) must come back through ncclAllGather and be reported with its rank
+os.environ["FNN_FAULT_ERROR"] = "0:40"
+os.environ["FNN_BATCH"] = "16"
+with Handle(a, n) as h:
+    a.check(a.comm_unique_id(buf, path.encode() if path else None))
+    h.comm_init_rccl(1, 0, bytes(buf), path)
+    h.set_matrix(D)
+    try:
+        h.run()
+        raise SystemExit("the injected error was not reported")
+    except RuntimeError as e:
+        assert "code 99 on rank 0" in str(e), str(e)
 print("RCCL_OK")
 '''
     env = dict(os.environ, FNN_COMM_FORCE="1", FNN_ROOT=ROOT, FNN_TORCH_FIRST="1" if torch_first else "0")
