@@ -1060,7 +1060,9 @@ struct Solver {
         }
         }
         (void)sized(pick.f, pick.kdiv, pick.rdiv);
-        rfrac = std::min(rfrac, 0.75 * (double)b.rcap / (double)b.cap);  // (the departed columns' buffers bound how many may stay in the factor)
+        // (the departed columns' buffers bound how many may stay in the factor: up to this share of it whatever its size, and beyond
+        //  that share as long as the buffers keep room for one more block's departures - the rebuild rule in the loop below)
+        const double rfrac_buf = 0.75 * (double)b.rcap / (double)b.cap;
         if (log) std::fprintf(stderr, "  [sw] capacity %lld splits (%.2f n), block <= %lld, departed <= %lld; device memory free %.1f GB\n", (long long)b.cap,
                               (double)b.cap / n, (long long)b.kmax, (long long)b.rcap, (double)free_b * 1e-9);
         capacity = b.cap;
@@ -1376,6 +1378,7 @@ struct Solver {
         const bool revive_on = revive_mode != 0;
         const int64_t revive_min_f = (int64_t)envd("FNN_SW_REVIVE_MINF", 0.0);
         bool revive_blocked = false;   // a step that only brought departed splits back did not descend: not again before a step moves
+        bool force_rebuild = false;    // a step ran out of room for its departed columns (taken back): rebuild before the next one
 
         auto give = [&](int why, const char* text) { giveup = why; giveup_text = text; good = false; };
         int stall = 0;  // steps in a row whose descent is not measurable (below 1e-13 |objective|)
@@ -1426,8 +1429,12 @@ struct Solver {
             const bool no_cand = ncand == 0;
             if (!no_cand && b.r == 0 && b.f + k > b.cap && b.f < b.cap) k = b.cap - b.f;  // (nothing to rebuild away: fill the factor to the brim first)
             // (the drift of the gradient on the splits that are in: half of what the solver's own Kuhn-Tucker check allows at the end)
+            // (departed splits in the factor: each costs every append 4 k f flops and every departure its share of the Gram matrix; a
+            //  rebuild costs 2/3 f^3 - FNN_SW_RFRAC is the share of the factor at which the rebuild is taken)
+            const double r_limit = std::min(rfrac * (double)b.f, std::max(rfrac_buf * (double)b.f, (double)b.rcap - 1.5 * (double)k));
             if ((no_cand && rev.empty() && (wdead > tol || (drift > 5e-10 * cmax && !fresh))) ||
-                (!no_cand && (b.f + k > b.cap || (double)(b.r - (int64_t)rev.size()) > rfrac * (double)b.f))) {
+                (!no_cand && (b.f + k > b.cap || (double)(b.r - (int64_t)rev.size()) > r_limit || (force_rebuild && b.r > 0)))) {
+                force_rebuild = false;
                 // a split that left wants back in, the factor has drifted or is full of departed splits: rebuild it, solve, look again
                 if (!no_cand && b.r == 0) { give(FNN_SW_GIVEUP_CAPACITY, "the free set outgrew the dense factor"); break; }  // the caller decides about the reference's route
                 if (!refactor()) { give(FNN_SW_GIVEUP_NUMERIC, "rebuild of the factor failed"); break; }
@@ -1486,7 +1493,7 @@ struct Solver {
             const bool revived = !rev.empty();
             if (revived && !revive(rev)) { give(FNN_SW_GIVEUP_NUMERIC, "Gram factor of the departed columns failed"); break; }
             bool feasible = true;
-            if (!ratio_mode) feasible = settle_all();
+            if (!ratio_mode) { feasible = settle_all(); if (!feasible && over_rcap) force_rebuild = true; }
             else {  // Lawson & Hanson: as far towards the sub-problem's minimiser as feasibility allows; what reaches zero leaves
                 std::vector<double> xcur = xw;
                 for (;;) {
@@ -1504,7 +1511,7 @@ struct Solver {
                         xcur[p] = hit ? 0.0 : xcur[p] + alpha * (sbuf[p] - xcur[p]);
                         if (hit || (neg && !(xcur[p] > 0.0))) out.push_back((int32_t)p);
                     }
-                    if (b.r + (int64_t)out.size() > b.rcap) { feasible = false; break; }
+                    if (b.r + (int64_t)out.size() > b.rcap) { feasible = false; force_rebuild = true; break; }
                     st_dels += (int64_t)out.size();
                     for (int32_t p : out) st_dels_new += p >= f_step0 ? 1 : 0;
                     if (!depart(out)) { feasible = false; break; }
