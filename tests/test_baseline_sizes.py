@@ -31,7 +31,9 @@ BIG_CASES = [(4096, "uniform53", 1), (4096, "dec4", 1), (16384, "uniform53", 1),
              (16384, "tree", 9), (16384, "treenoise", 10), (16384, "neg", 3),
              # round 4: nearly circular distances (a circular metric with 1 % noise, tests/inputs.py: circ_noise - the class whose split
              # weights outgrow the solver's default factor) and the 4-decimal generator at 16384 taxa
-             (4096, "circnoise", 11), (8192, "circnoise", 12), (16384, "dec4", 1)]
+             (4096, "circnoise", 11), (8192, "circnoise", 12), (16384, "dec4", 1),
+             # tree + noise at the headline size (2.6 h of the oracle on 8 threads)
+             (32768, "treenoise", 11)]
 
 
 
