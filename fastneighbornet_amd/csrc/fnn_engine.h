@@ -501,11 +501,14 @@ class Engine {
             // with lookahead windows on, k_update closes the events and the exact row sum of the new
             // cluster is computed inside the next event's k_track (flushed before the host looks)
             be.defer_chain = dev.la != 0 && !std::getenv("FNN_NO_DEFER");
+            const bool graph = be.graph_batches && comm_mode == 0;
+            if (graph && be.capture_begin() != FNN_OK) return fail(FNN_EHIP, "stream capture failed (" + be.err() + ")");
             for (int i = 0; i < batch; i++) {
                 int32_t rce = enqueue_event();
                 if (rce != FNN_OK) return rce;
             }
             if (be.defer_chain && be.launch_chain_flush(dev) != FNN_OK) return fail(FNN_EHIP, "launch failed (" + be.err() + ")");
+            if (graph && be.capture_end_launch() != FNN_OK) return fail(FNN_EHIP, "graph launch failed (" + be.err() + ")");
             be.defer_chain = false;
             int32_t rc = enqueue_status_exchange();
             if (rc != FNN_OK) return rc;

@@ -3317,6 +3317,7 @@ struct HipBackend {
         if (const char* e = std::getenv("FNN_RX_HELPERS")) rx_helpers_cfg = std::atoi(e) != 0 ? TRK_NHELP : 0;
         if (const char* e = std::getenv("FNN_TRACK_GROUP")) { int v = std::atoi(e); if (v >= 2 && v <= 1024) track_group = v; }
         if (const char* e = std::getenv("FNN_FUSE")) fuse_events = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FNN_GRAPH")) graph_batches = std::atoi(e) != 0;
         if (const char* e = std::getenv("FNN_TRACK_GRID")) { int v = std::atoi(e); if (v >= 1 && v <= 1024) track_grid = v; }
         // the first-level arrival counters sit at d.ticket + 32 (g + 1), g < ceil(grid / group); word 32 * 65 is TRK_FLAG, 32 * 67
         // TRK_BAD and the array holds 32 * 72 words: at most 64 groups (the two switches are development aids, but an
@@ -3403,7 +3404,7 @@ struct HipBackend {
     // of that launch altogether, so durations and classes cannot get out of step)
     template <class F>
     void timed(int cls, bool on, F&& launch) {
-        hipEvent_t e0 = on ? next_event() : nullptr, e1 = e0 ? next_event() : nullptr;
+        hipEvent_t e0 = on && !capturing ? next_event() : nullptr, e1 = e0 ? next_event() : nullptr;
         if (e0 && !e1) ev_used--;
         if (e0 && e1) {
             ev_kind.push_back((char)cls);
@@ -3411,6 +3412,30 @@ struct HipBackend {
             launch();
             (void)hipEventRecord(e1, stream);
         } else launch();
+    }
+    // Experiment (FNN_GRAPH=1, off by default): a batch of events captured into a hipGraph and launched as one - to see what the
+    // runtime's per-dispatch handling contributes to the kernels' traced durations (the launch parameters differ from batch to batch,
+    // so every batch is captured and instantiated anew: this measures the device side, it is not a way to run faster as it stands).
+    double graph_exec_s = 0.0;
+    int graph_count = 0;
+    bool graph_batches = false, capturing = false;  // (no event records inside a capture: the scans' live timing is off in this mode)
+    int32_t capture_begin() {
+        capturing = HIPOK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        return capturing ? FNN_OK : FNN_EHIP;
+    }
+    int32_t capture_end_launch() {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        capturing = false;
+        if (!HIPOK(hipStreamEndCapture(stream, &g))) return FNN_EHIP;
+        bool fine = HIPOK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        const auto t0 = std::chrono::steady_clock::now();
+        fine = fine && HIPOK(hipGraphLaunch(ge, stream)) && HIPOK(hipStreamSynchronize(stream));
+        graph_exec_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (++graph_count % 64 == 0) std::fprintf(stderr, "[fnn] graphs: %d launched, %.4f s between launch and completion\n", graph_count, graph_exec_s);
+        if (ge) (void)hipGraphExecDestroy(ge);
+        (void)hipGraphDestroy(g);
+        return fine ? FNN_OK : FNN_EHIP;
     }
     int32_t sync() {
         if (!HIPOK(hipStreamSynchronize(stream))) return FNN_EHIP;

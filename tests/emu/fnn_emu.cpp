@@ -90,6 +90,9 @@ struct EmuBackend {
         return FNN_OK;
     }
     int32_t sync() { return FNN_OK; }
+    bool graph_batches = false;
+    int32_t capture_begin() { return FNN_OK; }
+    int32_t capture_end_launch() { return FNN_OK; }
     void collect_timing(fnn_stats&) {}
 
     int32_t launch_synth(const fnn::Dev& d, uint64_t seed, int32_t dist) {
