@@ -1435,27 +1435,29 @@ struct WaveTab {
     int lane;
     int32_t key, vsid, vspos, pkey, vpslot;
     int32_t misses;
+    // (a miss - an entry outside tab_keys' set - is not expected: the hit path is the straight-line one.  The table's writes go
+    //  out from every lane: the value is wave-uniform, and one store instruction without the exec-mask detour of "lane 0 only")
     __device__ __forceinline__ int32_t sid(int32_t s) {
         const unsigned long long hit = __ballot(key == s);
-        if (hit) return __builtin_amdgcn_readlane(vsid, (int)__builtin_ctzll(hit));
+        if (__builtin_expect(hit != 0ULL, 1)) return __builtin_amdgcn_readlane(vsid, (int)__builtin_ctzll(hit));
         misses++;
         return d.sid[s];
     }
     __device__ __forceinline__ int32_t spos(int32_t s) {
         const unsigned long long hit = __ballot(key == s);
-        if (hit) return __builtin_amdgcn_readlane(vspos, (int)__builtin_ctzll(hit));
+        if (__builtin_expect(hit != 0ULL, 1)) return __builtin_amdgcn_readlane(vspos, (int)__builtin_ctzll(hit));
         misses++;
         return d.spos[s];
     }
     __device__ __forceinline__ int32_t pslot(int32_t p) {
         const unsigned long long hit = __ballot(pkey == p);
-        if (hit) return __builtin_amdgcn_readlane(vpslot, (int)__builtin_ctzll(hit));
+        if (__builtin_expect(hit != 0ULL, 1)) return __builtin_amdgcn_readlane(vpslot, (int)__builtin_ctzll(hit));
         misses++;
         return d.pslot[p];
     }
-    __device__ __forceinline__ void set_sid(int32_t s, int32_t v) { if (key == s) vsid = v; if (lane == 0) d.sid[s] = v; }
-    __device__ __forceinline__ void set_spos(int32_t s, int32_t v) { if (key == s) vspos = v; if (lane == 0) d.spos[s] = v; }
-    __device__ __forceinline__ void set_pslot(int32_t p, int32_t v) { if (pkey == p) vpslot = v; if (lane == 0) d.pslot[p] = v; }
+    __device__ __forceinline__ void set_sid(int32_t s, int32_t v) { if (key == s) vsid = v; d.sid[s] = v; }
+    __device__ __forceinline__ void set_spos(int32_t s, int32_t v) { if (key == s) vspos = v; d.spos[s] = v; }
+    __device__ __forceinline__ void set_pslot(int32_t p, int32_t v) { if (pkey == p) vpslot = v; d.pslot[p] = v; }
 };
 
 struct DecideLds {
